@@ -1,0 +1,210 @@
+"""Pins the CPU oracle (oracle/klr_oracle.c) against the reference's own known answers
+(SURVEY.md section 8(c), G1-G7).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def test_g1_gradient_theta0(scores_data):
+    # G1: logisticRegression.Gradient at theta=0, cw=[1,1] (kmerLr_logistic_regression.go:151)
+    x, labels, _ = scores_data
+    g = O.gradient(x, labels, np.zeros(x.dim), cw=(1.0, 1.0))
+    expect = [0.06875, 3.984375, -1.009375, 0.0228125, 0.96875, 0.045625, 4.03125]
+    np.testing.assert_allclose(g[1:], expect, rtol=0, atol=1e-13)
+    assert abs(g[0]) < 1e-15  # balanced classes, sigma = 1/2
+
+
+def test_g2_first_lambda_and_picks(scores_data):
+    # G2: README.md:39  "Estimating parameters with lambda=2.496875e+00", picks columns 6 then 1
+    x, labels, _ = scores_data
+    g = O.gradient(x, labels, np.zeros(x.dim))
+    order = O.sort_abs_desc(g[1:])
+    assert list(order[:2]) == [6, 1]
+    b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+    ok, lam, c, b2 = O.select(g[1:], b, 0, 2)
+    assert ok and c == 2
+    assert "%e" % lam == "2.496875e+00"
+    assert abs(lam - 2.496875) < 1e-13
+    # G4: selected Index = {1, 6} (scoresLr_test.go:53-58); mask index = column + 1
+    assert list(np.nonzero(b2)[0]) == [0, 2, 7]
+
+
+def test_g3_loss_at_reference_theta(scores_data):
+    # G3: scoresLr_test.go:41-47,59: theta on columns (1,6), outer config.Lambda=4.647556
+    x, labels, _ = scores_data
+    red = O.select_columns(x, [0, 2, 7])
+    theta = np.array([0.842178566751775, -0.05466291047449, -0.03026279836545])
+    v = O.loss(red, labels, theta, cw=(1.0, 1.0), lam=4.647556)
+    assert abs(v - 0.813659729805629) < 1e-12
+    # and on the full-width matrix with theta scattered back
+    t = np.zeros(x.dim); t[[0, 2, 7]] = theta
+    v2 = O.loss(x, labels, t, cw=(1.0, 1.0), lam=4.647556)
+    assert abs(v2 - 0.813659729805629) < 1e-12
+
+
+def test_g6_cd_reaches_exact_optimum(scores_data):
+    # G6: exact L1 optimum at lambda = 2.496875 (SURVEY finding 4); KKT check
+    x, labels, _ = scores_data
+    red = O.select_columns(x, [0, 2, 7])
+    n = red.n
+    lam = 2.496875
+    theta, recs = O.cd_solve(red, labels, np.zeros(3), l1reg=lam * n, eps=1e-13, eps_loss=0.0, max_iter=100000)
+    np.testing.assert_allclose(theta, [0.851127187641263, -0.05490113203904316, -0.03053978552591902],
+                               rtol=1e-8)
+    obj = O.loss(red, labels, theta, lam=lam)
+    assert abs(obj - 0.6310079318548185) < 1e-12
+    g = O.gradient(red, labels, theta)
+    assert abs(g[0]) < 1e-9
+    np.testing.assert_allclose(np.abs(g[1:]), lam, rtol=1e-8)
+    # reference SAGA golden is ~1% away (early stop) but must agree at the tests' own 1e-2 level
+    np.testing.assert_allclose(theta, [0.842178566751775, -0.05466291047449, -0.03026279836545], rtol=2e-2)
+    assert len(recs) > 0 and recs[-1]["nonzero"] == 3
+
+
+def test_g7_logpdf_and_loss():
+    # G7: kmerLr_test.go:201-257: theta, both features present (fg) / absent (bg)
+    theta = np.array([-0.1000970529629098, 0.09995715710821684, 0.09995715710821684])
+    rowptr = np.concatenate([np.arange(0, 31, 3), 30 + np.arange(1, 11)]).astype(np.int64)
+    col = np.array([0, 1, 2] * 10 + [0] * 10, dtype=np.int64)
+    val = np.ones(len(col))
+    x = O.Csr(20, 3, rowptr, col, val)
+    labels = np.array([1] * 10 + [0] * 10, dtype=np.uint8)
+    assert abs(O.class_log_pdf(x, 0, theta, 1) - -0.6444834689451768) < 1e-13
+    assert abs(O.class_log_pdf(x, 10, theta, 1) - -0.744447612033651) < 1e-13
+    assert abs(O.loss(x, labels, theta) - 0.644417014007959) < 1e-13
+
+
+def test_log_add_semantics():
+    assert abs(O.log_add(0.0, 0.0) - np.log(2.0)) < 1e-15
+    assert O.log_add(0.0, -1000.0) == 0.0
+    assert O.log_add(-1000.0, 0.0) == 0.0
+    assert abs(O.log_add(0.0, 800.0) - 800.0) < 1e-12
+    assert O.log_add(-np.inf, 3.0) == 3.0
+
+
+def test_class_weights():
+    cw = O.class_weights(np.array([1, 1, 1, 0], dtype=np.uint8))
+    np.testing.assert_allclose(cw, [4 / 2.0, 4 / 6.0])
+
+
+def test_eval_stopping():
+    assert O.eval_stopping([1.0, 2.0], [1.0, 2.0], 0.0) == (True, 0.0)
+    stop, d = O.eval_stopping([1.0, 2.0], [1.0, 2.2], 0.0)
+    assert not stop and abs(d - 0.2 / 2.2) < 1e-15
+    stop, d = O.eval_stopping([0.0], [np.nan], 0.0)
+    assert stop and np.isnan(d)
+    assert O.eval_stopping([0.0, 0.0], [0.0, 0.0], 0.0)[0]
+
+
+def test_select_tie_rule_and_fill():
+    # equal |g| -> lower column first; zero-gradient columns only fill in pass 2 and do not set ok
+    g = np.array([0.5, -0.5, 0.0, 0.0, 0.25])
+    b = np.zeros(6, dtype=np.uint8); b[0] = 1
+    ok, lam, c, b2 = O.select(g, b, 0, 2)
+    assert ok and c == 2 and list(np.nonzero(b2)[0]) == [0, 1, 2]
+    assert lam == (0.5 + 0.25) / 2
+    ok, lam, c, b2 = O.select(g, b, 0, 4)
+    assert c == 4 and list(np.nonzero(b2)[0]) == [0, 1, 2, 3, 5]
+    # N > m  -> lambda 0 (kmerLr_feature_selection.go:180-182)
+    ok, lam, c, b2 = O.select(g, b, 0, 9)
+    assert lam == 0.0 and c == 5
+
+
+def test_select_fixed(scores_data):
+    x, labels, _ = scores_data
+    g = O.gradient(x, labels, np.zeros(x.dim))
+    b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+    ok, c, b2 = O.select_fixed(g, b, 0, 1.0)
+    assert ok and list(np.nonzero(b2)[0]) == [0, 2, 3, 7]
+    ok, c, b2 = O.select_fixed(g, b, 0, 1.0, max_features=1)
+    assert ok and list(np.nonzero(b2)[0]) == [0, 2]
+
+
+def test_select_columns_sparse_and_transform():
+    x, labels = O.synth_csr(7, 0, 50, 50, 64, 40, 4)
+    cols = np.array([0, 3, 9, 17, 40], dtype=np.int64)
+    red = O.select_columns(x, cols)
+    d, dr = x.to_dense(), red.to_dense()
+    np.testing.assert_array_equal(dr, d[:, cols])
+    assert all(red.col[red.rowptr[i]] == 0 for i in range(red.n))
+    assert np.all(red.val != 0.0)
+    scale = np.array([1.0, 2.0, 0.5, 3.0, 4.0])
+    reds = O.select_columns(x, cols, scale=scale)
+    np.testing.assert_allclose(reds.to_dense(), d[:, cols] * scale)
+    off = np.array([0.0, 0.1, 0.2, 0.3, 0.4])
+    redo = O.select_columns(x, cols, scale=scale, offset=off)
+    np.testing.assert_allclose(redo.to_dense(), (d[:, cols] - off) * scale)
+    assert redo.nnz == 50 * 5
+
+
+def test_gradient_transform_matches_transformed_data():
+    x, labels = O.synth_csr(11, 0, 60, 60, 32, 30, 4)
+    rng = np.random.default_rng(0)
+    theta = rng.normal(size=x.dim) * 0.1
+    scale = rng.uniform(0.5, 2.0, size=x.dim); scale[0] = 1.0
+    off = rng.uniform(-0.2, 0.2, size=x.dim); off[0] = 0.0
+    cw = O.class_weights(labels)
+    for sc, of in ((scale, None), (scale, off)):
+        g = O.gradient(x, labels, theta, cw=cw, scale=sc, offset=of)
+        xt = O.select_columns(x, np.arange(x.dim), scale=sc, offset=of)
+        g2 = O.gradient(xt, labels, theta, cw=cw)
+        np.testing.assert_allclose(g, g2, rtol=1e-12, atol=1e-15)
+        l1 = O.loss(x, labels, theta, cw=cw, lam=0.01, scale=sc, offset=of)
+        l2 = O.loss(xt, labels, theta, cw=cw, lam=0.01)
+        assert abs(l1 - l2) < 1e-13
+
+
+def test_gradient_is_derivative_of_loss():
+    x, labels = O.synth_csr(3, 0, 40, 40, 16, 20, 4)
+    rng = np.random.default_rng(1)
+    theta = rng.normal(size=x.dim) * 0.05
+    cw = O.class_weights(labels)
+    g = O.gradient(x, labels, theta, cw=cw)
+    for j in (0, 1, 5, 16):
+        e = np.zeros(x.dim); e[j] = 1e-6
+        num = (O.loss(x, labels, theta + e, cw=cw) - O.loss(x, labels, theta - e, cw=cw)) / 2e-6
+        assert abs(num - g[j]) < 1e-8
+
+
+def test_synth_generator_properties():
+    x, labels = O.synth_csr(20261004, 0, 200, 200, 4096, 993, 20)
+    assert labels[:100].all() and not labels[100:].any()
+    for i in range(x.n):
+        s, e = x.rowptr[i], x.rowptr[i + 1]
+        assert x.col[s] == 0 and x.val[s] == 1.0
+        assert np.all(np.diff(x.col[s:e]) > 0)
+        assert x.val[s + 1:e].sum() == 993
+    # shard independence: rows generated with an offset equal the slice of the whole
+    y, ly = O.synth_csr(20261004, 50, 30, 200, 4096, 993, 20)
+    s, e = x.rowptr[50], x.rowptr[80]
+    np.testing.assert_array_equal(y.col, x.col[s:e])
+    np.testing.assert_array_equal(y.val, x.val[s:e])
+    np.testing.assert_array_equal(ly, labels[50:80])
+    # planted signal: fg motifs (even k) are enriched in fg rows
+    motifs = O.synth_motifs(20261004, 4096, 20)
+    assert len(set(motifs.tolist())) == 20
+    d = x.to_dense()
+    fg_m = d[:100][:, motifs[0::2] + 1].sum(); bg_m = d[100:][:, motifs[0::2] + 1].sum()
+    assert fg_m > 5 * max(bg_m, 1)
+
+
+def test_cd_solve_kkt_on_synthetic():
+    x, labels = O.synth_csr(5, 0, 300, 300, 256, 200, 8)
+    cw = O.class_weights(labels)
+    g = O.gradient(x, labels, np.zeros(x.dim), cw=cw)
+    b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+    ok, lam, c, b2 = O.select(g[1:], b, 0, 6)
+    cols = np.nonzero(b2)[0]
+    red = O.select_columns(x, cols)
+    theta, recs = O.cd_solve(red, labels, np.zeros(len(cols)), cw=cw, l1reg=lam * x.n,
+                             eps=1e-12, eps_loss=0.0, max_iter=100000)
+    gr = O.gradient(red, labels, theta, cw=cw)
+    assert abs(gr[0]) < 1e-7
+    for j in range(1, len(cols)):
+        if theta[j] != 0.0:
+            assert abs(gr[j] + lam * np.sign(theta[j])) < 1e-7
+        else:
+            assert abs(gr[j]) <= lam + 1e-7
+    losses = [r["loss"] for r in recs]
+    assert losses[-1] <= losses[0]
