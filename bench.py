@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- full-width coordinate sweep of kmerLr's L1-LR hot path on MI355X.
+
+One "step" = one leapfrog epoch's full-width pass (klr_sweep_select): X.theta / sigmoid / log-loss
+over the rows (from the reduced matrix of the current theta), the per-feature gradient sweep
+g = X'(cw (sigma - y))/n over the full CSC k-mer matrix, ONE all-reduce of [g | loss] across ranks,
+and the top-2N |g| selection + lambda rule.  Inputs are resident in HBM before the timed region.
+
+Workload (BASELINE.json configs[2]): synthetic 100k sequences x 65,536 8-mers per GPU (weak
+scaling: rows grow with N), --lambda-auto=100, theta on 100 selected columns.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20261004
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows-per-gpu", type=int, default=100000)
+    ap.add_argument("--features", type=int, default=65536)
+    ap.add_argument("--draws", type=int, default=993)
+    ap.add_argument("--lambda-auto", type=int, default=100)
+    ap.add_argument("--cpu-baseline-rows", type=int, default=4000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cd-sweeps", type=int, default=200, help="reduced-problem CD sweeps timed for cd_sweeps_per_s")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import kmerlr_amd as K
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_local, m, draws, N = args.rows_per_gpu, args.features, args.draws, args.lambda_auto
+    n_total = n_local * world
+    S = 2 * N
+
+    ctx = K.Context(local_rank)
+    if world > 1:
+        # RCCL communicator owned by the library: one all-reduce per sweep on the library's stream
+        ids = [K.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.init_rccl(ids[0], rank, world)
+
+    # ---- synthetic shard, generated on the host and moved to HBM once -------------------------------
+    t0 = time.time()
+    rowptr, col, val, labels = K.synth_csr(SEED, rank * n_local, n_local, n_total, m, draws, S)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    full = K.Matrix.from_csr(ctx, n_local, m + 1, rowptr, col, val, labels, n_total)
+    ctx.synchronize()
+    t_up = time.time() - t0
+    nnz = full.nnz
+    cw = full.class_weights()
+
+    # ---- a realistic mid-path state: epoch 0 selection, reduced matrix, solved theta ------------------
+    r0 = K.sweep_select(ctx, full, None, None, np.zeros(1), cw, N)
+    cols = np.nonzero(r0["b"])[0]
+    red = full.select_columns(cols)
+    t0 = time.time()
+    theta, recs = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=r0["lam"] * n_total, eps_loss=1e-8)
+    t_solve = time.time() - t0
+    n_sweeps_solve = len(recs)
+
+    def step():
+        return K.sweep_select(ctx, full, red, cols, theta, cw, N, lambda_prev=r0["lam"] * n_total)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ctx.prof_enable(True)
+    ctx.prof_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    launches, kern_ms = ctx.prof_read(reset=True)
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- reduced-problem CD sweep rate (sweeps/s) ------------------------------------------------------
+    t0 = time.perf_counter()
+    _, recs2 = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=r0["lam"] * n_total, eps=0.0, eps_loss=0.0,
+                          eval_loss=True, max_iter=args.cd_sweeps)
+    t_cd = time.perf_counter() - t0
+    cd_sweeps_per_s = len(recs2) / t_cd if t_cd > 0 else 0.0
+
+    ms_per_step = dt / args.steps * 1e3
+    value = float(n_total) * float(m) / (dt / args.steps)          # samples x features / s, whole job
+
+    # ---- roofline of the dominant kernel (column sweep k_xt_s), per launch ----------------------------
+    # single pass over the CSC: 4 B row id + 4 B f32 value per stored nonzero (padded), chunk table,
+    # s gathered once per row (8 B), g written once per column (8 B)
+    alg_bytes = 8.0 * nnz + 12.0 * (m + 1) + 8.0 * n_local + 8.0 * (m + 1)
+    kern_avg_ms = kern_ms / max(launches, 1)
+    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_xt_s<float,64>", "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "survey_two_pass_bytes": two_pass_bytes,
+                "survey_two_pass_equiv_gbs": round(two_pass_bytes / (kern_avg_ms * 1e-3) / 1e9, 1) if kern_avg_ms > 0 else 0.0}
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        cpu_baseline = cpu_baseline_leg(args, theta, cols, cw)
+
+    if rank == 0:
+        line = {
+            "metric": "samples_x_features_per_s (full-width coordinate sweep: X.theta/sigmoid/loss + per-feature gradient + select)",
+            "value": value, "unit": "samples*features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic %d seqs/GPU x %d 8-mer columns, %d draws/row, --lambda-auto=%d "
+                                   "(BASELINE configs[2])" % (n_local, m, draws, N),
+                       "rows_per_gpu": n_local, "rows_total": n_total, "features": m, "nnz_per_gpu": nnz,
+                       "selected": int(len(cols) - 1), "parallelism": "row-shards x%d, 1 RCCL all-reduce of m+2 f64 per sweep" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "cd_sweeps_per_s": round(cd_sweeps_per_s, 1),
+            "cd_solve": {"sweeps_to_converge": n_sweeps_solve, "seconds": round(t_solve, 4), "nonzero": int(np.count_nonzero(theta[1:]))},
+            "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]},
+            "setup_s": {"generate": round(t_gen, 2), "ingest_upload": round(t_up, 2)},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline_leg(args, theta, cols, cw):
+    """Times the CPU restatement of the reference path (oracle/, plain C, 1 core, reference loop
+    order and 16 B/nnz row layout) on a bounded sample of the same workload: the first rows of the
+    same synthetic matrix, same theta; one step = Gradient (a4) + Select (a6/a7)."""
+    from oracle import oracle as O
+    nr = args.cpu_baseline_rows
+    m, draws, N = args.features, args.draws, args.lambda_auto
+    x, labels = O.synth_csr(SEED, 0, nr, nr, m, draws, 2 * N)
+    th = np.zeros(m + 1)
+    th[cols] = theta
+    reps, t_tot = 0, 0.0
+    while t_tot < 10.0 and reps < 50:
+        t0 = time.perf_counter()
+        g = O.gradient(x, labels, th, cw=cw)
+        b = np.zeros(m + 1, dtype=np.uint8); b[0] = 1
+        O.select(g[1:], b, 0, N)
+        t_tot += time.perf_counter() - t0
+        reps += 1
+    per = t_tot / reps
+    return {"value": float(nr) * float(m) / per, "unit": "samples*features/s", "cores": 1, "kind": "port",
+            "sample": "first %d rows of the same synthetic matrix (%d nnz), %d repetitions of Gradient+Select, "
+                      "CPU restatement of the Go loops (oracle/klr_oracle.c), 1 thread" % (nr, x.nnz, reps),
+            "ms_per_step_sample": per * 1e3}
+
+
+if __name__ == "__main__":
+    main()

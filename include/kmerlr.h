@@ -1,0 +1,171 @@
+/*
+ * kmerlr.h -- C ABI of libkmerlr_hip.so: the MI355X (gfx950) implementation of kmerLr's
+ * L1 logistic-regression hot path.  Plain pointers and sizes only; no torch/HIP types.
+ *
+ * The reference (pbenner/kmerLr @ v1, Go) has no FFI; the path sits behind Go method calls.
+ * Each entry point below names the reference call site it replaces (file:line relative to
+ * the reference tree).  INTEGRATION.md shows the cgo stub a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a nonzero KLR_E* code otherwise;
+ *     klr_last_error(ctx) gives the message (ctx may be NULL for creation failures).
+ *   - a klr_ctx is bound to one GPU and one HIP stream and is single-threaded; use one ctx
+ *     per concurrent estimator (the reference runs one estimator per ensemble member / CV fold:
+ *     kmerLr_estimator_ensemble.go:81, kmerLr_crossvalidation.go:176).
+ *   - host buffers stay caller-owned; matrices are copied to HBM at creation
+ *     (the reference's solver keeps references to caller rows instead, kmerLr_estimator.go:152).
+ *   - rows use the reference layout: per row ascending column ids, col[rowptr[i]] == 0 is the
+ *     bias entry with value 1.0 (kmerLr_data.go:199-200, scoresLr_data.go:108-117).
+ *   - there is NO CPU fallback: without a HIP device klr_ctx_create fails.
+ *
+ * Sharding: a matrix holds rows [row0, row0+n) of a data set with n_total rows.  Every
+ * quantity that is a sum over samples (gradient, loss, Gram) is computed as a local partial,
+ * passed through the ctx's all-reduce hook (klr_ctx_set_allreduce / klr_ctx_init_rccl) if one
+ * is installed, and finished identically on every rank.
+ */
+#ifndef KMERLR_H
+#define KMERLR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLR_OK          0
+#define KLR_EINVAL      1   /* bad argument (the reference panics "internal error")      */
+#define KLR_EHIP        2   /* HIP runtime error                                          */
+#define KLR_ENODEV      3   /* no usable gfx950 device                                    */
+#define KLR_ENOMEM      4
+#define KLR_ECOMM       5   /* all-reduce hook / RCCL failure                             */
+
+typedef struct klr_ctx klr_ctx;
+typedef struct klr_mat klr_mat;
+
+/* ---- context ------------------------------------------------------------------------- */
+int         klr_ctx_create(int device_id, klr_ctx** out);
+void        klr_ctx_destroy(klr_ctx* ctx);
+const char* klr_last_error(const klr_ctx* ctx);
+/* run the ctx's kernels on an existing HIP stream (hipStream_t passed as void*); NULL = the
+ * ctx's own stream.  Lets a host (e.g. torch) order its own work against the kernels. */
+int         klr_ctx_set_stream(klr_ctx* ctx, void* hip_stream);
+int         klr_ctx_synchronize(klr_ctx* ctx);
+
+/* all-reduce hook: sums `count` doubles in place across ranks.  `buf` is a DEVICE pointer; the
+ * call is made after the producing kernels were enqueued on the ctx stream (also passed, as
+ * void*), and the hook must leave the result visible to later work on that stream. */
+typedef int (*klr_allreduce_fn)(void* user, void* dev_buf, int64_t count, void* hip_stream);
+int         klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* user, int rank, int nranks);
+/* built-in hook: RCCL over xGMI.  id = 128-byte ncclUniqueId obtained on rank 0 with
+ * klr_rccl_unique_id and distributed by the launcher. */
+int         klr_rccl_unique_id(void* id128);
+int         klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int nranks);
+
+/* ---- sparse k-mer / score matrix ------------------------------------------------------- */
+/* Replaces the []ConstVector the reference hands to SetSparseData (kmerLr_estimator.go:152)
+ * and to featureSelector.gradient (kmerLr_feature_selection.go:221-229).
+ * n rows of dimension dim = m+1; n_total = rows of the whole data set (0: = n). */
+int  klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int64_t* rowptr,
+                      const int64_t* col, const double* val, const uint8_t* labels,
+                      int64_t n_total, klr_mat** out);
+void klr_mat_destroy(klr_mat* mat);
+int  klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total);
+/* copy a (reduced) matrix back in the reference layout; any output pointer may be NULL.
+ * col/val need klr_mat_shape's nnz entries. */
+int  klr_mat_to_csr(klr_ctx* ctx, const klr_mat* mat, int64_t* rowptr, int64_t* col, double* val);
+
+/* compute_class_weights (kmerLr_data.go:178-193) over the (all-reduced) label counts */
+int  klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2]);
+
+/* ---- L1: logistic-regression arithmetic ------------------------------------------------ */
+/* logisticRegression.Gradient with Lambda = 0 as called by featureSelector.gradient
+ * (kmerLr_logistic_regression.go:151-248; kmerLr_feature_selection.go:221-229).
+ * theta is given sparse: th_idx ascending column ids (may include 0), th_val, th_nnz.
+ * scale/offset: TransformFull vectors of length dim or NULL (kmerLr_transform.go:260-268).
+ * g_out: host, length dim. */
+int  klr_gradient(klr_ctx* ctx, const klr_mat* mat, const int64_t* th_idx, const double* th_val,
+                  int64_t th_nnz, const double cw[2], const double* scale, const double* offset,
+                  double* g_out);
+/* logisticRegression.Loss (kmerLr_logistic_regression.go:250-272); theta dense, length dim;
+ * lambda NaN or 0 = no L1 term. */
+int  klr_loss(klr_ctx* ctx, const klr_mat* mat, const double* theta, const double cw[2],
+              double lambda, double* loss_out);
+/* LinearPdf / LogPdf per row (kmerLr_logistic_regression.go:47-149; predict path
+ * kmerLr_classifier.go): out[i] = log sigma(x_i . theta) for the local rows. */
+int  klr_log_pdf(klr_ctx* ctx, const klr_mat* mat, const double* theta, double* out);
+
+/* ---- L3: feature selection -------------------------------------------------------------- */
+/* featureSelector.Select + computeLambda + NLargestAbsFloat64
+ * (kmerLr_feature_selection.go:78-134,179-192; kmerLr_sort.go:120-131).
+ *   g        gradient[1:], host, length m
+ *   b        in/out mask, length m+1 (b[0] = 1 bias; b[j+1] = 1 where theta_j != 0)
+ *   c_prev   nonzero non-bias coefficients restored; N = number of features to select
+ *   lambda_prev, eps_lambda: the `ok` rule of :133
+ * Tie rule (the reference's unstable sort leaves it open): larger |g| first, then LOWER
+ * column index. */
+int  klr_select(klr_ctx* ctx, const double* g, int64_t m, uint8_t* b, int64_t c_prev, int64_t N,
+                double lambda_prev, double eps_lambda,
+                double* lambda_out, int64_t* c_out, int* ok_out);
+/* featureSelector.SelectFixed (kmerLr_feature_selection.go:136-159); g_full has length m+1 */
+int  klr_select_fixed(klr_ctx* ctx, const double* g_full, int64_t m, uint8_t* b, int64_t c_prev,
+                      double lambda, int64_t max_features, int64_t* c_out, int* ok_out);
+/* featureSelection.Data followed by Transform.Apply (kmerLr_feature_selection.go:309-343,
+ * kmerLr_transform.go:584-629): cols = ascending selected column ids incl. 0; scale/offset are
+ * the SELECTED transform vectors (length c_plus_1) or NULL. */
+int  klr_mat_select_columns(klr_ctx* ctx, const klr_mat* full, const int64_t* cols, int64_t c_plus_1,
+                            const double* scale, const double* offset, klr_mat** reduced);
+
+/* ---- fused leapfrog epoch step (device resident) ----------------------------------------- */
+/* One full-width sweep as the leapfrog driver needs it (kmerLr_estimator.go:235):
+ * X.theta / sigmoid / loss from the REDUCED matrix of the previous epoch (theta lives on its
+ * columns), per-feature gradient over the FULL matrix, one all-reduce of [g | loss], then
+ * top-2N selection and lambda on the device.  reduced may be NULL (theta = theta0 on the bias
+ * only, first epoch).  red_cols[c_plus_1] maps reduced columns to full columns.
+ * Outputs as klr_select; picked_out (length >= min(m,2N)) receives the sorted candidate
+ * columns (0-based feature ids), loss_out the mean log-loss without penalty. */
+int  klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat* reduced,
+                      const int64_t* red_cols, const double* theta_red, int64_t c_plus_1,
+                      const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
+                      uint8_t* b, double* lambda_out, int64_t* c_out, int* ok_out,
+                      double* loss_out, double* g_out /* nullable, length dim */);
+
+/* ---- L2: solver -------------------------------------------------------------------------- */
+/* hook record, kmerLr_estimator_hook.go:46-99 / Trace.Append (kmerLr_estimator_trace.go:80) */
+typedef struct {
+  int32_t iteration;
+  int32_t nonzero;    /* nonzero coefficients incl. bias */
+  double  change;     /* eval_stopping delta */
+  double  lambda;     /* l1reg / n_total */
+  double  loss;       /* NaN when eval_loss == 0 */
+  double  seconds;
+} klr_iter_rec;
+
+/* IRLS + covariance-update cyclic coordinate descent with soft threshold: the algorithm of
+ * estimate_coordinate / estimate_coordinate_loop (kmerLr_estimator_coordinate.go:31-139),
+ * eval_stopping (kmerLr_estimator_proximal.go:30-52) and the hook's loss rule
+ * (kmerLr_estimator_hook.go:94-98).  Takes the place of SetSparseData/Estimate/GetEstimate
+ * (kmerLr_estimator.go:152-164).  theta: in warm start, out estimate, length dim(reduced).
+ * l1reg = lambda * n_total.  recs may be NULL. */
+int  klr_cd_solve(klr_ctx* ctx, const klr_mat* reduced, double* theta, const double cw[2],
+                  double l1reg, double l2reg, double eps, double eps_loss, int eval_loss,
+                  int64_t max_iter, klr_iter_rec* recs, int64_t recs_cap, int64_t* n_recs);
+
+/* ---- synthetic workload (bench / tests) ----------------------------------- */
+/* rows [row0,row0+n_local) of the deterministic synthetic k-mer count matrix, reference layout.
+ * col/val need n_local*(draws+1) entries. */
+int  klr_synth_csr(uint64_t seed, int64_t row0, int64_t n_local, int64_t n_total, int64_t m,
+                   int64_t draws, int64_t S, int64_t* rowptr, int64_t* col, double* val,
+                   uint8_t* labels, int threads);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* HIP-event timing of the dominant kernel (the full-width column sweep) on the ctx stream:
+ * accumulated since the last reset.  Events are recorded only while enabled. */
+int  klr_prof_enable(klr_ctx* ctx, int on);
+int  klr_prof_read(klr_ctx* ctx, int64_t* launches, double* total_ms, int reset);
+
+const char* klr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,7 @@
+"""kmerlr_amd -- MI355X (gfx950) implementation of kmerLr's L1 logistic-regression hot path.
+
+The product is libkmerlr_hip.so (C ABI in include/kmerlr.h); this package is the thin Python
+plumbing around it (ctypes binding, torch.distributed launcher glue).  There is no CPU fallback.
+"""
+from ._capi import (Context, Matrix, KlrError, gradient, gradient_dense, loss, log_pdf, select,  # noqa: F401
+                    select_fixed, sweep_select, cd_solve, synth_csr, rccl_unique_id, lib, LIB_PATH, SIGNATURES)

@@ -1,0 +1,292 @@
+"""ctypes binding of include/kmerlr.h (libkmerlr_hip.so).  There is no fallback: if the library is
+missing or no gfx950 device is present, every entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libkmerlr_hip.so")
+_lib = None
+
+
+class KlrError(RuntimeError):
+    pass
+
+
+class IterRec(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("nonzero", C.c_int32), ("change", C.c_double),
+                ("lambda_", C.c_double), ("loss", C.c_double), ("seconds", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+# name -> (restype, argtypes); also the export list checked by tests/test_abi.py
+_vp, _i64, _dbl, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
+_PVP = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "klr_ctx_create": (_int, [_int, _PVP]),
+    "klr_ctx_destroy": (None, [_vp]),
+    "klr_last_error": (C.c_char_p, [_vp]),
+    "klr_ctx_set_stream": (_int, [_vp, _vp]),
+    "klr_ctx_synchronize": (_int, [_vp]),
+    "klr_ctx_set_allreduce": (_int, [_vp, ALLREDUCE_FN, _vp, _int, _int]),
+    "klr_rccl_unique_id": (_int, [_vp]),
+    "klr_ctx_init_rccl": (_int, [_vp, _vp, _int, _int]),
+    "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
+    "klr_mat_destroy": (None, [_vp]),
+    "klr_mat_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "klr_mat_to_csr": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "klr_class_weights": (_int, [_vp, _vp, _vp]),
+    "klr_gradient": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "klr_loss": (_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(_dbl)]),
+    "klr_log_pdf": (_int, [_vp, _vp, _vp, _vp]),
+    "klr_select": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _dbl, _dbl, C.POINTER(_dbl), C.POINTER(_i64),
+                          C.POINTER(_int)]),
+    "klr_select_fixed": (_int, [_vp, _vp, _i64, _vp, _i64, _dbl, _i64, C.POINTER(_i64), C.POINTER(_int)]),
+    "klr_mat_select_columns": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _PVP]),
+    "klr_sweep_select": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _vp, C.POINTER(_dbl),
+                                C.POINTER(_i64), C.POINTER(_int), C.POINTER(_dbl), _vp]),
+    "klr_cd_solve": (_int, [_vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _int, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "klr_synth_csr": (_int, [C.c_uint64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int]),
+    "klr_prof_enable": (_int, [_vp, _int]),
+    "klr_prof_read": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl), _int]),
+    "klr_version": (C.c_char_p, []),
+}
+
+
+def lib():
+    """Loads libkmerlr_hip.so; raises if it has not been built (python -m kmerlr_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KlrError("libkmerlr_hip.so is missing (%s): build it with `python -m kmerlr_amd.build`; "
+                           "there is no CPU fallback" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  (one HIP runtime per process: let torch's copy load first)
+        except Exception:  # pragma: no cover
+            pass
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _check(ctx_handle, rc):
+    if rc != 0:
+        msg = lib().klr_last_error(ctx_handle)
+        raise KlrError("kmerlr error %d: %s" % (rc, (msg or b"").decode()))
+
+
+class Context:
+    """klr_ctx: one GPU, one stream, single-threaded."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        rc = lib().klr_ctx_create(device_id, C.byref(self._h))
+        if rc != 0:
+            raise KlrError("klr_ctx_create failed (%d): %s" % (rc, (lib().klr_last_error(None) or b"").decode()))
+        self._cb = None
+
+    def close(self):
+        if self._h:
+            lib().klr_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        _check(self._h, rc)
+
+    def synchronize(self):
+        self.check(lib().klr_ctx_synchronize(self._h))
+
+    def set_stream(self, stream_ptr):
+        self.check(lib().klr_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_allreduce(self, fn, rank, nranks):
+        """fn(dev_ptr:int, count:int, stream:int) -> None, sums `count` doubles in place."""
+        def tramp(user, buf, count, stream):
+            try:
+                fn(buf, count, stream)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allreduce hook failed:", e)
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        self.check(lib().klr_ctx_set_allreduce(self._h, self._cb, None, rank, nranks))
+
+    def init_rccl(self, unique_id: bytes, rank, nranks):
+        buf = C.create_string_buffer(unique_id, 128)
+        self.check(lib().klr_ctx_init_rccl(self._h, buf, rank, nranks))
+
+    def prof_enable(self, on=True):
+        self.check(lib().klr_prof_enable(self._h, int(on)))
+
+    def prof_read(self, reset=True):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        self.check(lib().klr_prof_read(self._h, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, ms.value
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().klr_rccl_unique_id(buf)
+    if rc != 0:
+        raise KlrError("klr_rccl_unique_id failed: %s" % (lib().klr_last_error(None) or b"").decode())
+    return buf.raw
+
+
+class Matrix:
+    """klr_mat: rows [row0,row0+n) of the data set, resident in HBM as CSR + padded CSC."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h = ctx, handle
+        n, dim, nnz, nt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        ctx.check(lib().klr_mat_shape(self._h, C.byref(n), C.byref(dim), C.byref(nnz), C.byref(nt)))
+        self.n, self.dim, self.nnz, self.n_total = n.value, dim.value, nnz.value, nt.value
+
+    @staticmethod
+    def from_csr(ctx, n, dim, rowptr, col, val, labels, n_total=0):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(lib().klr_mat_from_csr(ctx._h, n, dim, _p(rowptr), _p(col), _p(val), _p(labels), n_total, C.byref(h)))
+        return Matrix(ctx, h)
+
+    def close(self):
+        if self._h:
+            lib().klr_mat_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def to_csr(self):
+        rowptr = np.zeros(self.n + 1, dtype=np.int64)
+        col = np.zeros(max(self.nnz, 1), dtype=np.int64)
+        val = np.zeros(max(self.nnz, 1), dtype=np.float64)
+        self.ctx.check(lib().klr_mat_to_csr(self.ctx._h, self._h, _p(rowptr), _p(col), _p(val)))
+        return rowptr, col[:self.nnz], val[:self.nnz]
+
+    def class_weights(self):
+        cw = np.zeros(2)
+        self.ctx.check(lib().klr_class_weights(self.ctx._h, self._h, _p(cw)))
+        return cw
+
+    def select_columns(self, cols, scale=None, offset=None):
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        scale, offset = _f64(scale), _f64(offset)
+        h = C.c_void_p()
+        self.ctx.check(lib().klr_mat_select_columns(self.ctx._h, self._h, _p(cols), len(cols), _p(scale), _p(offset),
+                                                    C.byref(h)))
+        return Matrix(self.ctx, h)
+
+
+def gradient(ctx, mat, theta_idx, theta_val, cw=(1.0, 1.0), scale=None, offset=None):
+    idx = np.ascontiguousarray(theta_idx, dtype=np.int64)
+    tv = _f64(theta_val)
+    cw, scale, offset = _f64(cw), _f64(scale), _f64(offset)
+    g = np.zeros(mat.dim)
+    ctx.check(lib().klr_gradient(ctx._h, mat._h, _p(idx), _p(tv), len(idx), _p(cw), _p(scale), _p(offset), _p(g)))
+    return g
+
+
+def gradient_dense(ctx, mat, theta, cw=(1.0, 1.0), scale=None, offset=None):
+    theta = _f64(theta)
+    idx = np.nonzero(theta)[0]
+    return gradient(ctx, mat, idx, theta[idx], cw, scale, offset)
+
+
+def loss(ctx, mat, theta, cw=(1.0, 1.0), lam=0.0):
+    theta, cw = _f64(theta), _f64(cw)
+    assert theta.shape == (mat.dim,)
+    out = C.c_double(0.0)
+    ctx.check(lib().klr_loss(ctx._h, mat._h, _p(theta), _p(cw), lam, C.byref(out)))
+    return out.value
+
+
+def log_pdf(ctx, mat, theta):
+    theta = _f64(theta)
+    out = np.zeros(mat.n)
+    ctx.check(lib().klr_log_pdf(ctx._h, mat._h, _p(theta), _p(out)))
+    return out
+
+
+def select(ctx, g, b, c_prev, N, lambda_prev=0.0, eps_lambda=0.0):
+    g = _f64(g)
+    b = np.array(b, dtype=np.uint8, copy=True)
+    lam, c, ok = C.c_double(0.0), C.c_int64(0), C.c_int(0)
+    ctx.check(lib().klr_select(ctx._h, _p(g), len(g), _p(b), c_prev, N, lambda_prev, eps_lambda,
+                               C.byref(lam), C.byref(c), C.byref(ok)))
+    return bool(ok.value), lam.value, c.value, b
+
+
+def select_fixed(ctx, g_full, b, c_prev, lam, max_features=0):
+    g_full = _f64(g_full)
+    b = np.array(b, dtype=np.uint8, copy=True)
+    c, ok = C.c_int64(0), C.c_int(0)
+    ctx.check(lib().klr_select_fixed(ctx._h, _p(g_full), len(g_full) - 1, _p(b), c_prev, lam, max_features,
+                                     C.byref(c), C.byref(ok)))
+    return bool(ok.value), c.value, b
+
+
+def sweep_select(ctx, full, reduced, red_cols, theta_red, cw, N, lambda_prev=0.0, eps_lambda=0.0, want_g=False):
+    """Returns dict(ok, lam, c, b, loss, g)."""
+    theta_red, cw = _f64(theta_red), _f64(cw)
+    red_cols = None if red_cols is None else np.ascontiguousarray(red_cols, dtype=np.int64)
+    b = np.zeros(full.dim, dtype=np.uint8)
+    g = np.zeros(full.dim) if want_g else None
+    lam, c, ok, ls = C.c_double(0.0), C.c_int64(0), C.c_int(0), C.c_double(0.0)
+    ctx.check(lib().klr_sweep_select(ctx._h, full._h, None if reduced is None else reduced._h, _p(red_cols),
+                                     _p(theta_red), len(theta_red), _p(cw), N, lambda_prev, eps_lambda, _p(b),
+                                     C.byref(lam), C.byref(c), C.byref(ok), C.byref(ls), _p(g)))
+    return dict(ok=bool(ok.value), lam=lam.value, c=c.value, b=b, loss=ls.value, g=g)
+
+
+def cd_solve(ctx, red, theta, cw=(1.0, 1.0), l1reg=0.0, l2reg=0.0, eps=0.0, eps_loss=1e-8, eval_loss=True,
+             max_iter=0, recs_cap=100000):
+    theta = np.array(theta, dtype=np.float64, copy=True)
+    cw = _f64(cw)
+    assert theta.shape == (red.dim,)
+    recs = (IterRec * recs_cap)()
+    n_recs = C.c_int64(0)
+    ctx.check(lib().klr_cd_solve(ctx._h, red._h, _p(theta), _p(cw), l1reg, l2reg, eps, eps_loss, int(eval_loss),
+                                 max_iter, C.cast(recs, C.c_void_p), recs_cap, C.byref(n_recs)))
+    out = [dict(iteration=r.iteration, nonzero=r.nonzero, change=r.change, lambda_=r.lambda_, loss=r.loss,
+                seconds=r.seconds) for r in recs[:min(n_recs.value, recs_cap)]]
+    return theta, out
+
+
+def synth_csr(seed, row0, n_local, n_total, m, draws, S, threads=0):
+    """Host-side synthetic generator of the product library (no GPU needed)."""
+    rowptr = np.zeros(n_local + 1, dtype=np.int64)
+    col = np.zeros(max(n_local * (draws + 1), 1), dtype=np.int64)
+    val = np.zeros(max(n_local * (draws + 1), 1), dtype=np.float64)
+    labels = np.zeros(max(n_local, 1), dtype=np.uint8)
+    rc = lib().klr_synth_csr(C.c_uint64(seed), row0, n_local, n_total, m, draws, S, _p(rowptr), _p(col), _p(val),
+                             _p(labels), threads)
+    if rc != 0:
+        raise KlrError("klr_synth_csr failed: %s" % (lib().klr_last_error(None) or b"").decode())
+    nnz = int(rowptr[-1])
+    return rowptr, col[:nnz], val[:nnz], labels[:n_local]

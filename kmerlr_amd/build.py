@@ -1,0 +1,72 @@
+"""Builds libkmerlr_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so stays under
+kmerlr_amd/_lib/ so it travels with the source tree to the GPU box."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIBDIR = os.path.join(HERE, "_lib")
+LIB = os.path.join(LIBDIR, "libkmerlr_hip.so")
+
+SOURCES = ["klr_ctx.hip", "klr_mat.hip", "klr_sweep.hip", "klr_select.hip", "klr_solve.hip",
+           "klr_synth.cpp", "klr_driver.cpp"]
+HEADERS = [os.path.join(CSRC, "klr_internal.h"), os.path.join(HERE, "..", "include", "kmerlr.h"),
+           os.path.join(HERE, "..", "include", "kmerlr_driver.h")]
+
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-result", "-fno-gpu-rdc"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found; libkmerlr_hip.so cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    cc = hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
+        if force or _stale(obj, [src] + HEADERS):
+            cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+        return r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for w in ex.map(run, jobs):
+                if verbose and w.strip():
+                    print(w)
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in srcs]
+    if force or jobs or _stale(LIB, objs):
+        run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
+            ["-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,256 @@
+// klr_ctx.hip -- context, error reporting, workspace, all-reduce hook (callback or RCCL),
+// HIP-event profiling of the column sweep.
+#include "klr_internal.h"
+
+#include <dlfcn.h>
+
+#include <cstdarg>
+
+thread_local std::string g_klr_err;
+
+int klr_fail(klr_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_klr_err = buf;
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+extern "C" const char* klr_version(void) { return "kmerlr-hip 0.1 (gfx950)"; }
+
+extern "C" const char* klr_last_error(const klr_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_klr_err.c_str();
+}
+
+extern "C" int klr_ctx_create(int device_id, klr_ctx** out) {
+  if (!out) return klr_fail(nullptr, KLR_EINVAL, "klr_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return klr_fail(nullptr, KLR_ENODEV, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev)
+    return klr_fail(nullptr, KLR_EINVAL, "device_id %d out of range [0,%d)", device_id, ndev);
+  hipDeviceProp_t prop;
+  KLR_HIP(nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return klr_fail(nullptr, KLR_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only",
+                    device_id, prop.gcnArchName);
+  KLR_HIP(nullptr, hipSetDevice(device_id));
+  klr_ctx* ctx = new klr_ctx();
+  ctx->device = device_id;
+  ctx->n_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return klr_fail(nullptr, KLR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  ctx->own_stream = true;
+  *out = ctx;
+  return KLR_OK;
+}
+
+// ---- RCCL, loaded lazily so that single-GPU use has no dependency on it -------------------
+struct Id128 { char b[128]; };
+struct RcclState {
+  void* lib = nullptr;
+  void* comm = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ Id128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+
+static int rccl_load(RcclState* st) {
+  if (st->lib) return KLR_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    st->lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (st->lib) break;
+  }
+  if (!st->lib) return klr_fail(nullptr, KLR_ECOMM, "cannot load librccl: %s", dlerror());
+  st->GetUniqueId = (int (*)(void*))dlsym(st->lib, "ncclGetUniqueId");
+  st->CommInitRank = (int (*)(void**, int, Id128, int))dlsym(st->lib, "ncclCommInitRank");
+  st->AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(st->lib, "ncclAllReduce");
+  st->CommDestroy = (int (*)(void*))dlsym(st->lib, "ncclCommDestroy");
+  st->GetErrorString = (const char* (*)(int))dlsym(st->lib, "ncclGetErrorString");
+  if (!st->GetUniqueId || !st->CommInitRank || !st->AllReduce || !st->CommDestroy)
+    return klr_fail(nullptr, KLR_ECOMM, "librccl lacks the expected nccl* symbols");
+  return KLR_OK;
+}
+
+extern "C" int klr_rccl_unique_id(void* id128) {
+  if (!id128) return klr_fail(nullptr, KLR_EINVAL, "id128 is NULL");
+  static RcclState st;
+  KLR_TRY(rccl_load(&st));
+  int rc = st.GetUniqueId(id128);
+  if (rc != 0) return klr_fail(nullptr, KLR_ECOMM, "ncclGetUniqueId failed (%d)", rc);
+  return KLR_OK;
+}
+
+static int rccl_allreduce_hook(void* user, void* dev_buf, int64_t count, void* stream) {
+  RcclState* st = (RcclState*)user;
+  const int ncclFloat64 = 8, ncclSum = 0;
+  int rc = st->AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, st->comm, (hipStream_t)stream);
+  return rc == 0 ? 0 : 1;
+}
+
+extern "C" int klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int nranks) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, id128 != nullptr && nranks >= 1 && rank >= 0 && rank < nranks);
+  RcclState* st = new RcclState();
+  int rc = rccl_load(st);
+  if (rc != KLR_OK) { ctx->err = g_klr_err; delete st; return rc; }
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  Id128 id;
+  memcpy(id.b, id128, 128);
+  int nrc = st->CommInitRank(&st->comm, nranks, id, rank);
+  if (nrc != 0) {
+    const char* es = st->GetErrorString ? st->GetErrorString(nrc) : "?";
+    delete st;
+    return klr_fail(ctx, KLR_ECOMM, "ncclCommInitRank failed: %s", es);
+  }
+  ctx->rccl = st;
+  ctx->ar_fn = rccl_allreduce_hook;
+  ctx->ar_user = st;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  return KLR_OK;
+}
+
+extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* user, int rank, int nranks) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, nranks >= 1 && rank >= 0 && rank < nranks);
+  ctx->ar_fn = fn;
+  ctx->ar_user = user;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  return KLR_OK;
+}
+
+int klr_allreduce(klr_ctx* ctx, double* dev, i64 count) {
+  if (!ctx->ar_fn || ctx->nranks <= 1) return KLR_OK;
+  int rc = ctx->ar_fn(ctx->ar_user, dev, count, (void*)ctx->stream);
+  if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "all-reduce hook failed (%d) on %lld doubles", rc, (long long)count);
+  return KLR_OK;
+}
+
+extern "C" void klr_ctx_destroy(klr_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& pr : ctx->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (int i = 0; i < WS_COUNT; i++) if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->rccl) {
+    RcclState* st = (RcclState*)ctx->rccl;
+    if (st->comm) st->CommDestroy(st->comm);
+    delete st;
+  }
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int klr_ctx_set_stream(klr_ctx* ctx, void* hip_stream) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hip_stream == nullptr) {
+    if (!ctx->own_stream) {
+      KLR_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+    return KLR_OK;
+  }
+  if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+  ctx->stream = (hipStream_t)hip_stream;
+  return KLR_OK;
+}
+
+extern "C" int klr_ctx_synchronize(klr_ctx* ctx) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KLR_OK;
+}
+
+// ---- memory ---------------------------------------------------------------------------------
+int dev_alloc(klr_ctx* ctx, void** p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess)
+    return klr_fail(ctx, KLR_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return KLR_OK;
+}
+
+int ws_get(klr_ctx* ctx, int which, size_t bytes, void** out) {
+  DevBuf& b = ctx->ws[which];
+  if (bytes == 0) bytes = 16;
+  if (b.cap < bytes) {
+    // earlier work on the stream may still use the old block
+    KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    KLR_TRY(dev_alloc(ctx, &b.p, want));
+    b.cap = want;
+  }
+  *out = b.p;
+  return KLR_OK;
+}
+
+int pin_get(klr_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->pin_cap < bytes) {
+    KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    ctx->pin = nullptr; ctx->pin_cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&ctx->pin, want, hipHostMallocDefault);
+    if (e != hipSuccess) return klr_fail(ctx, KLR_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->pin_cap = want;
+  }
+  *out = ctx->pin;
+  return KLR_OK;
+}
+
+int h2d(klr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return KLR_OK;
+  // pageable source: hipMemcpyAsync stages synchronously, so the host buffer is reusable on return
+  KLR_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return KLR_OK;
+}
+
+int d2h_sync(klr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes) KLR_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KLR_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+extern "C" int klr_prof_enable(klr_ctx* ctx, int on) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  ctx->prof_on = on != 0;
+  return KLR_OK;
+}
+
+extern "C" int klr_prof_read(klr_ctx* ctx, int64_t* launches, double* total_ms, int reset) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (auto& pr : ctx->prof_ev) {
+    float ms = 0.f;
+    KLR_HIP(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += (double)ms;
+  }
+  if (launches) *launches = (int64_t)ctx->prof_ev.size();
+  if (total_ms) *total_ms = tot;
+  if (reset) {
+    for (auto& pr : ctx->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    ctx->prof_ev.clear();
+  }
+  return KLR_OK;
+}

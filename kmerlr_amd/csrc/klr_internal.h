@@ -1,0 +1,164 @@
+// klr_internal.h -- shared declarations of libkmerlr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kmerlr.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t  i64;
+
+// ---------------------------------------------------------------------------------------
+// device buffer that grows on demand (stream-ordered use only; never shrinks)
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+  void*  p = nullptr;
+  size_t cap = 0;
+};
+
+enum {
+  WS_S = 0,        // per-row weights s_i / w_i (f64[n])
+  WS_Z,            // IRLS working response (f64[n])
+  WS_PART,         // per-chunk partial sums of the column sweep
+  WS_G,            // [g(dim) | scalars] all-reduce buffer
+  WS_THETA,        // dense theta on device
+  WS_BLK,          // per-block partials of row passes
+  WS_SEL_KEYS,     // selection: keys
+  WS_SEL_MISC,     // selection: histograms, state, block counts
+  WS_SEL_CAND,     // selection: candidates
+  WS_MASK,         // u8 mask / colmap
+  WS_CD_G,         // Gram matrix
+  WS_CD_VEC,       // xy, norm, theta, q, hist, deltas...
+  WS_CD_LOSS,      // K losses (+ block partials)
+  WS_TMP0,
+  WS_TMP1,
+  WS_TMP2,
+  WS_COUNT
+};
+
+struct klr_ctx {
+  int          device = 0;
+  hipStream_t  stream = nullptr;
+  bool         own_stream = false;
+  std::string  err;
+  // all-reduce hook
+  klr_allreduce_fn ar_fn = nullptr;
+  void*        ar_user = nullptr;
+  int          rank = 0, nranks = 1;
+  void*        rccl = nullptr;       // struct RcclState*
+  DevBuf       ws[WS_COUNT];
+  // pinned host staging
+  void*        pin = nullptr;
+  size_t       pin_cap = 0;
+  // profiling of the column sweep
+  bool         prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  int          n_cu = 256;
+};
+
+struct klr_mat {
+  klr_ctx* ctx = nullptr;
+  i64  n = 0, dim = 0, nnz = 0, n_total = 0;
+  bool val_f64 = false;          // value arrays are f64 (else f32)
+  bool has_explicit_zero = false;
+  // ---- CSR (device)
+  i64* rowptr = nullptr;         // n+1
+  u32* col = nullptr;            // nnz
+  void* val = nullptr;           // nnz  (f32|f64)
+  // ---- CSC (device), every column segment padded to a multiple of 4 entries (row 0, val 0)
+  i64* colptr = nullptr;         // dim+1 (padded offsets)
+  u32* crow = nullptr;           // nnz_pad
+  void* cval = nullptr;          // nnz_pad
+  i64  nnz_pad = 0;
+  // chunks of the column sweep: one lane group per chunk
+  i64  nchunks = 0;
+  i64* chunk_begin = nullptr;    // nchunks (offset into crow/cval, multiple of 4)
+  u32* chunk_len = nullptr;      // nchunks (multiple of 4)
+  i64* colchunk = nullptr;       // dim+1: chunks of column j are [colchunk[j], colchunk[j+1])
+  int  group = 64;               // lanes per chunk
+  uint8_t* labels = nullptr;     // n
+  // ---- host metadata
+  std::vector<i64> h_colptr;     // dim+1 padded offsets
+  std::vector<u32> h_collen;     // dim   true lengths
+  std::vector<u32> h_colnz;      // dim   entries with value != 0
+  i64  n1_local = 0;             // labels == 1 among local rows
+  double avg_row = 0.0;
+};
+
+// ---------------------------------------------------------------------------------------
+// error helpers
+// ---------------------------------------------------------------------------------------
+extern thread_local std::string g_klr_err;
+
+int klr_fail(klr_ctx* ctx, int code, const char* fmt, ...);
+
+#define KLR_HIP(ctx, expr)                                                             \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return klr_fail((ctx), KLR_EHIP, "%s failed: %s (%s:%d)", #expr,                 \
+                      hipGetErrorString(e__), __FILE__, __LINE__);                     \
+  } while (0)
+
+#define KLR_TRY(expr)                 \
+  do {                                \
+    int rc__ = (expr);                \
+    if (rc__ != KLR_OK) return rc__;  \
+  } while (0)
+
+#define KLR_ARG(ctx, cond)                                                                   \
+  do {                                                                                       \
+    if (!(cond)) return klr_fail((ctx), KLR_EINVAL, "invalid argument: %s (%s:%d)", #cond,   \
+                                 __FILE__, __LINE__);                                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// internal (stream-ordered, no host sync unless stated)
+// ---------------------------------------------------------------------------------------
+int   ws_get(klr_ctx* ctx, int which, size_t bytes, void** out);
+int   pin_get(klr_ctx* ctx, size_t bytes, void** out);
+int   klr_allreduce(klr_ctx* ctx, double* dev, i64 count);   // no-op without hook
+int   dev_alloc(klr_ctx* ctx, void** p, size_t bytes);
+int   h2d(klr_ctx* ctx, void* dst, const void* src, size_t bytes);     // async on ctx stream
+int   d2h_sync(klr_ctx* ctx, void* dst, const void* src, size_t bytes); // copies and waits
+
+// row pass modes
+enum { ROW_SWEEP = 0, ROW_LOSS = 1, ROW_IRLS = 2, ROW_LOGPDF = 3 };
+// Row pass over mat's CSR with dense device theta (length mat->dim).
+//  ROW_SWEEP : out0[i] = s_i = cw[y]/n_total * (sigma - y); *loss_acc_dev += sum of loss terms
+//  ROW_LOSS  : *loss_acc_dev += sum_i cw[y] * (-log sigma(+-r))
+//  ROW_IRLS  : out0[i] = w_i*cw, out1[i] = z_i; loss as ROW_LOSS
+//  ROW_LOGPDF: out0[i] = log sigma(r_i)
+// loss_acc_dev (nullable) is OVERWRITTEN with the local sum (deterministic two-stage reduction).
+int   launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, int mode,
+                      const double cw[2], double* out0, double* out1, double* loss_acc_dev);
+// out0 for rows when theta has only a bias (no matrix access)
+int   launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
+                       double* out0, double* out1, double* loss_acc_dev);
+
+// column sweep: g_raw[j] = sum_i s[i] * x_ij (sq: x_ij^2) for every column of mat (length dim)
+int   launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev, bool square);
+
+// device exclusive scan of u32 counts into i64 offsets (out has n+1 entries)
+int   launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out);
+
+// selection on a device gradient (g_dev[0..dim), feature j at g_dev[j+1]); finishes Select on host
+int   select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
+                         double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
+                         int* ok_out, i64* picked_out);
+
+// matrix construction helpers
+int   mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat);   // uses h_colptr/h_collen
+void  mat_free(klr_mat* mat);
+
+int   build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, const double* scale,
+                    const double* offset, bool need_csc, klr_mat** out);
+
+static inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }

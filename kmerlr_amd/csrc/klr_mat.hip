@@ -1,0 +1,575 @@
+// klr_mat.hip -- the sparse k-mer / score matrix in HBM: ingest of the reference row layout,
+// CSR + padded CSC + sweep chunks, and the column sub-select (featureSelection.Data).
+//
+// HBM layout (DESIGN.md "data layout"):
+//   CSR   rowptr i64[n+1], col u32[nnz], val f32|f64[nnz]            rows = samples
+//   CSC   colptr i64[dim+1], crow u32[nnz_pad], cval f32|f64[nnz_pad] columns = k-mers;
+//         every column segment starts 16-byte aligned and is padded to a multiple of 4 entries
+//         with (row 0, value 0) so a lane can fetch 4 entries with one dwordx4 load per array
+//   chunks  a column longer than CHUNK_MAX entries is cut into chunks; the sweep gives one lane
+//         group to each chunk and a second tiny kernel adds a column's chunk sums in order
+// Values are stored as f32 when every value is exactly representable (k-mer counts are small
+// integers), else f64; all accumulation is f64.
+#include "klr_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <thread>
+
+static const i64 CHUNK_MAX = 4096;   // entries per sweep chunk (multiple of 256)
+
+void mat_free(klr_mat* m) {
+  if (!m) return;
+  if (m->ctx) {
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+  }
+  void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
+                m->chunk_begin, m->chunk_len, m->colchunk, m->labels};
+  for (void* p : ps) if (p) (void)hipFree(p);
+  delete m;
+}
+
+extern "C" void klr_mat_destroy(klr_mat* mat) { mat_free(mat); }
+
+extern "C" int klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total) {
+  if (!mat) return klr_fail(nullptr, KLR_EINVAL, "mat is NULL");
+  if (n) *n = mat->n;
+  if (dim) *dim = mat->dim;
+  if (nnz) *nnz = mat->nnz;
+  if (n_total) *n_total = mat->n_total;
+  return KLR_OK;
+}
+
+static int pick_group(double avg_len) {
+  int g = 4;
+  while (g < 64 && 4.0 * g < avg_len) g *= 2;
+  return g;
+}
+
+// Builds the chunk list from h_colptr/h_collen and uploads colptr + chunks.
+int mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat) {
+  const i64 dim = mat->dim;
+  std::vector<i64> cb, cc(dim + 1);
+  std::vector<u32> cl;
+  cb.reserve(dim + 16); cl.reserve(dim + 16);
+  for (i64 j = 0; j < dim; j++) {
+    cc[j] = (i64)cb.size();
+    i64 b = mat->h_colptr[j], e = mat->h_colptr[j + 1];
+    while (b < e) {
+      i64 len = std::min(CHUNK_MAX, e - b);
+      cb.push_back(b); cl.push_back((u32)len);
+      b += len;
+    }
+  }
+  cc[dim] = (i64)cb.size();
+  mat->nchunks = (i64)cb.size();
+  mat->group = pick_group(mat->nchunks ? (double)mat->nnz_pad / (double)mat->nchunks : 4.0);
+  KLR_TRY(dev_alloc(ctx, (void**)&mat->colptr, (size_t)(dim + 1) * sizeof(i64)));
+  KLR_TRY(dev_alloc(ctx, (void**)&mat->chunk_begin, (size_t)std::max<i64>(mat->nchunks, 1) * sizeof(i64)));
+  KLR_TRY(dev_alloc(ctx, (void**)&mat->chunk_len, (size_t)std::max<i64>(mat->nchunks, 1) * sizeof(u32)));
+  KLR_TRY(dev_alloc(ctx, (void**)&mat->colchunk, (size_t)(dim + 1) * sizeof(i64)));
+  KLR_HIP(ctx, hipMemcpy(mat->colptr, mat->h_colptr.data(), (size_t)(dim + 1) * sizeof(i64), hipMemcpyHostToDevice));
+  if (mat->nchunks) {
+    KLR_HIP(ctx, hipMemcpy(mat->chunk_begin, cb.data(), (size_t)mat->nchunks * sizeof(i64), hipMemcpyHostToDevice));
+    KLR_HIP(ctx, hipMemcpy(mat->chunk_len, cl.data(), (size_t)mat->nchunks * sizeof(u32), hipMemcpyHostToDevice));
+  }
+  KLR_HIP(ctx, hipMemcpy(mat->colchunk, cc.data(), (size_t)(dim + 1) * sizeof(i64), hipMemcpyHostToDevice));
+  return KLR_OK;
+}
+
+extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int64_t* rowptr,
+                                const int64_t* col, const double* val, const uint8_t* labels,
+                                int64_t n_total, klr_mat** out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, out != nullptr);
+  *out = nullptr;
+  KLR_ARG(ctx, n >= 0 && dim >= 1 && rowptr != nullptr && labels != nullptr);
+  KLR_ARG(ctx, n < (i64)0xFFFFFFFFll && dim < (i64)0xFFFFFFFFll);
+  KLR_ARG(ctx, rowptr[0] == 0);
+  if (n_total == 0) n_total = n;
+  KLR_ARG(ctx, n_total >= n);
+  const i64 nnz = rowptr[n];
+  KLR_ARG(ctx, nnz == 0 || (col != nullptr && val != nullptr));
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+
+  // ---- validate + per-column counts (threads own contiguous row blocks) ----------------------
+  int T = (int)std::min<i64>(std::max<unsigned>(1u, std::min(8u, std::thread::hardware_concurrency())),
+                             std::max<i64>(1, n / 4096));
+  std::vector<std::vector<u32>> cnt(T, std::vector<u32>((size_t)dim, 0u));
+  std::vector<std::vector<u32>> cnz(T, std::vector<u32>((size_t)dim, 0u));
+  std::vector<int> bad(T, 0), notf32(T, 0);
+  std::vector<i64> n1(T, 0);
+  auto rows_of = [&](int t, i64& r0, i64& r1) { r0 = n * t / T; r1 = n * (t + 1) / T; };
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
+      i64 r0, r1; rows_of(t, r0, r1);
+      for (i64 i = r0; i < r1; i++) {
+        const i64 b = rowptr[i], e = rowptr[i + 1];
+        if (labels[i]) n1[t]++;
+        // LinearPdf asserts i[0] == 0 (kmerLr_logistic_regression.go:53); bias value is 1.0
+        if (e <= b || col[b] != 0 || val[b] != 1.0) { bad[t] = 1; continue; }
+        i64 prev = -1;
+        for (i64 a = b; a < e; a++) {
+          const i64 c = col[a];
+          if (c <= prev || c >= dim) { bad[t] = 2; break; }
+          prev = c;
+          cnt[t][c]++;
+          const double v = val[a];
+          if (v != 0.0) cnz[t][c]++;
+          if ((double)(float)v != v) notf32[t] = 1;
+        }
+      }
+    });
+    for (auto& x : th) x.join();
+  }
+  for (int t = 0; t < T; t++) {
+    if (bad[t] == 1) return klr_fail(ctx, KLR_EINVAL, "every row must start with the bias entry (column 0, value 1.0)");
+    if (bad[t] == 2) return klr_fail(ctx, KLR_EINVAL, "column ids must be strictly ascending within a row and < dim");
+  }
+  klr_mat* m = new klr_mat();
+  m->ctx = ctx; m->n = n; m->dim = dim; m->nnz = nnz; m->n_total = n_total;
+  m->val_f64 = false;
+  for (int t = 0; t < T; t++) { if (notf32[t]) m->val_f64 = true; m->n1_local += n1[t]; }
+  m->avg_row = n ? (double)nnz / (double)n : 0.0;
+  m->h_colptr.assign((size_t)dim + 1, 0);
+  m->h_collen.assign((size_t)dim, 0);
+  m->h_colnz.assign((size_t)dim, 0);
+  for (i64 j = 0; j < dim; j++) {
+    u32 c = 0, z = 0;
+    for (int t = 0; t < T; t++) { c += cnt[t][j]; z += cnz[t][j]; }
+    m->h_collen[j] = c; m->h_colnz[j] = z;
+    if (z != c) m->has_explicit_zero = true;
+    m->h_colptr[j + 1] = m->h_colptr[j] + (i64)((c + 3u) & ~3u);
+  }
+  m->nnz_pad = m->h_colptr[dim];
+
+  // ---- host CSC (stable: rows ascending inside a column) + narrow CSR ------------------------
+  const size_t vsz = m->val_f64 ? 8 : 4;
+  std::vector<u32> h_col((size_t)std::max<i64>(nnz, 1));
+  std::vector<char> h_val((size_t)std::max<i64>(nnz, 1) * vsz);
+  std::vector<u32> h_crow((size_t)std::max<i64>(m->nnz_pad, 1), 0u);
+  std::vector<char> h_cval((size_t)std::max<i64>(m->nnz_pad, 1) * vsz, 0);
+  {
+    // cursor[t][j] = first slot of thread t in column j
+    std::vector<std::vector<i64>> cur(T, std::vector<i64>((size_t)dim));
+    for (i64 j = 0; j < dim; j++) {
+      i64 o = m->h_colptr[j];
+      for (int t = 0; t < T; t++) { cur[t][j] = o; o += cnt[t][j]; }
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
+      i64 r0, r1; rows_of(t, r0, r1);
+      std::vector<i64>& cu = cur[t];
+      for (i64 i = r0; i < r1; i++) {
+        for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
+          const i64 c = col[a];
+          const i64 s = cu[c]++;
+          h_col[a] = (u32)c;
+          h_crow[s] = (u32)i;
+          if (m->val_f64) { ((double*)h_val.data())[a] = val[a]; ((double*)h_cval.data())[s] = val[a]; }
+          else            { ((float*)h_val.data())[a] = (float)val[a]; ((float*)h_cval.data())[s] = (float)val[a]; }
+        }
+      }
+    });
+    for (auto& x : th) x.join();
+  }
+
+  // ---- upload ----------------------------------------------------------------------------------
+  int rc = KLR_OK;
+  do {
+    if ((rc = dev_alloc(ctx, (void**)&m->rowptr, (size_t)(n + 1) * sizeof(i64)))) break;
+    if ((rc = dev_alloc(ctx, (void**)&m->col, (size_t)nnz * sizeof(u32)))) break;
+    if ((rc = dev_alloc(ctx, &m->val, (size_t)nnz * vsz))) break;
+    if ((rc = dev_alloc(ctx, (void**)&m->crow, (size_t)m->nnz_pad * sizeof(u32)))) break;
+    if ((rc = dev_alloc(ctx, &m->cval, (size_t)m->nnz_pad * vsz))) break;
+    if ((rc = dev_alloc(ctx, (void**)&m->labels, (size_t)n))) break;
+    hipError_t e = hipSuccess;
+    e = hipMemcpy(m->rowptr, rowptr, (size_t)(n + 1) * sizeof(i64), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(m->col, h_col.data(), (size_t)nnz * sizeof(u32), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(m->val, h_val.data(), (size_t)nnz * vsz, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m->nnz_pad) e = hipMemcpy(m->crow, h_crow.data(), (size_t)m->nnz_pad * sizeof(u32), hipMemcpyHostToDevice);
+    if (e == hipSuccess && m->nnz_pad) e = hipMemcpy(m->cval, h_cval.data(), (size_t)m->nnz_pad * vsz, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(m->labels, labels, (size_t)n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "matrix upload failed: %s", hipGetErrorString(e)); break; }
+    rc = mat_build_chunks_and_upload(ctx, m);
+  } while (0);
+  if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(m); ctx->err = keep; return rc; }
+  *out = m;
+  return KLR_OK;
+}
+
+extern "C" int klr_mat_to_csr(klr_ctx* ctx, const klr_mat* mat, int64_t* rowptr, int64_t* col, double* val) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (rowptr) KLR_HIP(ctx, hipMemcpy(rowptr, mat->rowptr, (size_t)(mat->n + 1) * sizeof(i64), hipMemcpyDeviceToHost));
+  if (col && mat->nnz) {
+    std::vector<u32> t((size_t)mat->nnz);
+    KLR_HIP(ctx, hipMemcpy(t.data(), mat->col, (size_t)mat->nnz * sizeof(u32), hipMemcpyDeviceToHost));
+    for (i64 a = 0; a < mat->nnz; a++) col[a] = (i64)t[a];
+  }
+  if (val && mat->nnz) {
+    if (mat->val_f64) KLR_HIP(ctx, hipMemcpy(val, mat->val, (size_t)mat->nnz * 8, hipMemcpyDeviceToHost));
+    else {
+      std::vector<float> t((size_t)mat->nnz);
+      KLR_HIP(ctx, hipMemcpy(t.data(), mat->val, (size_t)mat->nnz * 4, hipMemcpyDeviceToHost));
+      for (i64 a = 0; a < mat->nnz; a++) val[a] = (double)t[a];
+    }
+  }
+  return KLR_OK;
+}
+
+// compute_class_weights, kmerLr_data.go:178-193, over all shards
+extern "C" int klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2]) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr && cw != nullptr);
+  double cnts[2] = {(double)(mat->n - mat->n1_local), (double)mat->n1_local};
+  if (ctx->ar_fn && ctx->nranks > 1) {
+    double* d;
+    KLR_TRY(ws_get(ctx, WS_G, 2 * sizeof(double), (void**)&d));
+    KLR_TRY(h2d(ctx, d, cnts, sizeof(cnts)));
+    KLR_TRY(klr_allreduce(ctx, d, 2));
+    KLR_TRY(d2h_sync(ctx, cnts, d, sizeof(cnts)));
+  }
+  const double n0 = cnts[0], n1 = cnts[1];
+  cw[0] = (n0 + n1) / (2.0 * n0);
+  cw[1] = (n0 + n1) / (2.0 * n1);
+  return KLR_OK;
+}
+
+// =================================================================================================
+// device exclusive scan (u32 counts -> i64 offsets), three tiny kernels
+// =================================================================================================
+#define SCAN_BLOCK 1024
+#define SCAN_ITEMS 4
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_block_sums(const u32* __restrict__ in, i64 n, i64* __restrict__ bsum) {
+  __shared__ i64 sh[SCAN_BLOCK / 64];
+  const i64 base = (i64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+  i64 s = 0;
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const i64 i = base + (i64)threadIdx.x * SCAN_ITEMS + k;
+    if (i < n) s += in[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    i64 t = 0;
+    for (int w = 0; w < SCAN_BLOCK / 64; w++) t += sh[w];
+    bsum[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_bsums(i64* bsum, i64 nb) {
+  // single block, serial over tiles of 1024 (nb is small: n / 4096)
+  __shared__ i64 sh[1024];
+  __shared__ i64 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (i64 base = 0; base < nb; base += 1024) {
+    const i64 i = base + threadIdx.x;
+    const i64 v = i < nb ? bsum[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      i64 t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const i64 incl = sh[threadIdx.x];
+    if (i < nb) bsum[i] = carry + incl - v;   // exclusive
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const u32* __restrict__ in, i64 n, const i64* __restrict__ bsum,
+                                                          i64* __restrict__ out) {
+  __shared__ i64 sh[SCAN_BLOCK];
+  const i64 base = (i64)blockIdx.x * SCAN_BLOCK * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS];
+  i64 s = 0;
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const i64 i = base + (i64)threadIdx.x * SCAN_ITEMS + k;
+    v[k] = i < n ? in[i] : 0u;
+    s += v[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
+    i64 t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  i64 run = bsum[blockIdx.x] + sh[threadIdx.x] - s;
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const i64 i = base + (i64)threadIdx.x * SCAN_ITEMS + k;
+    if (i < n) out[i] = run;
+    run += v[k];
+    if (i == n - 1) out[n] = run;
+  }
+}
+
+int launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out) {
+  if (n == 0) {
+    KLR_HIP(ctx, hipMemsetAsync(out, 0, sizeof(i64), ctx->stream));
+    return KLR_OK;
+  }
+  const i64 nb = ceil_div(n, (i64)SCAN_BLOCK * SCAN_ITEMS);
+  i64* bsum;
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)nb * sizeof(i64), (void**)&bsum));
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, bsum);
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, ctx->stream, in, n, bsum, out);
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
+// =================================================================================================
+// column sub-select: featureSelection.Data (kmerLr_feature_selection.go:309-343) + Transform.Apply
+// (kmerLr_transform.go:584-629), built from the CSC side so only the selected columns are read.
+// =================================================================================================
+template <typename VT>
+__global__ __launch_bounds__(256) void k_gather_cols(const i64* __restrict__ src_colptr, const u32* __restrict__ src_len,
+                                                     const u32* __restrict__ crow, const VT* __restrict__ cval,
+                                                     const i64* __restrict__ sel, const i64* __restrict__ dst_colptr,
+                                                     const double* __restrict__ scale, u32* __restrict__ rcrow,
+                                                     double* __restrict__ rcval) {
+  // one block per selected column; the source column holds no explicit zeros
+  const int p = blockIdx.x;
+  const i64 j = sel[p];
+  const i64 sb = src_colptr[j];
+  const i64 len = src_len[p];
+  const i64 db = dst_colptr[p], de = dst_colptr[p + 1];
+  const double sc = scale ? scale[p] : 1.0;
+  for (i64 e = threadIdx.x; e < de - db; e += 256) {
+    if (e < len) { rcrow[db + e] = crow[sb + e]; rcval[db + e] = (double)cval[sb + e] * sc; }
+    else         { rcrow[db + e] = 0u;           rcval[db + e] = 0.0; }
+  }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ src_colptr, const u32* __restrict__ src_len,
+                                                       const u32* __restrict__ crow, const VT* __restrict__ cval,
+                                                       const i64* __restrict__ sel, const i64* __restrict__ dst_colptr,
+                                                       const double* __restrict__ scale, u32* __restrict__ rcrow,
+                                                       double* __restrict__ rcval) {
+  // one wave per selected column; keeps entries with value != 0 in order (:332 `value != 0.0`)
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const i64 j = sel[p];
+  const i64 sb = src_colptr[j];
+  const i64 len = src_len[p];     // TRUE source length here
+  const i64 db = dst_colptr[p], de = dst_colptr[p + 1];
+  const double sc = scale ? scale[p] : 1.0;
+  i64 o = db;
+  for (i64 e0 = 0; e0 < len; e0 += 64) {
+    const i64 e = e0 + lane;
+    double v = 0.0; u32 r = 0;
+    if (e < len) { v = (double)cval[sb + e]; r = crow[sb + e]; }
+    const bool keep = (e < len) && (v != 0.0);
+    const unsigned long long mask = __ballot(keep);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) { rcrow[o + rank] = r; rcval[o + rank] = v * sc; }
+    o += __popcll(mask);
+  }
+  for (i64 e = o + lane; e < de; e += 64) { rcrow[e] = 0u; rcval[e] = 0.0; }
+}
+
+__global__ __launch_bounds__(256) void k_count_rows(const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len,
+                                                    const u32* __restrict__ rcrow, u32* __restrict__ cnt) {
+  const int p = blockIdx.x;
+  const i64 db = dst_colptr[p];
+  const i64 len = dst_len[p];
+  for (i64 e = threadIdx.x; e < len; e += 256) atomicAdd(&cnt[rcrow[db + e]], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_fill_rows(const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len,
+                                                   const u32* __restrict__ rcrow, const double* __restrict__ rcval,
+                                                   const i64* __restrict__ rrowptr, u32* __restrict__ cursor,
+                                                   u32* __restrict__ rcol, double* __restrict__ rval) {
+  const int p = blockIdx.x;
+  const i64 db = dst_colptr[p];
+  const i64 len = dst_len[p];
+  for (i64 e = threadIdx.x; e < len; e += 256) {
+    const u32 r = rcrow[db + e];
+    const i64 slot = rrowptr[r] + (i64)atomicAdd(&cursor[r], 1u);
+    rcol[slot] = (u32)p;
+    rval[slot] = rcval[db + e];
+  }
+}
+
+// in-row insertion sort by (distinct) reduced column id -> deterministic, ascending rows
+__global__ __launch_bounds__(256) void k_sort_rows(const i64* __restrict__ rrowptr, i64 n, u32* __restrict__ rcol,
+                                                   double* __restrict__ rval) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const i64 b = rrowptr[i], e = rrowptr[i + 1];
+  for (i64 a = b + 1; a < e; a++) {
+    const u32 kc = rcol[a]; const double kv = rval[a];
+    i64 q = a - 1;
+    while (q >= b && rcol[q] > kc) { rcol[q + 1] = rcol[q]; rval[q + 1] = rval[q]; q--; }
+    rcol[q + 1] = kc; rval[q + 1] = kv;
+  }
+}
+
+// dense variants for offset transforms (Transform.Apply densifies, kmerLr_transform.go:596-609)
+__global__ __launch_bounds__(256) void k_dense_init(i64 n, int c1, i64 colstride, const double* __restrict__ scale,
+                                                    const double* __restrict__ offset, i64* __restrict__ rrowptr,
+                                                    u32* __restrict__ rcol, double* __restrict__ rval,
+                                                    u32* __restrict__ rcrow, double* __restrict__ rcval) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t <= n && t < n + 1) rrowptr[t] = t * (i64)c1;
+  if (t < n * (i64)c1) {
+    const i64 i = t / c1; const int p = (int)(t % c1);
+    double v = 0.0 - offset[p];
+    if (scale) v = v * scale[p];
+    rcol[t] = (u32)p; rval[t] = v;
+    rcrow[(i64)p * colstride + i] = (u32)i; rcval[(i64)p * colstride + i] = v;
+  }
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_dense_overwrite(const i64* __restrict__ src_colptr, const u32* __restrict__ src_len,
+                                                         const u32* __restrict__ crow, const VT* __restrict__ cval,
+                                                         const i64* __restrict__ sel, int c1, i64 colstride,
+                                                         const double* __restrict__ scale, const double* __restrict__ offset,
+                                                         double* __restrict__ rval, double* __restrict__ rcval) {
+  const int p = blockIdx.x;
+  const i64 sb = src_colptr[sel[p]];
+  const i64 len = src_len[p];
+  for (i64 e = threadIdx.x; e < len; e += 256) {
+    const i64 i = crow[sb + e];
+    double v = (double)cval[sb + e] - offset[p];
+    if (scale) v = v * scale[p];
+    rval[i * c1 + p] = v;
+    rcval[(i64)p * colstride + i] = v;
+  }
+}
+
+int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, const double* scale,
+                  const double* offset, bool need_csc, klr_mat** out) {
+  (void)need_csc;
+  *out = nullptr;
+  KLR_ARG(ctx, c1 >= 1 && cols[0] == 0);
+  for (i64 p = 1; p < c1; p++) KLR_ARG(ctx, cols[p] > cols[p - 1] && cols[p] < full->dim);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 n = full->n;
+  klr_mat* r = new klr_mat();
+  r->ctx = ctx; r->n = n; r->dim = c1; r->n_total = full->n_total; r->val_f64 = true;
+  r->n1_local = full->n1_local;
+  r->h_colptr.assign((size_t)c1 + 1, 0);
+  r->h_collen.assign((size_t)c1, 0);
+  r->h_colnz.assign((size_t)c1, 0);
+  std::vector<u32> src_len((size_t)c1);
+  const bool dense = offset != nullptr;
+  const i64 colstride = (n + 3) & ~(i64)3;
+  bool any_zero = false;
+  for (i64 p = 0; p < c1; p++) {
+    const i64 j = cols[p];
+    src_len[p] = full->h_collen[j];
+    const u32 len = dense ? (u32)n : full->h_colnz[j];
+    if (full->h_colnz[j] != full->h_collen[j]) any_zero = true;
+    r->h_collen[p] = len; r->h_colnz[p] = len;
+    r->h_colptr[p + 1] = r->h_colptr[p] + (dense ? colstride : (i64)((len + 3u) & ~3u));
+    r->nnz += len;
+  }
+  r->nnz_pad = r->h_colptr[c1];
+  r->avg_row = n ? (double)r->nnz / (double)n : 0.0;
+
+  int rc = KLR_OK;
+  i64* d_sel = nullptr; u32* d_srclen = nullptr; u32* d_dstlen = nullptr; double* d_scale = nullptr; double* d_off = nullptr;
+  do {
+    if ((rc = dev_alloc(ctx, (void**)&r->rowptr, (size_t)(n + 1) * sizeof(i64)))) break;
+    if ((rc = dev_alloc(ctx, (void**)&r->col, (size_t)r->nnz * sizeof(u32)))) break;
+    if ((rc = dev_alloc(ctx, &r->val, (size_t)r->nnz * 8))) break;
+    if ((rc = dev_alloc(ctx, (void**)&r->crow, (size_t)r->nnz_pad * sizeof(u32)))) break;
+    if ((rc = dev_alloc(ctx, &r->cval, (size_t)r->nnz_pad * 8))) break;
+    if ((rc = dev_alloc(ctx, (void**)&r->labels, (size_t)n))) break;
+    if ((rc = mat_build_chunks_and_upload(ctx, r))) break;
+    // small per-call tables
+    char* tab;
+    const size_t tab_bytes = (size_t)c1 * (8 + 4 + 4 + 8 + 8) + 64;
+    if ((rc = ws_get(ctx, WS_TMP0, tab_bytes, (void**)&tab))) break;
+    d_sel = (i64*)tab;
+    d_scale = (double*)(tab + (size_t)c1 * 8);
+    d_off = (double*)(tab + (size_t)c1 * 16);
+    d_srclen = (u32*)(tab + (size_t)c1 * 24);
+    d_dstlen = (u32*)(tab + (size_t)c1 * 28);
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d_sel, cols, (size_t)c1 * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)c1 * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && offset) e = hipMemcpyAsync(d_off, offset, (size_t)c1 * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_srclen, src_len.data(), (size_t)c1 * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dstlen, r->h_collen.data(), (size_t)c1 * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(r->labels, full->labels, (size_t)n, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns copy failed: %s", hipGetErrorString(e)); break; }
+    const double* scp = scale ? d_scale : nullptr;
+    if (dense) {
+      const i64 tot = std::max<i64>(n * c1, n + 1);
+      hipLaunchKernelGGL(k_dense_init, dim3((unsigned)ceil_div(tot, 256)), dim3(256), 0, st, n, (int)c1, colstride, scp,
+                         d_off, r->rowptr, r->col, (double*)r->val, r->crow, (double*)r->cval);
+      // padding rows of the dense CSC columns
+      if (colstride != n) {
+        // entries [n, colstride) of every column: row 0 / value 0
+        for (i64 p = 0; p < c1; p++) {
+          (void)hipMemsetAsync(r->crow + p * colstride + n, 0, (size_t)(colstride - n) * 4, st);
+          (void)hipMemsetAsync((double*)r->cval + p * colstride + n, 0, (size_t)(colstride - n) * 8, st);
+        }
+      }
+      if (full->val_f64)
+        hipLaunchKernelGGL(k_dense_overwrite<double>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
+                           (const double*)full->cval, d_sel, (int)c1, colstride, scp, d_off, (double*)r->val, (double*)r->cval);
+      else
+        hipLaunchKernelGGL(k_dense_overwrite<float>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
+                           (const float*)full->cval, d_sel, (int)c1, colstride, scp, d_off, (double*)r->val, (double*)r->cval);
+    } else {
+      if (any_zero) {
+        if (full->val_f64)
+          hipLaunchKernelGGL(k_gather_cols_nz<double>, dim3((unsigned)c1), dim3(64), 0, st, full->colptr, d_srclen, full->crow,
+                             (const double*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
+        else
+          hipLaunchKernelGGL(k_gather_cols_nz<float>, dim3((unsigned)c1), dim3(64), 0, st, full->colptr, d_srclen, full->crow,
+                             (const float*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
+      } else {
+        if (full->val_f64)
+          hipLaunchKernelGGL(k_gather_cols<double>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
+                             (const double*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
+        else
+          hipLaunchKernelGGL(k_gather_cols<float>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
+                             (const float*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
+      }
+      u32* cnt;
+      if ((rc = ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * sizeof(u32), (void**)&cnt))) break;
+      (void)hipMemsetAsync(cnt, 0, (size_t)std::max<i64>(n, 1) * sizeof(u32), st);
+      hipLaunchKernelGGL(k_count_rows, dim3((unsigned)c1), dim3(256), 0, st, r->colptr, d_dstlen, r->crow, cnt);
+      if ((rc = launch_exscan_u32(ctx, cnt, n, r->rowptr))) break;
+      (void)hipMemsetAsync(cnt, 0, (size_t)std::max<i64>(n, 1) * sizeof(u32), st);
+      hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)c1), dim3(256), 0, st, r->colptr, d_dstlen, r->crow, (const double*)r->cval,
+                         r->rowptr, cnt, r->col, (double*)r->val);
+      if (n) hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, r->rowptr, n, r->col, (double*)r->val);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns launch failed: %s", hipGetErrorString(e)); break; }
+    // the per-call tables live in workspace that later calls reuse: finish before returning
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns failed: %s", hipGetErrorString(e)); break; }
+  } while (0);
+  if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(r); ctx->err = keep; return rc; }
+  *out = r;
+  return KLR_OK;
+}
+
+extern "C" int klr_mat_select_columns(klr_ctx* ctx, const klr_mat* full, const int64_t* cols, int64_t c_plus_1,
+                                      const double* scale, const double* offset, klr_mat** reduced) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, full != nullptr && cols != nullptr && reduced != nullptr);
+  return build_reduced(ctx, full, cols, c_plus_1, scale, offset, true, reduced);
+}

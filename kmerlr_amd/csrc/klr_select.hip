@@ -1,0 +1,327 @@
+// klr_select.hip -- featureSelector.Select on the device (kmerLr_feature_selection.go:78-134,
+// computeLambda :179-192, NLargestAbsFloat64 kmerLr_sort.go:120-131).
+//
+// The reference sorts all m gradient entries by |g| (O(m log m) on one core) to read the first
+// 2N.  Here: keys = bit pattern of |g| (monotone for non-negative doubles); an 8-pass radix
+// SELECT finds the 2N-th largest key; an ordered compaction gathers the candidates (ties in
+// ascending column order); one workgroup sorts the <= 2N candidates by (|g| desc, column asc);
+// one max-reduction finds the largest |g| strictly below the N-th.  The host then runs the two
+// short pick loops of :95-116 over the 2N candidates.  Everything is integer/compare work, so the
+// result is bit-exact with the oracle for identical g.
+#include "klr_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+struct SelState {
+  u64 prefix;      // bits decided so far (high to low)
+  u32 kremain;     // rank still to resolve inside the current prefix bucket
+  u32 pad;
+  u64 thresh;      // final: key of the K-th largest
+  u32 n_gt;        // keys  > thresh
+  u32 n_eq_take;   // keys == thresh to take (lowest column ids)
+  u64 vkey;        // key of the N-th largest (set by the sort kernel)
+  u64 wkey;        // largest key < vkey
+};
+
+__device__ __forceinline__ u64 abs_key(double g) {
+  // NaN is treated as a zero gradient (never preferred); documented in DESIGN.md
+  if (g != g) return 0ull;
+  return (u64)__double_as_longlong(fabs(g));
+}
+
+__global__ __launch_bounds__(256) void k_sel_keys(const double* __restrict__ g, i64 m, u64* __restrict__ keys) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j < m) keys[j] = abs_key(g[j + 1]);      // g[0] is the bias
+}
+
+__global__ __launch_bounds__(256) void k_sel_hist(const u64* __restrict__ keys, i64 m, const SelState* __restrict__ st,
+                                                  int shift, u32* __restrict__ hist) {
+  __shared__ u32 sh[256];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 prefix = st->prefix;
+  const u64 himask = shift >= 56 ? 0ull : (~0ull << (shift + 8));
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < m; j += (i64)gridDim.x * 256) {
+    const u64 k = keys[j];
+    if ((k & himask) == (prefix & himask)) atomicAdd(&sh[(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+__global__ void k_sel_pick(SelState* st, int shift, u32* hist) {
+  // one thread: walk the 256 bins from the top
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u32 k = st->kremain, cum = 0;
+  int d = 255;
+  for (; d > 0; d--) {
+    if (cum + hist[d] >= k) break;
+    cum += hist[d];
+  }
+  st->prefix |= ((u64)d) << shift;
+  st->kremain = k - cum;
+  for (int i = 0; i < 256; i++) hist[i] = 0;
+  if (shift == 0) {
+    st->thresh = st->prefix;
+    st->n_eq_take = st->kremain;
+  }
+}
+
+// per-block counts of (key > T) and (key == T)
+#define CMP_BLOCK 1024
+__global__ __launch_bounds__(CMP_BLOCK) void k_sel_count(const u64* __restrict__ keys, i64 m, const SelState* __restrict__ st,
+                                                        u32* __restrict__ bgt, u32* __restrict__ beq) {
+  __shared__ u32 sg[CMP_BLOCK / 64], se[CMP_BLOCK / 64];
+  const i64 j = (i64)blockIdx.x * CMP_BLOCK + threadIdx.x;
+  const u64 T = st->thresh;
+  const u64 k = j < m ? keys[j] : 0ull;
+  const bool gt = j < m && k > T, eq = j < m && k == T;
+  const u32 cg = (u32)__popcll(__ballot(gt)), ce = (u32)__popcll(__ballot(eq));
+  if ((threadIdx.x & 63) == 0) { sg[threadIdx.x >> 6] = cg; se[threadIdx.x >> 6] = ce; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 a = 0, b = 0;
+    for (int w = 0; w < CMP_BLOCK / 64; w++) { a += sg[w]; b += se[w]; }
+    bgt[blockIdx.x] = a; beq[blockIdx.x] = b;
+  }
+}
+
+// single block: exclusive scans of the per-block counts (in place) + totals
+__global__ __launch_bounds__(1024) void k_sel_scan(u32* bgt, u32* beq, i64 nb, SelState* st) {
+  __shared__ u32 sa[1024], sb[1024];
+  __shared__ u32 ca, cb;
+  if (threadIdx.x == 0) { ca = 0; cb = 0; }
+  __syncthreads();
+  for (i64 base = 0; base < nb; base += 1024) {
+    const i64 i = base + threadIdx.x;
+    const u32 va = i < nb ? bgt[i] : 0u, vb = i < nb ? beq[i] : 0u;
+    sa[threadIdx.x] = va; sb[threadIdx.x] = vb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const u32 ta = (int)threadIdx.x >= o ? sa[threadIdx.x - o] : 0u;
+      const u32 tb = (int)threadIdx.x >= o ? sb[threadIdx.x - o] : 0u;
+      __syncthreads();
+      sa[threadIdx.x] += ta; sb[threadIdx.x] += tb;
+      __syncthreads();
+    }
+    if (i < nb) { bgt[i] = ca + sa[threadIdx.x] - va; beq[i] = cb + sb[threadIdx.x] - vb; }
+    __syncthreads();
+    if (threadIdx.x == 1023) { ca += sa[1023]; cb += sb[1023]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st->n_gt = ca;
+}
+
+struct Cand { u64 key; u32 idx; u32 pad; };
+
+__global__ __launch_bounds__(CMP_BLOCK) void k_sel_compact(const u64* __restrict__ keys, i64 m, const SelState* __restrict__ st,
+                                                          const u32* __restrict__ bgt, const u32* __restrict__ beq,
+                                                          Cand* __restrict__ cand) {
+  __shared__ u32 sg[CMP_BLOCK / 64], se[CMP_BLOCK / 64];
+  const i64 j = (i64)blockIdx.x * CMP_BLOCK + threadIdx.x;
+  const u64 T = st->thresh;
+  const u64 k = j < m ? keys[j] : 0ull;
+  const bool gt = j < m && k > T, eq = j < m && k == T;
+  const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sg[w] = (u32)__popcll(mg); se[w] = (u32)__popcll(me); }
+  __syncthreads();
+  u32 og = bgt[blockIdx.x], oe = beq[blockIdx.x];
+  for (int q = 0; q < w; q++) { og += sg[q]; oe += se[q]; }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (gt) {
+    const u32 pos = og + (u32)__popcll(mg & below);
+    cand[pos].key = k; cand[pos].idx = (u32)j; cand[pos].pad = 0;
+  } else if (eq) {
+    const u32 r = oe + (u32)__popcll(me & below);
+    if (r < st->n_eq_take) {
+      const u32 pos = st->n_gt + r;
+      cand[pos].key = k; cand[pos].idx = (u32)j; cand[pos].pad = 0;
+    }
+  }
+}
+
+__device__ __forceinline__ bool cand_before(const Cand& a, const Cand& b) {
+  // larger |g| first, then lower column id
+  return a.key > b.key || (a.key == b.key && a.idx < b.idx);
+}
+
+// one workgroup bitonic sort of P = 2^k candidates held in global memory (L2-resident, <= 2N)
+__global__ __launch_bounds__(1024) void k_sel_sort(Cand* __restrict__ c, u32 K, u32 P, u32 Nth, SelState* st) {
+  for (u32 i = K + threadIdx.x; i < P; i += 1024) { c[i].key = 0ull; c[i].idx = 0xFFFFFFFFu; c[i].pad = 0; }
+  __syncthreads();
+  for (u32 size = 2; size <= P; size <<= 1) {
+    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+      for (u32 t = threadIdx.x; t < P / 2; t += 1024) {
+        const u32 lo = 2 * t - (t & (stride - 1));
+        const u32 hi = lo + stride;
+        const bool up = (lo & size) == 0;     // ascending block in "before" order
+        Cand a = c[lo], b = c[hi];
+        const bool swap = up ? cand_before(b, a) : cand_before(a, b);
+        if (swap) { c[lo] = b; c[hi] = a; }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) { st->vkey = (Nth >= 1 && Nth <= K) ? c[Nth - 1].key : 0ull; st->wkey = 0ull; }
+}
+
+__global__ __launch_bounds__(256) void k_sel_wmax(const u64* __restrict__ keys, i64 m, SelState* st) {
+  // w = max{ |g_k| : |g_k| < v }   (computeLambda :186-190); integer max -> order independent
+  const u64 v = st->vkey;
+  u64 best = 0ull;
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < m; j += (i64)gridDim.x * 256) {
+    const u64 k = keys[j];
+    if (k < v && k > best) best = k;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 t = __shfl_xor(best, o, 64);
+    if (t > best) best = t;
+  }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax((unsigned long long*)&st->wkey, (unsigned long long)best);
+}
+
+static inline double key_to_double(u64 k) { double d; memcpy(&d, &k, 8); return d; }
+
+int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
+                       double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
+                       int* ok_out, i64* picked_out) {
+  KLR_ARG(ctx, m >= 0 && N >= 0 && b != nullptr);
+  const i64 K = std::min<i64>(m, 2 * N);             // NLargestAbsFloat64(g_, 2N)
+  std::vector<Cand> hc((size_t)std::max<i64>(K, 1));
+  SelState hs; memset(&hs, 0, sizeof(hs));
+  if (K > 0) {
+    hipStream_t st = ctx->stream;
+    u64* keys; char* misc; Cand* cand;
+    const i64 nb = ceil_div(m, CMP_BLOCK);
+    u32 P = 1; while ((i64)P < K) P <<= 1; if (P < 2) P = 2;
+    KLR_TRY(ws_get(ctx, WS_SEL_KEYS, (size_t)m * sizeof(u64), (void**)&keys));
+    const size_t misc_bytes = sizeof(SelState) + 256 * sizeof(u32) + (size_t)nb * 2 * sizeof(u32) + 64;
+    KLR_TRY(ws_get(ctx, WS_SEL_MISC, misc_bytes, (void**)&misc));
+    KLR_TRY(ws_get(ctx, WS_SEL_CAND, (size_t)P * sizeof(Cand), (void**)&cand));
+    SelState* dst = (SelState*)misc;
+    u32* hist = (u32*)(misc + sizeof(SelState));
+    u32* bgt = hist + 256;
+    u32* beq = bgt + nb;
+    SelState init; memset(&init, 0, sizeof(init));
+    init.kremain = (u32)K;
+    KLR_HIP(ctx, hipMemsetAsync(misc, 0, misc_bytes, st));
+    KLR_TRY(h2d(ctx, dst, &init, sizeof(init)));
+    hipLaunchKernelGGL(k_sel_keys, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, g_dev, m, keys);
+    const unsigned hgrid = (unsigned)std::min<i64>(ceil_div(m, 256 * 8), 1024);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      hipLaunchKernelGGL(k_sel_hist, dim3(std::max(1u, hgrid)), dim3(256), 0, st, keys, m, dst, shift, hist);
+      hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, st, dst, shift, hist);
+    }
+    hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, keys, m, dst, bgt, beq);
+    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, bgt, beq, nb, dst);
+    hipLaunchKernelGGL(k_sel_compact, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, keys, m, dst, bgt, beq, cand);
+    hipLaunchKernelGGL(k_sel_sort, dim3(1), dim3(1024), 0, st, cand, (u32)K, P, (u32)N, dst);
+    hipLaunchKernelGGL(k_sel_wmax, dim3(std::max(1u, hgrid)), dim3(256), 0, st, keys, m, dst);
+    KLR_HIP(ctx, hipGetLastError());
+    KLR_HIP(ctx, hipMemcpyAsync(hc.data(), cand, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
+    KLR_TRY(d2h_sync(ctx, &hs, dst, sizeof(hs)));
+  }
+  // ---- Select :95-119 on the sorted candidates ------------------------------------------------
+  i64 c = c_prev;
+  int ok = 0;
+  for (i64 k = 0; k < K; k++) {                                        // :95-105
+    if (c >= N) break;
+    const u32 j = hc[k].idx;
+    if (!b[j + 1] && hc[k].key != 0ull) { ok = 1; b[j + 1] = 1; c++; }
+  }
+  for (i64 k = 0; k < K; k++) {                                        // :107-116
+    if (c >= N) break;
+    const u32 j = hc[k].idx;
+    if (!b[j + 1]) { b[j + 1] = 1; c++; }
+  }
+  if (c > N) ok = 1;                                                   // :117-119
+  // computeLambda :179-192
+  double l = 0.0;
+  if (!(N > K) && N >= 1) {
+    const double v = key_to_double(hs.vkey), w = key_to_double(hs.wkey);
+    l = (v + w) / 2.0;
+  }
+  if (picked_out) for (i64 k = 0; k < K; k++) picked_out[k] = (i64)hc[k].idx;
+  *lambda_out = l;
+  *c_out = c;
+  *ok_out = (ok || (eps_lambda > 0.0 && std::fabs(lambda_prev - l) >= eps_lambda)) ? 1 : 0;   // :133
+  return KLR_OK;
+}
+
+extern "C" int klr_select(klr_ctx* ctx, const double* g, int64_t m, uint8_t* b, int64_t c_prev, int64_t N,
+                          double lambda_prev, double eps_lambda, double* lambda_out, int64_t* c_out, int* ok_out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, (g != nullptr || m == 0) && b != nullptr && lambda_out && c_out && ok_out);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  double* gd;
+  KLR_TRY(ws_get(ctx, WS_G, (size_t)(m + 8) * sizeof(double), (void**)&gd));
+  if (m) KLR_TRY(h2d(ctx, gd + 1, g, (size_t)m * sizeof(double)));
+  return select_from_device(ctx, gd, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr);
+}
+
+// featureSelector.SelectFixed (kmerLr_feature_selection.go:136-159): a sequential scan in column
+// order with an early exit -- O(m) compares on an array already on the host.
+extern "C" int klr_select_fixed(klr_ctx* ctx, const double* g_full, int64_t m, uint8_t* b, int64_t c_prev,
+                                double lambda, int64_t max_features, int64_t* c_out, int* ok_out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, g_full != nullptr && b != nullptr && c_out && ok_out);
+  int ok = 0; i64 c = c_prev;
+  for (i64 k = 1; k < m + 1; k++) {
+    if (std::fabs(g_full[k]) >= lambda && !b[k]) { ok = 1; b[k] = 1; c++; }
+    if (max_features > 0 && c >= max_features && ok) break;
+  }
+  *c_out = c; *ok_out = ok;
+  return KLR_OK;
+}
+
+// =================================================================================================
+// fused leapfrog epoch step: kmerLr_estimator.go:235 (Select) with the gradient of
+// kmerLr_feature_selection.go:87 computed in a single pass over the full CSC.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_store_scalar(double* dst, const double* src) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
+}
+
+extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat* reduced,
+                                const int64_t* red_cols, const double* theta_red, int64_t c_plus_1,
+                                const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
+                                uint8_t* b, double* lambda_out, int64_t* c_out, int* ok_out,
+                                double* loss_out, double* g_out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, full != nullptr && cw != nullptr && b != nullptr && lambda_out && c_out && ok_out);
+  KLR_ARG(ctx, theta_red != nullptr && c_plus_1 >= 1);
+  KLR_ARG(ctx, reduced == nullptr || (reduced->dim == c_plus_1 && reduced->n == full->n && red_cols != nullptr));
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 n = full->n, dim = full->dim, m = dim - 1;
+  double *s, *gbuf, *thd;
+  KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&s));
+  KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&gbuf));
+  // restoreNonzero (:194-219): b[0] = 1 and b[j] = 1 where theta_j != 0; c = count
+  i64 c_prev = 0;
+  memset(b, 0, (size_t)dim);
+  b[0] = 1;
+  if (reduced) {
+    for (i64 p = 1; p < c_plus_1; p++) {
+      KLR_ARG(ctx, red_cols[p] > 0 && red_cols[p] < dim);
+      if (theta_red[p] != 0.0) { b[red_cols[p]] = 1; c_prev++; }
+    }
+    KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
+    KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
+    KLR_TRY(launch_row_pass(ctx, reduced, thd, ROW_SWEEP, cw, s, nullptr, gbuf + dim + 1));
+  } else {
+    KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, nullptr, gbuf + dim + 1));
+  }
+  KLR_TRY(launch_xt_s(ctx, full, s, gbuf, false));
+  // [g | loss] contiguous for ONE all-reduce per sweep
+  hipLaunchKernelGGL(k_store_scalar, dim3(1), dim3(64), 0, ctx->stream, gbuf + dim, gbuf + dim + 1);
+  KLR_TRY(klr_allreduce(ctx, gbuf, dim + 1));
+  if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  double loss_sum = 0.0;
+  KLR_HIP(ctx, hipMemcpyAsync(&loss_sum, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr));
+  if (loss_out) *loss_out = full->n_total ? loss_sum / (double)full->n_total : 0.0;
+  return KLR_OK;
+}

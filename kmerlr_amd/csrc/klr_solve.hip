@@ -1,0 +1,344 @@
+// klr_solve.hip -- the reduced-problem solver: IRLS + covariance-update cyclic coordinate descent
+// with soft threshold (the algorithm of kmerLr_estimator_coordinate.go:31-139, see oracle
+// klo_cd_solve for the exact semantics), eval_stopping (kmerLr_estimator_proximal.go:30-52) and the
+// hook's loss rule (kmerLr_estimator_hook.go:46-99).
+//
+// Per IRLS iteration:
+//   row pass (CSR)          r, p, w = cw p(1-p), z                              [n rows]
+//   Gram     (CSC + CSR)    G = X'WX, xy = X'Wz  -> ONE all-reduce of d*d+d doubles
+//   sweeps   (1 workgroup)  Gauss-Seidel over the d coordinates on the replicated Gram; q = G theta is
+//                           kept current with a rank-1 update per changed coordinate, so coordinates
+//                           whose value does not move cost no synchronisation
+//   loss     (CSR)          log-loss of every sweep's theta in one pass -> ONE all-reduce of K scalars
+// Sweeps are issued K at a time ("speculatively"); the host replays the reference's per-sweep
+// hook/stop logic over the K recorded iterates and discards those after the stopping one, so the
+// iterate sequence is exactly the sweep-by-sweep one.
+#include "klr_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#define KSPEC 8          // sweeps per launch
+#define CD_THREADS 1024
+
+__global__ __launch_bounds__(256) void k_mul(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o, i64 n) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) o[i] = a[i] * b[i];
+}
+
+// off-diagonal, non-bias Gram cells from the short reduced rows:  G[ja][jb] += w_i v_a v_b
+__global__ __launch_bounds__(256) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                      const double* __restrict__ val, const double* __restrict__ w,
+                                                      i64 n, int d, double* __restrict__ G) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const i64 b = rowptr[i], e = rowptr[i + 1];
+  const double wi = w[i];
+  for (i64 a = b + 1; a < e; a++) {
+    const double wa = wi * val[a];
+    const i64 ja = col[a];
+    for (i64 c = b + 1; c < e; c++) {
+      if (c == a) continue;
+      unsafeAtomicAdd(&G[ja * d + col[c]], wa * val[c]);
+    }
+  }
+}
+
+// row 0 / column 0 / diagonal from the three column sweeps
+__global__ __launch_bounds__(256) void k_gram_assemble(const double* __restrict__ a0, const double* __restrict__ nm, int d,
+                                                       double* __restrict__ G) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= d) return;
+  G[(i64)j * d + j] = nm[j];
+  if (j > 0) { G[j] = a0[j]; G[(i64)j * d] = a0[j]; }
+}
+
+struct CdArgs {
+  const double* G; const double* xy; int d;
+  double* theta;              // in/out (device)
+  double l1reg, l2reg, eps;
+  int K;
+  double* hist;               // K*d iterates
+  double* delta;              // K eval_stopping deltas
+  int* stopf;                 // K eval_stopping verdicts
+  int* ndone;
+  int g_in_lds;
+};
+
+// One workgroup.  LDS: theta[d], q[d], diag[d], xyv[d] (+ G[d*d] when it fits).
+__global__ __launch_bounds__(CD_THREADS) void k_cd_sweeps(CdArgs a) {
+  extern __shared__ double lds[];
+  const int d = a.d, tid = threadIdx.x;
+  double* th = lds;
+  double* q = th + d;
+  double* dg = q + d;
+  double* xyv = dg + d;
+  double* Gl = xyv + d;
+  __shared__ double sh_delta;
+  __shared__ int sh_j, sh_flag;
+  const double* G = a.G;
+  if (a.g_in_lds) {
+    for (i64 i = tid; i < (i64)d * d; i += CD_THREADS) Gl[i] = a.G[i];
+    G = Gl;
+  }
+  for (int i = tid; i < d; i += CD_THREADS) { th[i] = a.theta[i]; xyv[i] = a.xy[i]; dg[i] = a.G[(i64)i * d + i]; }
+  __syncthreads();
+  // q = G theta (skipping zero coefficients)
+  for (int i = tid; i < d; i += CD_THREADS) {
+    double s = 0.0;
+    for (int k = 0; k < d; k++) { const double t = th[k]; if (t != 0.0) s += G[(i64)k * d + i] * t; }
+    q[i] = s;
+  }
+  __syncthreads();
+  int done = 0;
+  for (int k = 0; k < a.K; k++) {
+    double max_x = 0.0, max_delta = 0.0;   // thread 0 only
+    int isnan_ = 0;
+    int j = 0;
+    while (true) {
+      // thread 0 walks coordinates until one moves
+      if (tid == 0) {
+        double dl = 0.0;
+        for (; j < d; j++) {
+          const double old = th[j];
+          double t = xyv[j] + dg[j] * old - q[j];                 // coordinate.go:56-59
+          if (j > 0) {                                            // :60-67 soft threshold
+            const double m = fmax(fabs(t) - a.l1reg, 0.0);
+            t = (t >= 0.0) ? m : -m;
+          }
+          t /= (dg[j] + a.l2reg);                                 // :69
+          if (t != t) isnan_ = 1;
+          th[j] = t;                                              // :70-71
+          max_x = fmax(max_x, fabs(t));
+          dl = t - old;
+          max_delta = fmax(max_delta, fabs(dl));
+          if (dl != 0.0 || t != t) break;
+        }
+        sh_j = j; sh_delta = dl;
+      }
+      __syncthreads();
+      const int jj = sh_j;
+      const double dl = sh_delta;
+      if (jj >= d) break;
+      for (int i = tid; i < d; i += CD_THREADS) q[i] += dl * G[(i64)jj * d + i];
+      __syncthreads();
+      j = jj + 1;
+    }
+    // record the iterate and eval_stopping (proximal.go:30-52)
+    for (int i = tid; i < d; i += CD_THREADS) a.hist[(i64)k * d + i] = th[i];
+    if (tid == 0) {
+      double delta; int stop;
+      if (isnan_) { delta = nan(""); stop = 1; }
+      else {
+        delta = (max_x != 0.0) ? max_delta / max_x : max_delta;
+        stop = ((max_x != 0.0 && max_delta / max_x <= a.eps) || (max_x == 0.0 && max_delta == 0.0)) ? 1 : 0;
+      }
+      a.delta[k] = delta; a.stopf[k] = stop; sh_flag = stop;
+    }
+    done = k + 1;
+    __syncthreads();
+    if (sh_flag) break;
+  }
+  for (int i = tid; i < d; i += CD_THREADS) a.theta[i] = th[i];
+  if (tid == 0) *a.ndone = done;
+}
+
+// log-loss of up to KSPEC iterates in one pass over the reduced rows (thread per row)
+__global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                    const double* __restrict__ val, const uint8_t* __restrict__ labels,
+                                                    i64 n, int d, const double* __restrict__ hist, const int* __restrict__ ndone,
+                                                    double cw0, double cw1, double* __restrict__ blk) {
+  __shared__ double sh[KSPEC][4];
+  const int K = *ndone;
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  double term[KSPEC];
+#pragma unroll
+  for (int k = 0; k < KSPEC; k++) term[k] = 0.0;
+  if (i < n) {
+    const i64 b = rowptr[i], e = rowptr[i + 1];
+    const int y = labels[i] != 0;
+#pragma unroll
+    for (int k = 0; k < KSPEC; k++) {
+      if (k < K) {
+        const double* th = hist + (i64)k * d;
+        double r = 0.0;
+        for (i64 p = b + 1; p < e; p++) r += val[p] * th[col[p]];
+        r = th[0] + r;
+        const double a = fabs(r);
+        const double l1p = log1p(exp(-a));
+        // y: -log sigma(r) = LogAdd(0,-r);  !y: LogAdd(0,r)
+        term[k] = y ? cw1 * (fmax(-r, 0.0) + l1p) : cw0 * (fmax(r, 0.0) + l1p);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KSPEC; k++) {
+    double v = term[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < KSPEC) blk[(i64)blockIdx.x * KSPEC + threadIdx.x] =
+      (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(1024) void k_sum_partials_multi(const double* __restrict__ blk, i64 nb, double* __restrict__ out) {
+  // block k sums column k of blk[nb][KSPEC] in a fixed order
+  __shared__ double sh[1024];
+  const int k = blockIdx.x;
+  double v = 0.0;
+  for (i64 i = threadIdx.x; i < nb; i += 1024) v += blk[i * KSPEC + k];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[k] = sh[0];
+}
+
+static bool host_eval_stopping(const double* xs, const double* x1, i64 len, double eps, double* delta_out) {
+  double max_x = 0.0, max_delta = 0.0;
+  for (i64 i = 0; i < len; i++) {
+    if (std::isnan(x1[i])) { *delta_out = NAN; return true; }
+    max_x = std::fmax(max_x, std::fabs(x1[i]));
+    max_delta = std::fmax(max_delta, std::fabs(x1[i] - xs[i]));
+  }
+  *delta_out = (max_x != 0.0) ? max_delta / max_x : max_delta;
+  return (max_x != 0.0 && max_delta / max_x <= eps) || (max_x == 0.0 && max_delta == 0.0);
+}
+
+extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, const double cw[2],
+                            double l1reg, double l2reg, double eps, double eps_loss, int eval_loss,
+                            int64_t max_iter, klr_iter_rec* recs, int64_t recs_cap, int64_t* n_recs) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, red != nullptr && theta != nullptr && cw != nullptr);
+  KLR_ARG(ctx, red->val_f64);   // reduced matrices hold f64 values (select_columns output)
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 n = red->n;
+  const int d = (int)red->dim;
+  const i64 n_total = red->n_total;
+  if (max_iter <= 0) max_iter = INT32_MAX;
+  const size_t lds_small = (size_t)4 * d * sizeof(double);
+  const size_t lds_big = lds_small + (size_t)d * d * sizeof(double);
+  const size_t LDS_MAX = 160 * 1024 - 1024;
+  if (lds_small > LDS_MAX)
+    return klr_fail(ctx, KLR_EINVAL, "%d selected features exceed the device solver's limit (%zu)", d - 1, LDS_MAX / 32 - 1);
+  const int g_in_lds = lds_big <= LDS_MAX;
+  const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
+  static bool attr_set = false;
+  if (!attr_set) {
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    attr_set = true;
+  }
+
+  hipStream_t st = ctx->stream;
+  double *w, *z, *wz, *Gxy, *vec, *lossb;
+  KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * 8, (void**)&w));
+  KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&z));
+  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * 8, (void**)&wz));
+  KLR_TRY(ws_get(ctx, WS_CD_G, ((size_t)d * d + d) * 8, (void**)&Gxy));
+  double* G = Gxy; double* xy = Gxy + (size_t)d * d;
+  // vec: a0[d] nm[d] theta[d] hist[K*d] delta[K] | ints: stopf[K] ndone
+  const size_t vec_bytes = ((size_t)3 * d + (size_t)KSPEC * d + KSPEC) * 8 + (KSPEC + 8) * sizeof(int);
+  KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
+  double* a0 = vec; double* nm = a0 + d; double* thd = nm + d; double* hist = thd + d; double* delta = hist + (size_t)KSPEC * d;
+  int* stopf = (int*)(delta + KSPEC); int* ndone = stopf + KSPEC;
+  const i64 nb = std::max<i64>(1, ceil_div(n, 256));
+  KLR_TRY(ws_get(ctx, WS_CD_LOSS, ((size_t)nb * KSPEC + KSPEC) * 8, (void**)&lossb));
+  double* losses = lossb + (size_t)nb * KSPEC;
+
+  std::vector<double> th(theta, theta + d), tp(d), hhist((size_t)KSPEC * d), hdelta(KSPEC), hloss(KSPEC);
+  std::vector<int> hstop(KSPEC + 1);
+  KLR_TRY(h2d(ctx, thd, th.data(), (size_t)d * 8));
+
+  const auto t0 = std::chrono::steady_clock::now();
+  const double lambda = l1reg / (double)n_total;
+  double loss_old = NAN, loss_new = NAN, loss_outer_prev = NAN;
+  i64 count = 0;
+  auto full_loss = [&](const double* t, double sum) {
+    double r = n_total ? sum / (double)n_total : 0.0;
+    if (!std::isnan(lambda) && lambda != 0.0) for (int j = 1; j < d; j++) r += lambda * std::fabs(t[j]);
+    return r;
+  };
+
+  for (i64 iter = 0; iter < max_iter; iter++) {
+    // ---- IRLS linearisation + Gram --------------------------------------------------------------
+    KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr));
+    if (n) hipLaunchKernelGGL(k_mul, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, w, z, wz, n);
+    KLR_HIP(ctx, hipMemsetAsync(G, 0, (size_t)d * d * 8, st));
+    KLR_TRY(launch_xt_s(ctx, red, w, a0, false));      // sum_i w_i x_ij      -> row/column 0
+    KLR_TRY(launch_xt_s(ctx, red, w, nm, true));       // sum_i w_i x_ij^2    -> diagonal (norm)
+    KLR_TRY(launch_xt_s(ctx, red, wz, xy, false));     // sum_i w_i z_i x_ij  -> inner_xy
+    if (n) hipLaunchKernelGGL(k_gram_offdiag, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, red->rowptr, red->col,
+                              (const double*)red->val, w, n, d, G);
+    hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, a0, nm, d, G);
+    KLR_HIP(ctx, hipGetLastError());
+    KLR_TRY(klr_allreduce(ctx, Gxy, (i64)d * d + d));
+    tp = th;
+
+    // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
+    bool inner_done = false;
+    double accepted_sum = NAN; bool have_sum = false;
+    while (!inner_done && iter < max_iter) {
+      const int Kb = (int)std::min<i64>(KSPEC, max_iter - iter);
+      CdArgs a;
+      a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
+      a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
+      hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
+      if (eval_loss) {
+        hipLaunchKernelGGL(k_loss_multi, dim3((unsigned)nb), dim3(256), 0, st, red->rowptr, red->col, (const double*)red->val,
+                           red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
+        hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
+        KLR_TRY(klr_allreduce(ctx, losses, KSPEC));
+        KLR_HIP(ctx, hipMemcpyAsync(hloss.data(), losses, KSPEC * 8, hipMemcpyDeviceToHost, st));
+      }
+      KLR_HIP(ctx, hipGetLastError());
+      KLR_HIP(ctx, hipMemcpyAsync(hhist.data(), hist, (size_t)Kb * d * 8, hipMemcpyDeviceToHost, st));
+      KLR_HIP(ctx, hipMemcpyAsync(hdelta.data(), delta, KSPEC * 8, hipMemcpyDeviceToHost, st));
+      KLR_TRY(d2h_sync(ctx, hstop.data(), stopf, (KSPEC + 1) * sizeof(int)));
+      const int nd = hstop[KSPEC];
+      bool cut = false;     // stopped before the end of the batch -> device theta must be rewound
+      for (int k = 0; k < nd; k++) {
+        th.assign(hhist.begin() + (size_t)k * d, hhist.begin() + (size_t)(k + 1) * d);
+        if (eval_loss) { accepted_sum = hloss[k]; have_sum = true; }
+        if (hstop[k]) { inner_done = true; cut = (k + 1 < nd); break; }                  // coordinate.go:74-75
+        // hook (kmerLr_estimator_hook.go:46-99)
+        std::swap(loss_old, loss_new);
+        if (eval_loss) loss_new = full_loss(th.data(), hloss[k]);
+        if (recs && count < recs_cap) {
+          int nz = 0;
+          for (int j = 0; j < d; j++) if (th[j] != 0.0) nz++;
+          klr_iter_rec& r = recs[count];
+          r.iteration = (int32_t)iter; r.nonzero = nz; r.change = hdelta[k]; r.lambda = lambda; r.loss = loss_new;
+          r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        count++;
+        if (eps_loss != 0.0 && std::fabs(loss_old - loss_new) < eps_loss) { inner_done = true; cut = (k + 1 < nd); break; }
+        iter++;
+        if (iter >= max_iter) { inner_done = true; cut = (k + 1 < nd); break; }
+      }
+      if (cut) KLR_TRY(h2d(ctx, thd, th.data(), (size_t)d * 8));
+      if (nd == 0) inner_done = true;
+    }
+    // ---- outer checks -----------------------------------------------------------------------------
+    double dl;
+    if (host_eval_stopping(tp.data(), th.data(), d, eps, &dl)) break;                   // coordinate.go:119-120
+    if (eval_loss && eps_loss != 0.0) {
+      if (!have_sum) {
+        double* acc = lossb;
+        KLR_TRY(launch_row_pass(ctx, red, thd, ROW_LOSS, cw, nullptr, nullptr, acc));
+        KLR_TRY(klr_allreduce(ctx, acc, 1));
+        KLR_TRY(d2h_sync(ctx, &accepted_sum, acc, 8));
+      }
+      const double lc = full_loss(th.data(), accepted_sum);
+      if (std::fabs(loss_outer_prev - lc) < eps_loss) break;
+      loss_outer_prev = lc;
+    }
+  }
+  KLR_HIP(ctx, hipStreamSynchronize(st));
+  memcpy(theta, th.data(), (size_t)d * 8);
+  if (n_recs) *n_recs = count;
+  return KLR_OK;
+}

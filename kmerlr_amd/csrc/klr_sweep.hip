@@ -1,0 +1,380 @@
+// klr_sweep.hip -- the two passes of logisticRegression.Gradient / Loss
+// (kmerLr_logistic_regression.go:151-272) as HIP kernels for gfx950:
+//
+//   row pass     r_i = x_i . theta, log sigma, s_i = cw[y]/n (sigma - y), loss terms       (CSR)
+//   column sweep g_j = sum_i s_i x_ij : one lane group per column chunk, 16-byte coalesced
+//                reads of the CSC row-id and value streams, f64 gather of s, f64 FMA,
+//                shuffle reduction inside the group                                        (CSC)
+//
+// The column sweep is the HBM-roofline kernel (DESIGN.md "kernels"): algorithmic bytes per stored
+// nonzero = 4 (row id) + 4|8 (value); s (8n bytes) is gathered from L2.
+#include "klr_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+// ---------------------------------------------------------------------------------------------
+// scalar arithmetic shared by all row passes; mirrors oracle/klr_oracle.c
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double d_log_add0(double x) {
+  // LogAdd(0, x) = log(1 + e^x) = max(0,x) + log1p(exp(-|x|))   (autodiff logarithmetic.LogAdd)
+  const double a = fabs(x);
+  return fmax(x, 0.0) + log1p(exp(-a));
+}
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row pass: G lanes per row
+// ---------------------------------------------------------------------------------------------
+struct RowPassArgs {
+  const i64* rowptr; const u32* col; const void* val; const uint8_t* labels;
+  const double* theta; i64 n; double inv_n; double cw0, cw1;
+  double* out0; double* out1; double* blk;   // blk: per-block loss partials
+  double theta0_only; int const_mode;
+};
+
+__device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i, double r, double& loss_term) {
+  const int y = a.labels[i] != 0;
+  const double lp = -d_log_add0(-r);                 // log sigma(r), LogPdf (:147-149)
+  if (mode == ROW_LOGPDF) { a.out0[i] = lp; loss_term = 0.0; return; }
+  // Loss: r -= cw[y] * ClassLogPdf (:258-264)
+  loss_term = y ? a.cw1 * (-lp) : a.cw0 * d_log_add0(r);
+  if (mode == ROW_SWEEP) {
+    const double e = exp(lp);
+    // Gradient weights (:174-178), same association as the reference: 1/n * cw * (...)
+    a.out0[i] = y ? a.inv_n * a.cw1 * (e - 1.0) : a.inv_n * a.cw0 * e;
+  } else if (mode == ROW_IRLS) {
+    // estimate_coordinate (:97-111) with the guarded weight of oracle KLO_IRLS_WMIN
+    const double p = exp(lp);
+    double w = p * (1.0 - p);
+    if (w < 1e-12) w = 1e-12;
+    a.out1[i] = r + ((y ? 1.0 : 0.0) - p) / w;
+    a.out0[i] = w * (y ? a.cw1 : a.cw0);
+  }
+}
+
+template <typename VT, int G, int MODE>
+__global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
+  __shared__ double sh[256 / 64];
+  const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  double loss_term = 0.0;
+  if (gid < a.n) {
+    double r;
+    if (a.const_mode) {
+      r = a.theta0_only;
+    } else {
+      const i64 b = a.rowptr[gid], e = a.rowptr[gid + 1];
+      const VT* val = (const VT*)a.val;
+      // LinearPdf (:47-68): r = theta[0] + sum_{j>=1} v_j theta[i_j]; entry 0 is the bias
+      double acc = 0.0;
+      for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * a.theta[a.col[p]];
+      acc = group_sum<G>(acc);
+      r = a.theta[0] + acc;
+    }
+    if (lane == 0) row_finish(a, MODE, gid, r, loss_term);
+  }
+  if (MODE != ROW_LOGPDF) {
+    // block partial of the loss: fixed order -> deterministic
+    double v = loss_term;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) a.blk[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  }
+}
+
+// sums nb block partials in a fixed order into *out
+__global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ blk, i64 nb, double* __restrict__ out) {
+  __shared__ double sh[1024];
+  double v = 0.0;
+  for (i64 i = threadIdx.x; i < nb; i += 1024) v += blk[i];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+template <typename VT, int G>
+static void row_pass_mode(int mode, dim3 grid, hipStream_t st, const RowPassArgs& a) {
+  switch (mode) {
+    case ROW_SWEEP:  hipLaunchKernelGGL((k_row_pass<VT, G, ROW_SWEEP>), grid, dim3(256), 0, st, a); break;
+    case ROW_LOSS:   hipLaunchKernelGGL((k_row_pass<VT, G, ROW_LOSS>), grid, dim3(256), 0, st, a); break;
+    case ROW_IRLS:   hipLaunchKernelGGL((k_row_pass<VT, G, ROW_IRLS>), grid, dim3(256), 0, st, a); break;
+    default:         hipLaunchKernelGGL((k_row_pass<VT, G, ROW_LOGPDF>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+template <typename VT>
+static void row_pass_group(int g, int mode, i64 n, hipStream_t st, const RowPassArgs& a) {
+  const dim3 grid((unsigned)std::max<i64>(1, ceil_div(n * g, 256)));
+  switch (g) {
+    case 1:  row_pass_mode<VT, 1>(mode, grid, st, a); break;
+    case 4:  row_pass_mode<VT, 4>(mode, grid, st, a); break;
+    case 16: row_pass_mode<VT, 16>(mode, grid, st, a); break;
+    default: row_pass_mode<VT, 64>(mode, grid, st, a); break;
+  }
+}
+
+static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
+                           int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev) {
+  const i64 n = mat->n;
+  int g = 64;
+  if (const_mode || mat->avg_row <= 4.0) g = 1;
+  else if (mat->avg_row <= 24.0) g = 4;
+  else if (mat->avg_row <= 160.0) g = 16;
+  const i64 nb = std::max<i64>(1, ceil_div(n * g, 256));
+  double* blk;
+  KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * sizeof(double), (void**)&blk));
+  RowPassArgs a;
+  a.rowptr = mat->rowptr; a.col = mat->col; a.val = mat->val; a.labels = mat->labels;
+  a.theta = theta_dev; a.n = n; a.inv_n = 1.0 / (double)mat->n_total; a.cw0 = cw[0]; a.cw1 = cw[1];
+  a.out0 = out0; a.out1 = out1; a.blk = blk; a.theta0_only = theta0; a.const_mode = const_mode ? 1 : 0;
+  if (n > 0) {
+    if (mat->val_f64) row_pass_group<double>(g, mode, n, ctx->stream, a);
+    else              row_pass_group<float>(g, mode, n, ctx->stream, a);
+  }
+  if (loss_acc_dev) {
+    if (n > 0 && mode != ROW_LOGPDF)
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, blk, nb, loss_acc_dev);
+    else
+      KLR_HIP(ctx, hipMemsetAsync(loss_acc_dev, 0, sizeof(double), ctx->stream));
+  }
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
+int launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, int mode, const double cw[2],
+                    double* out0, double* out1, double* loss_acc_dev) {
+  return row_pass_common(ctx, mat, theta_dev, 0.0, false, mode, cw, out0, out1, loss_acc_dev);
+}
+
+int launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
+                     double* out0, double* out1, double* loss_acc_dev) {
+  return row_pass_common(ctx, mat, nullptr, theta0, true, mode, cw, out0, out1, loss_acc_dev);
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sweep  g_raw[j] = sum_i s[row] * x    (the roofline kernel)
+// ---------------------------------------------------------------------------------------------
+template <typename VT> struct V4;
+template <> struct V4<float>  { typedef float4 type; };
+template <> struct V4<double> { typedef double4 type; };
+
+template <typename VT, int G, bool SQ>
+__global__ __launch_bounds__(256) void k_xt_s(const u32* __restrict__ crow, const VT* __restrict__ cval,
+                                              const i64* __restrict__ chunk_begin, const u32* __restrict__ chunk_len,
+                                              i64 nchunks, const double* __restrict__ s, double* __restrict__ part) {
+  const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (gid >= nchunks) return;            // whole groups leave together
+  const i64 b = chunk_begin[gid];
+  const i64 e = b + (i64)chunk_len[gid];
+  typedef typename V4<VT>::type vt4;
+  double acc = 0.0;
+#pragma unroll 2
+  for (i64 p = b + 4 * lane; p < e; p += 4 * G) {
+    const uint4 r = *reinterpret_cast<const uint4*>(crow + p);
+    const vt4 v = *reinterpret_cast<const vt4*>(cval + p);
+    const double s0 = s[r.x], s1 = s[r.y], s2 = s[r.z], s3 = s[r.w];
+    double x0 = (double)v.x, x1 = (double)v.y, x2 = (double)v.z, x3 = (double)v.w;
+    if (SQ) { x0 *= x0; x1 *= x1; x2 *= x2; x3 *= x3; }
+    acc = fma(s0, x0, acc);
+    acc = fma(s1, x1, acc);
+    acc = fma(s2, x2, acc);
+    acc = fma(s3, x3, acc);
+  }
+  acc = group_sum<G>(acc);
+  if (lane == 0) part[gid] = acc;
+}
+
+// adds a column's chunk sums in chunk order
+__global__ __launch_bounds__(256) void k_finish_cols(const i64* __restrict__ colchunk, i64 dim,
+                                                     const double* __restrict__ part, double* __restrict__ g) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= dim) return;
+  double v = 0.0;
+  for (i64 c = colchunk[j]; c < colchunk[j + 1]; c++) v += part[c];
+  g[j] = v;
+}
+
+template <typename VT, bool SQ>
+static void xt_s_group(int g, dim3 grid, hipStream_t st, const klr_mat* m, const double* s, double* part) {
+  const VT* cv = (const VT*)m->cval;
+  switch (g) {
+    case 4:  hipLaunchKernelGGL((k_xt_s<VT, 4, SQ>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, s, part); break;
+    case 8:  hipLaunchKernelGGL((k_xt_s<VT, 8, SQ>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, s, part); break;
+    case 16: hipLaunchKernelGGL((k_xt_s<VT, 16, SQ>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, s, part); break;
+    case 32: hipLaunchKernelGGL((k_xt_s<VT, 32, SQ>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, s, part); break;
+    default: hipLaunchKernelGGL((k_xt_s<VT, 64, SQ>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, s, part); break;
+  }
+}
+
+int launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev, bool square) {
+  double* part;
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<i64>(mat->nchunks, 1) * sizeof(double), (void**)&part));
+  if (mat->nchunks > 0) {
+    const int g = mat->group;
+    const dim3 grid((unsigned)ceil_div(mat->nchunks * g, 256));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = ctx->prof_on && !square;
+    if (prof) {
+      KLR_HIP(ctx, hipEventCreate(&e0));
+      KLR_HIP(ctx, hipEventCreate(&e1));
+      KLR_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    if (mat->val_f64) { if (square) xt_s_group<double, true>(g, grid, ctx->stream, mat, s_dev, part); else xt_s_group<double, false>(g, grid, ctx->stream, mat, s_dev, part); }
+    else              { if (square) xt_s_group<float, true>(g, grid, ctx->stream, mat, s_dev, part);  else xt_s_group<float, false>(g, grid, ctx->stream, mat, s_dev, part); }
+    if (prof) {
+      KLR_HIP(ctx, hipEventRecord(e1, ctx->stream));
+      ctx->prof_ev.emplace_back(e0, e1);
+    }
+  }
+  hipLaunchKernelGGL(k_finish_cols, dim3((unsigned)ceil_div(mat->dim, 256)), dim3(256), 0, ctx->stream, mat->colchunk, mat->dim, part, g_raw_dev);
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finishing: TransformFull on the fly (kmerLr_logistic_regression.go:196-222)
+//   scale only : g_j = scale_j * raw_j
+//   offset     : g_j = scale_j * (raw_j - offset_j * sum_i s_i), sum_i s_i = raw_0 (bias column)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_apply_transform(double* __restrict__ g, i64 dim, const double* __restrict__ scale,
+                                                         const double* __restrict__ offset) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= dim) return;
+  const double ssum = g[0];     // column 0 is never rewritten
+  double v = g[j];
+  if (offset && j > 0) v = v - offset[j] * ssum;
+  if (scale && j > 0) v = v * scale[j];
+  if (j > 0) g[j] = v;
+}
+
+// dense theta (device) from a sparse host theta
+static int upload_sparse_theta(klr_ctx* ctx, i64 dim, const i64* idx, const double* val, i64 nnz, double** out) {
+  double* th;
+  KLR_TRY(ws_get(ctx, WS_THETA, (size_t)dim * sizeof(double), (void**)&th));
+  std::vector<double> h((size_t)dim, 0.0);
+  for (i64 k = 0; k < nnz; k++) {
+    if (idx[k] < 0 || idx[k] >= dim) return klr_fail(ctx, KLR_EINVAL, "theta index %lld out of range", (long long)idx[k]);
+    h[(size_t)idx[k]] = val[k];
+  }
+  KLR_TRY(h2d(ctx, th, h.data(), (size_t)dim * sizeof(double)));
+  *out = th;
+  return KLR_OK;
+}
+
+extern "C" int klr_gradient(klr_ctx* ctx, const klr_mat* mat, const int64_t* th_idx, const double* th_val,
+                            int64_t th_nnz, const double cw[2], const double* scale, const double* offset,
+                            double* g_out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr && cw != nullptr && g_out != nullptr && th_nnz >= 0);
+  KLR_ARG(ctx, th_nnz == 0 || (th_idx != nullptr && th_val != nullptr));
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 n = mat->n, dim = mat->dim;
+  double *s, *gbuf;
+  KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&s));
+  KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&gbuf));
+
+  // effective theta: with an on-the-fly transform, x.theta = sum_j (x_j - o_j) s_j theta_j
+  //   = sum_j x_j (s_j theta_j) + (theta_0 - sum_j o_j s_j theta_j)
+  std::vector<i64> eidx; std::vector<double> evalv;
+  double theta0 = 0.0, shift = 0.0;
+  for (i64 k = 0; k < th_nnz; k++) {
+    KLR_ARG(ctx, th_idx[k] >= 0 && th_idx[k] < dim && (k == 0 || th_idx[k] > th_idx[k - 1]));
+    if (th_idx[k] == 0) { theta0 = th_val[k]; continue; }
+    if (th_val[k] == 0.0) continue;
+    double t = th_val[k];
+    if (scale) t = t * scale[th_idx[k]];
+    if (offset) shift += offset[th_idx[k]] * t;
+    eidx.push_back(th_idx[k]); evalv.push_back(t);
+  }
+  theta0 -= shift;
+
+  klr_mat* tmp = nullptr;
+  int rc = KLR_OK;
+  if (eidx.empty()) {
+    rc = launch_row_const(ctx, mat, theta0, ROW_SWEEP, cw, s, nullptr, nullptr);
+  } else if ((i64)eidx.size() * 8 < dim) {
+    // theta lives on few columns: gather them (CSC side) and run the row pass on the reduced rows
+    std::vector<i64> cols; cols.push_back(0);
+    cols.insert(cols.end(), eidx.begin(), eidx.end());
+    rc = build_reduced(ctx, mat, cols.data(), (i64)cols.size(), nullptr, nullptr, false, &tmp);
+    if (rc == KLR_OK) {
+      std::vector<double> th; th.push_back(theta0); th.insert(th.end(), evalv.begin(), evalv.end());
+      double* thd;
+      rc = ws_get(ctx, WS_THETA, th.size() * sizeof(double), (void**)&thd);
+      if (rc == KLR_OK) rc = h2d(ctx, thd, th.data(), th.size() * sizeof(double));
+      if (rc == KLR_OK) rc = launch_row_pass(ctx, tmp, thd, ROW_SWEEP, cw, s, nullptr, nullptr);
+    }
+  } else {
+    std::vector<i64> idx; std::vector<double> vv;
+    idx.push_back(0); vv.push_back(theta0);
+    idx.insert(idx.end(), eidx.begin(), eidx.end()); vv.insert(vv.end(), evalv.begin(), evalv.end());
+    double* thd;
+    rc = upload_sparse_theta(ctx, dim, idx.data(), vv.data(), (i64)idx.size(), &thd);
+    if (rc == KLR_OK) rc = launch_row_pass(ctx, mat, thd, ROW_SWEEP, cw, s, nullptr, nullptr);
+  }
+  if (rc == KLR_OK) rc = launch_xt_s(ctx, mat, s, gbuf, false);
+  if (rc == KLR_OK) rc = klr_allreduce(ctx, gbuf, dim);
+  if (rc == KLR_OK && (scale || offset)) {
+    double* tr;
+    rc = ws_get(ctx, WS_TMP0, (size_t)dim * 2 * sizeof(double), (void**)&tr);
+    if (rc == KLR_OK && scale) rc = h2d(ctx, tr, scale, (size_t)dim * sizeof(double));
+    if (rc == KLR_OK && offset) rc = h2d(ctx, tr + dim, offset, (size_t)dim * sizeof(double));
+    if (rc == KLR_OK) {
+      hipLaunchKernelGGL(k_apply_transform, dim3((unsigned)ceil_div(dim, 256)), dim3(256), 0, ctx->stream, gbuf, dim,
+                         scale ? tr : nullptr, offset ? tr + dim : nullptr);
+    }
+  }
+  if (rc == KLR_OK) rc = d2h_sync(ctx, g_out, gbuf, (size_t)dim * sizeof(double));
+  if (tmp) { std::string keep = ctx->err; mat_free(tmp); ctx->err = keep; }
+  return rc;
+}
+
+extern "C" int klr_loss(klr_ctx* ctx, const klr_mat* mat, const double* theta, const double cw[2],
+                        double lambda, double* loss_out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr && theta != nullptr && cw != nullptr && loss_out != nullptr);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 dim = mat->dim;
+  double *thd, *acc;
+  KLR_TRY(ws_get(ctx, WS_THETA, (size_t)dim * sizeof(double), (void**)&thd));
+  KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&acc));
+  KLR_TRY(h2d(ctx, thd, theta, (size_t)dim * sizeof(double)));
+  KLR_TRY(launch_row_pass(ctx, mat, thd, ROW_LOSS, cw, nullptr, nullptr, acc));
+  KLR_TRY(klr_allreduce(ctx, acc, 1));
+  double sum = 0.0;
+  KLR_TRY(d2h_sync(ctx, &sum, acc, sizeof(double)));
+  if (mat->n_total == 0) { *loss_out = 0.0; return KLR_OK; }              // :251-253
+  double r = sum / (double)mat->n_total;                                    // :265
+  if (!std::isnan(lambda) && lambda != 0.0)
+    for (i64 j = 1; j < dim; j++) r += lambda * std::fabs(theta[j]);       // :266-270
+  *loss_out = r;
+  return KLR_OK;
+}
+
+extern "C" int klr_log_pdf(klr_ctx* ctx, const klr_mat* mat, const double* theta, double* out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr && theta != nullptr && out != nullptr);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 dim = mat->dim, n = mat->n;
+  double *thd, *o;
+  const double cw[2] = {1.0, 1.0};
+  KLR_TRY(ws_get(ctx, WS_THETA, (size_t)dim * sizeof(double), (void**)&thd));
+  KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&o));
+  KLR_TRY(h2d(ctx, thd, theta, (size_t)dim * sizeof(double)));
+  KLR_TRY(launch_row_pass(ctx, mat, thd, ROW_LOGPDF, cw, o, nullptr, nullptr));
+  KLR_TRY(d2h_sync(ctx, out, o, (size_t)n * sizeof(double)));
+  return KLR_OK;
+}

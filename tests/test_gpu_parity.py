@@ -1,0 +1,280 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same seeded inputs.
+Integer / index results must be bit-exact; floating point within the tolerances written here
+(north_star: coefficients within 1e-6 relative; gradient / loss far tighter)."""
+import numpy as np
+import pytest
+
+import kmerlr_amd as K
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+G_RTOL = 1e-11      # gradient entries, relative to max|g|
+LOSS_ATOL = 1e-12
+THETA_RTOL = 1e-6   # north_star tolerance for coefficients
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def upload(ctx, x, labels, n_total=0):
+    return K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels, n_total)
+
+
+def assert_g_close(g, g_ref):
+    scale = max(np.max(np.abs(g_ref)), 1e-300)
+    assert np.max(np.abs(g - g_ref)) <= G_RTOL * scale
+
+
+@pytest.fixture(scope="module")
+def synth_small():
+    x, labels = O.synth_csr(20261004, 0, 600, 600, 2048, 300, 16)
+    return x, labels
+
+
+@pytest.fixture(scope="module")
+def scores(scores_data):
+    return scores_data
+
+
+def test_golden_g1_g2_g3_on_gpu(ctx, scores):
+    x, labels, _ = scores
+    m = upload(ctx, x, labels)
+    g = K.gradient(ctx, m, [], [], cw=(1.0, 1.0))
+    np.testing.assert_allclose(g[1:], [0.06875, 3.984375, -1.009375, 0.0228125, 0.96875, 0.045625, 4.03125],
+                               rtol=0, atol=1e-13)
+    b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+    ok, lam, c, b2 = K.select(ctx, g[1:], b, 0, 2)
+    assert ok and c == 2 and list(np.nonzero(b2)[0]) == [0, 2, 7]
+    assert "%e" % lam == "2.496875e+00"
+    red = m.select_columns([0, 2, 7])
+    theta = np.array([0.842178566751775, -0.05466291047449, -0.03026279836545])
+    assert abs(K.loss(ctx, red, theta, lam=4.647556) - 0.813659729805629) < 1e-12
+
+
+def test_roundtrip_and_select_columns(ctx, synth_small):
+    x, labels = synth_small
+    m = upload(ctx, x, labels)
+    rp, col, val = m.to_csr()
+    np.testing.assert_array_equal(rp, x.rowptr)
+    np.testing.assert_array_equal(col, x.col)
+    np.testing.assert_array_equal(val, x.val)
+    rng = np.random.default_rng(3)
+    cols = np.concatenate([[0], 1 + np.sort(rng.choice(x.dim - 1, size=40, replace=False))])
+    scale = rng.uniform(0.5, 2.0, size=len(cols)); scale[0] = 1.0
+    off = rng.uniform(-0.3, 0.3, size=len(cols)); off[0] = 0.0
+    for sc, of in ((None, None), (scale, None), (scale, off), (None, off)):
+        red = m.select_columns(cols, scale=sc, offset=of)
+        ro = O.select_columns(x, cols, scale=sc, offset=of)
+        rp, col, val = red.to_csr()
+        np.testing.assert_array_equal(rp, ro.rowptr)       # bit-exact structure
+        np.testing.assert_array_equal(col, ro.col)
+        np.testing.assert_array_equal(val, ro.val)         # same single multiply -> bit-exact
+
+
+def test_select_columns_drops_explicit_zeros(ctx, scores):
+    x, labels, dense = scores
+    d2 = dense.copy(); d2[3, 1] = 0.0; d2[9, 6] = 0.0; d2[0, 0] = 0.0
+    xz = O.Csr.from_dense(d2)
+    m = upload(ctx, xz, labels)
+    red = m.select_columns([0, 1, 2, 7]); ro = O.select_columns(xz, [0, 1, 2, 7])
+    rp, col, val = red.to_csr()
+    np.testing.assert_array_equal(rp, ro.rowptr)
+    np.testing.assert_array_equal(col, ro.col)
+    np.testing.assert_array_equal(val, ro.val)
+
+
+@pytest.mark.parametrize("nnz_theta", [0, 5, 60, 1500])
+def test_gradient_and_loss_vs_oracle(ctx, synth_small, nnz_theta):
+    x, labels = synth_small
+    m = upload(ctx, x, labels)
+    cw = O.class_weights(labels)
+    np.testing.assert_array_equal(m.class_weights(), cw)
+    rng = np.random.default_rng(nnz_theta)
+    theta = np.zeros(x.dim)
+    theta[0] = 0.3
+    if nnz_theta:
+        idx = 1 + rng.choice(x.dim - 1, size=nnz_theta, replace=False)
+        theta[idx] = rng.normal(size=nnz_theta) * 0.05
+    g = K.gradient_dense(ctx, m, theta, cw=cw)
+    assert_g_close(g, O.gradient(x, labels, theta, cw=cw))
+    l = K.loss(ctx, m, theta, cw=cw, lam=0.01)
+    assert abs(l - O.loss(x, labels, theta, cw=cw, lam=0.01)) < LOSS_ATOL
+    lp = K.log_pdf(ctx, m, theta)
+    lpo = np.array([O.class_log_pdf(x, i, theta, 1) for i in range(0, x.n, 37)])
+    np.testing.assert_allclose(lp[::37], lpo, rtol=1e-13, atol=1e-15)
+
+
+def test_gradient_with_transforms(ctx, synth_small):
+    x, labels = synth_small
+    m = upload(ctx, x, labels)
+    rng = np.random.default_rng(5)
+    theta = np.zeros(x.dim); theta[0] = -0.2
+    idx = 1 + rng.choice(x.dim - 1, size=30, replace=False)
+    theta[idx] = rng.normal(size=30) * 0.1
+    scale = rng.uniform(0.5, 2.0, size=x.dim); scale[0] = 1.0
+    off = rng.uniform(-0.05, 0.05, size=x.dim); off[0] = 0.0
+    cw = (0.7, 1.9)
+    for sc, of in ((scale, None), (scale, off)):
+        g = K.gradient_dense(ctx, m, theta, cw=cw, scale=sc, offset=of)
+        assert_g_close(g, O.gradient(x, labels, theta, cw=cw, scale=sc, offset=of))
+
+
+def test_f64_values_path(ctx):
+    # scoresLr-style dense rows with values that are not f32-representable
+    rng = np.random.default_rng(11)
+    dense = rng.normal(size=(300, 24)) * 3.0 + 0.1
+    x = O.Csr.from_dense(dense)
+    labels = (rng.uniform(size=300) < 0.4).astype(np.uint8)
+    m = upload(ctx, x, labels)
+    cw = O.class_weights(labels)
+    theta = rng.normal(size=x.dim) * 0.1
+    assert_g_close(K.gradient_dense(ctx, m, theta, cw=cw), O.gradient(x, labels, theta, cw=cw))
+    assert abs(K.loss(ctx, m, theta, cw=cw) - O.loss(x, labels, theta, cw=cw)) < LOSS_ATOL
+
+
+@pytest.mark.parametrize("N", [1, 7, 64, 700, 3000])
+def test_select_bit_exact(ctx, N):
+    rng = np.random.default_rng(N)
+    m = 2500
+    g = rng.normal(size=m)
+    g[rng.choice(m, size=300, replace=False)] = 0.0          # zero gradients (pass 2 only)
+    g[100:140] = 0.5; g[900:910] = -0.5                      # exact ties, mixed sign
+    g[17] = np.nan
+    b = np.zeros(m + 1, dtype=np.uint8); b[0] = 1
+    pre = rng.choice(m, size=min(N // 2, 20), replace=False)
+    b[pre + 1] = 1
+    ok, lam, c, b2 = K.select(ctx, g, b, len(pre), N, lambda_prev=0.3, eps_lambda=0.0)
+    oko, lamo, co, bo = O.select(np.nan_to_num(g, nan=0.0), b, len(pre), N, lambda_prev=0.3, eps_lambda=0.0)
+    assert (ok, c) == (oko, co)
+    assert lam == lamo                                       # bit-exact
+    np.testing.assert_array_equal(b2, bo)
+
+
+def test_select_ties_across_threshold_and_all_zero(ctx):
+    # the 2N-th largest sits inside a block of ties: lowest column ids must be taken
+    g = np.zeros(1000); g[200:260] = 1.0; g[5] = 2.0
+    b = np.zeros(1001, dtype=np.uint8); b[0] = 1
+    for N in (3, 10, 31):
+        r = K.select(ctx, g, b, 0, N); ro = O.select(g, b, 0, N)
+        assert r[:3] == ro[:3]
+        np.testing.assert_array_equal(r[3], ro[3])
+    g0 = np.zeros(50)
+    r = K.select(ctx, g0, np.r_[1, np.zeros(50)].astype(np.uint8), 0, 4)
+    ro = O.select(g0, np.r_[1, np.zeros(50)].astype(np.uint8), 0, 4)
+    assert r[:3] == ro[:3]
+    np.testing.assert_array_equal(r[3], ro[3])
+
+
+def test_select_fixed(ctx, scores):
+    x, labels, _ = scores
+    g = O.gradient(x, labels, np.zeros(x.dim))
+    b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+    for lam, mf in ((1.0, 0), (1.0, 1), (0.05, 3)):
+        r = K.select_fixed(ctx, g, b, 0, lam, mf); ro = O.select_fixed(g, b, 0, lam, mf)
+        assert r[:2] == ro[:2]
+        np.testing.assert_array_equal(r[2], ro[2])
+
+
+def leapfrog_epoch_oracle(x, labels, cw, cols, theta_red, N, lam_prev):
+    theta = np.zeros(x.dim); theta[cols] = theta_red
+    g = O.gradient(x, labels, theta, cw=cw)
+    b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+    nzc = [c for c, t in zip(cols[1:], theta_red[1:]) if t != 0.0]
+    b[nzc] = 1
+    ok, lam, c, b2 = O.select(g[1:], b, len(nzc), N, lambda_prev=lam_prev)
+    return ok, lam, c, b2, O.loss(x, labels, theta, cw=cw), g
+
+
+def test_sweep_select_and_cd_solve_leapfrog(ctx, synth_small):
+    """Two leapfrog epochs end to end: identical selections, lambda to rounding, theta to 1e-6."""
+    x, labels = synth_small
+    m = upload(ctx, x, labels)
+    cw = O.class_weights(labels)
+    N = 12
+    # epoch 0: theta = 0
+    r = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, N, want_g=True)
+    ok, lam, c, b2, l0, g = leapfrog_epoch_oracle(x, labels, cw, np.array([0]), np.zeros(1), N, 0.0)
+    assert (r["ok"], r["c"]) == (ok, c)
+    np.testing.assert_array_equal(r["b"], b2)
+    assert abs(r["lam"] - lam) <= 1e-12 * lam
+    assert abs(r["loss"] - l0) < LOSS_ATOL
+    assert_g_close(r["g"], g)
+    cols = np.nonzero(b2)[0]
+    red = m.select_columns(cols); redo = O.select_columns(x, cols)
+    th_gpu, recs = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=r["lam"] * x.n, eps_loss=1e-8)
+    th_ora, reco = O.cd_solve(redo, labels, np.zeros(len(cols)), cw=cw, l1reg=lam * x.n, eps_loss=1e-8)
+    assert len(recs) == len(reco)
+    assert [a["iteration"] for a in recs] == [a["iteration"] for a in reco]
+    assert [a["nonzero"] for a in recs] == [a["nonzero"] for a in reco]
+    np.testing.assert_allclose([a["loss"] for a in recs], [a["loss"] for a in reco], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(th_gpu, th_ora, rtol=THETA_RTOL, atol=1e-12)
+    # epoch 1 from the solved theta
+    r1 = K.sweep_select(ctx, m, red, cols, th_gpu, cw, N, lambda_prev=r["lam"] * x.n, want_g=True)
+    ok1, lam1, c1, b1, l1, g1 = leapfrog_epoch_oracle(x, labels, cw, cols, th_ora, N, lam * x.n)
+    assert (r1["ok"], r1["c"]) == (ok1, c1)
+    np.testing.assert_array_equal(r1["b"], b1)
+    assert abs(r1["lam"] - lam1) <= 1e-6 * lam1
+    assert abs(r1["loss"] - l1) < 1e-9
+
+
+def test_cd_solve_tight_matches_oracle_and_kkt(ctx, scores):
+    x, labels, _ = scores
+    m = upload(ctx, x, labels)
+    red = m.select_columns([0, 2, 7]); redo = O.select_columns(x, [0, 2, 7])
+    lam = 2.496875
+    th, recs = K.cd_solve(ctx, red, np.zeros(3), l1reg=lam * 16, eps=1e-13, eps_loss=0.0, max_iter=100000)
+    np.testing.assert_allclose(th, [0.851127187641263, -0.05490113203904316, -0.03053978552591902], rtol=1e-8)
+    tho, _ = O.cd_solve(redo, labels, np.zeros(3), l1reg=lam * 16, eps=1e-13, eps_loss=0.0, max_iter=100000)
+    np.testing.assert_allclose(th, tho, rtol=1e-9)
+    # max_iter cap is honoured identically
+    th5, r5 = K.cd_solve(ctx, red, np.zeros(3), l1reg=lam * 16, eps_loss=1e-8, max_iter=5)
+    to5, o5 = O.cd_solve(redo, labels, np.zeros(3), l1reg=lam * 16, eps_loss=1e-8, max_iter=5)
+    assert len(r5) == len(o5)
+    np.testing.assert_allclose(th5, to5, rtol=1e-9)
+
+
+def test_edge_cases(ctx):
+    # a matrix whose rows hold only the bias; a single row; ragged rows
+    rowptr = np.array([0, 1, 2, 3], dtype=np.int64); col = np.zeros(3, dtype=np.int64); val = np.ones(3)
+    x = O.Csr(3, 5, rowptr, col, val); labels = np.array([1, 0, 1], dtype=np.uint8)
+    m = upload(ctx, x, labels)
+    theta = np.array([0.4, 0, 0, 0, 0.0])
+    assert_g_close(K.gradient_dense(ctx, m, theta), O.gradient(x, labels, theta))
+    assert abs(K.loss(ctx, m, theta) - O.loss(x, labels, theta)) < LOSS_ATOL
+    rowptr = np.array([0, 1, 6, 8], dtype=np.int64)
+    col = np.array([0, 0, 1, 2, 3, 4, 0, 4], dtype=np.int64); val = np.array([1, 1, 2, 3, 4, 5, 1, 7.0])
+    x = O.Csr(3, 5, rowptr, col, val)
+    m = upload(ctx, x, labels)
+    theta = np.array([0.1, -0.2, 0.3, 0.0, 0.05])
+    assert_g_close(K.gradient_dense(ctx, m, theta), O.gradient(x, labels, theta))
+    red = m.select_columns([0, 3, 4]); ro = O.select_columns(x, [0, 3, 4])
+    rp, c, v = red.to_csr()
+    np.testing.assert_array_equal(rp, ro.rowptr); np.testing.assert_array_equal(c, ro.col)
+    # invalid input is refused like the reference's panic("internal error")
+    with pytest.raises(K.KlrError):
+        K.Matrix.from_csr(ctx, 1, 3, np.array([0, 1]), np.array([1]), np.array([1.0]), np.array([1], dtype=np.uint8))
+    with pytest.raises(K.KlrError):
+        m.select_columns([1, 2])
+
+
+def test_sharded_partials_sum_to_whole(ctx, synth_small):
+    """Row shards with n_total: partial gradients / losses add up to the unsharded result."""
+    x, labels = synth_small
+    cw = O.class_weights(labels)
+    theta = np.zeros(x.dim); theta[0] = 0.1; theta[[5, 77, 900]] = [0.2, -0.1, 0.05]
+    g_ref = O.gradient(x, labels, theta, cw=cw)
+    g_sum = np.zeros(x.dim); l_sum = 0.0
+    for (r0, r1) in ((0, 250), (250, 600)):
+        rp = x.rowptr[r0:r1 + 1] - x.rowptr[r0]
+        sl = slice(x.rowptr[r0], x.rowptr[r1])
+        xs = O.Csr(r1 - r0, x.dim, rp, x.col[sl], x.val[sl])
+        ms = upload(ctx, xs, labels[r0:r1], n_total=x.n)
+        g_sum += K.gradient_dense(ctx, ms, theta, cw=cw)
+        l_sum += K.loss(ctx, ms, theta, cw=cw)      # each shard already divides by n_total
+    assert_g_close(g_sum, g_ref)
+    assert abs(l_sum - O.loss(x, labels, theta, cw=cw)) < LOSS_ATOL
