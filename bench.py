@@ -128,15 +128,22 @@ def main():
     value = float(n_total) * float(m) / (dt / args.steps)          # samples x features / s, whole job
 
     # ---- roofline of the dominant kernel (column sweep k_xt_s), per launch ----------------------------
-    # single pass over the CSC: 4 B row id + 4 B f32 value per stored nonzero (padded), chunk table,
-    # s gathered once per row (8 B), g written once per column (8 B)
-    alg_bytes = 8.0 * nnz + 12.0 * (m + 1) + 8.0 * n_local + 8.0 * (m + 1)
+    lay = full.layout()
+    if lay["tiled"]:
+        # single pass over the row-tiled packed CSC: 4 B per stored nonzero ((count<<16)|row-in-tile),
+        # 4 B segment offset + 8 B partial sum per (tile, column) segment, s read once (8 B per row)
+        alg_bytes = 4.0 * nnz + 12.0 * lay["nseg"] + 8.0 * n_local
+        kname = "k_sweep_tiled<%d>" % lay["lanes_per_segment"]
+    else:
+        # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column
+        alg_bytes = (4.0 + lay["value_bytes"]) * nnz + 12.0 * lay["nseg"] + 8.0 * n_local + 8.0 * (m + 1)
+        kname = "k_xt_s<%d>" % lay["lanes_per_segment"]
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
     two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "k_xt_s<float,64>", "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
+                "kernel": kname, "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "survey_two_pass_bytes": two_pass_bytes,
                 "survey_two_pass_equiv_gbs": round(two_pass_bytes / (kern_avg_ms * 1e-3) / 1e9, 1) if kern_avg_ms > 0 else 0.0}

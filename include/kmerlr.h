@@ -70,6 +70,11 @@ int  klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int64_t* rowpt
                       int64_t n_total, klr_mat** out);
 void klr_mat_destroy(klr_mat* mat);
 int  klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total);
+/* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the row-tiled packed CSC
+ * (4 B per stored nonzero) is in use, with its tile height, number of (tile, column) segments,
+ * stored entries incl. padding and lanes per segment; tiled = 0: plain CSC (u32 row + f32|f64 value). */
+int  klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows, int64_t* nseg,
+                    int64_t* padded_entries, int* lanes_per_segment, int* value_bytes);
 /* copy a (reduced) matrix back in the reference layout; any output pointer may be NULL.
  * col/val need klr_mat_shape's nnz entries. */
 int  klr_mat_to_csr(klr_ctx* ctx, const klr_mat* mat, int64_t* rowptr, int64_t* col, double* val);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
     "klr_mat_destroy": (None, [_vp]),
     "klr_mat_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "klr_mat_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
+                              C.POINTER(_int), C.POINTER(_int)]),
     "klr_mat_to_csr": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "klr_class_weights": (_int, [_vp, _vp, _vp]),
     "klr_gradient": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -181,6 +183,14 @@ class Matrix:
             self.close()
         except Exception:
             pass
+
+    def layout(self):
+        t, g, vb = C.c_int(), C.c_int(), C.c_int()
+        r, ns, pe = C.c_int64(), C.c_int64(), C.c_int64()
+        self.ctx.check(lib().klr_mat_layout(self._h, C.byref(t), C.byref(r), C.byref(ns), C.byref(pe), C.byref(g),
+                                            C.byref(vb)))
+        return dict(tiled=bool(t.value), tile_rows=r.value, nseg=ns.value, padded_entries=pe.value,
+                    lanes_per_segment=g.value, value_bytes=vb.value)
 
     def to_csr(self):
         rowptr = np.zeros(self.n + 1, dtype=np.int64)

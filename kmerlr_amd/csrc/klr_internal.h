@@ -65,6 +65,7 @@ struct klr_ctx {
 
 struct klr_mat {
   klr_ctx* ctx = nullptr;
+  int  device = 0;
   i64  n = 0, dim = 0, nnz = 0, n_total = 0;
   bool val_f64 = false;          // value arrays are f64 (else f32)
   bool has_explicit_zero = false;
@@ -84,6 +85,16 @@ struct klr_mat {
   i64* colchunk = nullptr;       // dim+1: chunks of column j are [colchunk[j], colchunk[j+1])
   int  group = 64;               // lanes per chunk
   uint8_t* labels = nullptr;     // n
+  // ---- row-tiled packed CSC for the full-width sweep (klr_sweep.hip, DESIGN.md "data layout"):
+  //      tile t = rows [t*R, (t+1)*R); segment (t, j) = entries of column j inside tile t, padded to a
+  //      multiple of 4; entry = (count << 16) | row-in-tile  (u32, 4 B per stored nonzero)
+  bool tiled = false;
+  u32  R = 0, ntiles = 0, nwg = 0;
+  int  tgroup = 32;              // lanes per segment
+  i64  nseg = 0, total4 = 0;     // segments, entries/4
+  u32* t_ent = nullptr;          // total4*4 packed entries
+  u32* t_off4 = nullptr;         // nseg+1 prefix offsets in units of 4 entries
+  u32* t_wgseg = nullptr;        // nwg+1 equal-bytes partition of the segment list
   // ---- host metadata
   std::vector<i64> h_colptr;     // dim+1 padded offsets
   std::vector<u32> h_collen;     // dim   true lengths
@@ -162,3 +173,8 @@ int   build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, 
                     const double* offset, bool need_csc, klr_mat** out);
 
 static inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
+
+// row-tiled packed CSC (klr_mat.hip build_tiled, klr_sweep.hip k_sweep_tiled)
+static const u32 TILE_ROWS = 8192;        // s tile = 64 KiB of f64 in LDS
+static const u32 TILE_LONG4 = 512;        // segments longer than 2048 entries go to whole waves
+static const u32 TILE_LONGCAP = 2048;     // per-workgroup list of such segments

@@ -20,12 +20,11 @@ static const i64 CHUNK_MAX = 4096;   // entries per sweep chunk (multiple of 256
 
 void mat_free(klr_mat* m) {
   if (!m) return;
-  if (m->ctx) {
-    (void)hipSetDevice(m->ctx->device);
-    (void)hipStreamSynchronize(m->ctx->stream);
-  }
+  // the owning ctx may already be gone: use the recorded device, wait for everything on it
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
-                m->chunk_begin, m->chunk_len, m->colchunk, m->labels};
+                m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->t_ent, m->t_off4, m->t_wgseg};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete m;
 }
@@ -38,6 +37,18 @@ extern "C" int klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64
   if (dim) *dim = mat->dim;
   if (nnz) *nnz = mat->nnz;
   if (n_total) *n_total = mat->n_total;
+  return KLR_OK;
+}
+
+extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows, int64_t* nseg,
+                               int64_t* padded_entries, int* lanes_per_segment, int* value_bytes) {
+  if (!mat) return klr_fail(nullptr, KLR_EINVAL, "mat is NULL");
+  if (tiled) *tiled = mat->tiled ? 1 : 0;
+  if (tile_rows) *tile_rows = mat->tiled ? (int64_t)mat->R : mat->n;
+  if (nseg) *nseg = mat->tiled ? mat->nseg : mat->nchunks;
+  if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * 4 : mat->nnz_pad;
+  if (lanes_per_segment) *lanes_per_segment = mat->tiled ? mat->tgroup : mat->group;
+  if (value_bytes) *value_bytes = mat->tiled ? 2 : (mat->val_f64 ? 8 : 4);
   return KLR_OK;
 }
 
@@ -75,6 +86,92 @@ int mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat) {
     KLR_HIP(ctx, hipMemcpy(mat->chunk_len, cl.data(), (size_t)mat->nchunks * sizeof(u32), hipMemcpyHostToDevice));
   }
   KLR_HIP(ctx, hipMemcpy(mat->colchunk, cc.data(), (size_t)(dim + 1) * sizeof(i64), hipMemcpyHostToDevice));
+  return KLR_OK;
+}
+
+// =================================================================================================
+// row-tiled packed CSC for the full-width sweep.  Built when every value is an integer in
+// [0, 65535] (k-mer counts) and the matrix is large enough for the sweep to be bandwidth bound;
+// otherwise the plain CSC kernel is used.
+// =================================================================================================
+
+static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* col, const double* val) {
+  const i64 n = m->n, dim = m->dim;
+  if (n < (i64)TILE_ROWS / 2 || m->nnz < (1 << 20)) return KLR_OK;          // small: plain kernel
+  const u32 R = TILE_ROWS;
+  const i64 ntiles = ceil_div(n, (i64)R);
+  const i64 nseg = ntiles * dim;
+  if (nseg >= (i64)0xFFFFFFF0ll) return KLR_OK;
+  // packable?
+  int T = (int)std::min<i64>(std::max<unsigned>(1u, std::min(8u, std::thread::hardware_concurrency())), ntiles);
+  std::vector<int> bad(T, 0);
+  std::vector<u32> len((size_t)nseg, 0u);          // entries per segment
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
+      for (i64 tile = t; tile < ntiles; tile += T) {
+        u32* l = len.data() + (size_t)tile * dim;
+        const i64 r0 = tile * R, r1 = std::min<i64>(n, r0 + R);
+        for (i64 a = rowptr[r0]; a < rowptr[r1]; a++) {
+          const double v = val[a];
+          if (!(v >= 0.0 && v <= 65535.0 && v == (double)(u32)v)) { bad[t] = 1; return; }
+          l[col[a]]++;
+        }
+      }
+    });
+    for (auto& x : th) x.join();
+  }
+  for (int t = 0; t < T; t++) if (bad[t]) return KLR_OK;      // not count data: keep the plain path
+  std::vector<u32> off4((size_t)nseg + 1);
+  u64 run = 0;
+  for (i64 sg = 0; sg < nseg; sg++) { off4[(size_t)sg] = (u32)run; run += (len[(size_t)sg] + 3u) / 4u; if (run >= 0xFFFFFFF0ull) return KLR_OK; }
+  off4[(size_t)nseg] = (u32)run;
+  const i64 total4 = (i64)run;
+  if ((u64)total4 * 4ull >= 0xFFFFFFF0ull) return KLR_OK;
+  std::vector<u32> ent((size_t)std::max<i64>(total4, 1) * 4, 0u);
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
+      std::vector<u32> cur((size_t)dim);
+      for (i64 tile = t; tile < ntiles; tile += T) {
+        const u32* o = off4.data() + (size_t)tile * dim;
+        for (i64 j = 0; j < dim; j++) cur[(size_t)j] = o[j] * 4u;       // fits: total4*4 checked below
+        const i64 r0 = tile * R, r1 = std::min<i64>(n, r0 + R);
+        for (i64 i = r0; i < r1; i++)
+          for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++)
+            ent[cur[(size_t)col[a]]++] = ((u32)val[a] << 16) | (u32)(i - r0);
+      }
+    });
+    for (auto& x : th) x.join();
+  }
+  // equal-bytes partition of the segment list over 2 workgroups per CU
+  const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
+  std::vector<u32> wg((size_t)nwg + 1);
+  {
+    i64 sg = 0;
+    for (u32 w = 0; w < nwg; w++) {
+      const u64 target = (u64)total4 * w / nwg;
+      while (sg < nseg && off4[(size_t)sg] < target) sg++;
+      wg[w] = (u32)sg;
+    }
+    wg[0] = 0; wg[nwg] = (u32)nseg;
+    // the per-workgroup list of long segments must not overflow
+    for (u32 w = 0; w < nwg; w++) {
+      u32 nl = 0;
+      for (u32 q = wg[w]; q < wg[w + 1]; q++) if (off4[q + 1] - off4[q] > TILE_LONG4) nl++;
+      if (nl > TILE_LONGCAP) return KLR_OK;
+    }
+  }
+  double avg = nseg ? (double)m->nnz / (double)nseg : 0.0;
+  int g = 4;
+  while (g < 64 && 4.0 * g < avg * 1.2) g *= 2;
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)std::max<i64>(total4, 1) * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_off4, ((size_t)nseg + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgseg, ((size_t)nwg + 1) * 4));
+  KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * 16, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_off4, off4.data(), ((size_t)nseg + 1) * 4, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_wgseg, wg.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
+  m->tiled = true; m->R = R; m->ntiles = (u32)ntiles; m->nwg = nwg; m->tgroup = g; m->nseg = nseg; m->total4 = total4;
   return KLR_OK;
 }
 
@@ -129,7 +226,7 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
     if (bad[t] == 2) return klr_fail(ctx, KLR_EINVAL, "column ids must be strictly ascending within a row and < dim");
   }
   klr_mat* m = new klr_mat();
-  m->ctx = ctx; m->n = n; m->dim = dim; m->nnz = nnz; m->n_total = n_total;
+  m->ctx = ctx; m->device = ctx->device; m->n = n; m->dim = dim; m->nnz = nnz; m->n_total = n_total;
   m->val_f64 = false;
   for (int t = 0; t < T; t++) { if (notf32[t]) m->val_f64 = true; m->n1_local += n1[t]; }
   m->avg_row = n ? (double)nnz / (double)n : 0.0;
@@ -194,6 +291,7 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
     if (e == hipSuccess && n) e = hipMemcpy(m->labels, labels, (size_t)n, hipMemcpyHostToDevice);
     if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "matrix upload failed: %s", hipGetErrorString(e)); break; }
     rc = mat_build_chunks_and_upload(ctx, m);
+    if (rc == KLR_OK && !m->val_f64) rc = build_tiled(ctx, m, rowptr, col, val);
   } while (0);
   if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(m); ctx->err = keep; return rc; }
   *out = m;
@@ -463,7 +561,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
   KLR_HIP(ctx, hipSetDevice(ctx->device));
   const i64 n = full->n;
   klr_mat* r = new klr_mat();
-  r->ctx = ctx; r->n = n; r->dim = c1; r->n_total = full->n_total; r->val_f64 = true;
+  r->ctx = ctx; r->device = ctx->device; r->n = n; r->dim = c1; r->n_total = full->n_total; r->val_f64 = true;
   r->n1_local = full->n1_local;
   r->h_colptr.assign((size_t)c1 + 1, 0);
   r->h_collen.assign((size_t)c1, 0);

@@ -322,6 +322,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   double loss_sum = 0.0;
   KLR_HIP(ctx, hipMemcpyAsync(&loss_sum, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr));
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out / loss copies (select may not have synchronised)
   if (loss_out) *loss_out = full->n_total ? loss_sum / (double)full->n_total : 0.0;
   return KLR_OK;
 }

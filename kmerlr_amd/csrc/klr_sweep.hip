@@ -219,7 +219,148 @@ static void xt_s_group(int g, dim3 grid, hipStream_t st, const klr_mat* m, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// tiled column sweep (the roofline kernel for k-mer count data)
+//
+// Random 8-byte gathers of s from L2 move a whole cache line per stored nonzero and cap the plain
+// kernel at ~20 % of HBM peak (profiles/r01).  Here the rows are cut into tiles of TILE_ROWS and
+// each workgroup stages its tile of s (64 KiB) in LDS, so the only HBM stream is the packed entry
+// array: 4 bytes per stored nonzero, ((count << 16) | row-in-tile), read with 16-byte loads.
+//   - the segment list (tile-major, one segment per (tile, column)) is cut into equal-byte ranges,
+//     one per workgroup (2 per CU), so every workgroup streams the same number of bytes
+//   - G lanes per segment; D segments in flight per group to keep ~100 KiB of loads outstanding per CU
+//   - segments longer than 4*TILE_LONG4 entries (the bias column, dense data) are deferred to a
+//     second pass where a whole wave takes each
+//   - partial sums land in part[tile*dim + column]; k_finish_tiled adds the tiles in order
+// Results do not depend on scheduling: every partial is produced by one lane group with a fixed
+// reduction tree.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double consume4(const uint4 e, const double* __restrict__ sl, double acc) {
+  acc = fma(sl[e.x & 0xFFFFu], (double)(e.x >> 16), acc);
+  acc = fma(sl[e.y & 0xFFFFu], (double)(e.y >> 16), acc);
+  acc = fma(sl[e.z & 0xFFFFu], (double)(e.z >> 16), acc);
+  acc = fma(sl[e.w & 0xFFFFu], (double)(e.w >> 16), acc);
+  return acc;
+}
+
+#define TILED_THREADS 512
+
+template <int G, int D>
+__global__ __launch_bounds__(TILED_THREADS) void k_sweep_tiled(const uint4* __restrict__ ent4, const u32* __restrict__ off4,
+                                                               const u32* __restrict__ wgseg, u32 dim, u32 R, i64 n,
+                                                               const double* __restrict__ s, double* __restrict__ part) {
+  extern __shared__ double sl[];
+  __shared__ u32 long_list[TILE_LONGCAP];
+  __shared__ u32 long_cnt;
+  const int tid = threadIdx.x;
+  const int lane = tid % G, grp = tid / G;
+  constexpr int NG = TILED_THREADS / G;
+  const u32 sb = wgseg[blockIdx.x], se = wgseg[blockIdx.x + 1];
+  if (sb >= se) return;
+  const u32 t0 = sb / dim, t1 = (se - 1) / dim;
+  for (u32 t = t0; t <= t1; t++) {
+    const u32 a = max(sb, t * dim);
+    const u32 b = min(se, (t + 1) * dim);
+    __syncthreads();                                   // the previous tile is no longer read
+    const i64 r0 = (i64)t * R;
+    const i64 rn = min((i64)R, n - r0);
+    for (u32 i = tid; i < R; i += TILED_THREADS) sl[i] = (i64)i < rn ? s[r0 + i] : 0.0;
+    if (tid == 0) long_cnt = 0;
+    __syncthreads();
+    // ---- pass A: short segments, G lanes each, D segments in flight per group -----------------
+    for (u32 base = a + grp; base < b; base += NG * D) {
+      u32 o0[D], l4[D];
+      uint4 e[D];
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const u32 seg = base + d * NG;
+        if (seg < b) { o0[d] = off4[seg]; l4[d] = off4[seg + 1] - o0[d]; }
+        else         { o0[d] = 0; l4[d] = 0; }
+      }
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const bool act = (u32)lane < l4[d] && l4[d] <= TILE_LONG4;
+        e[d] = act ? ent4[o0[d] + lane] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const u32 seg = base + d * NG;
+        if (seg < b) {
+          if (l4[d] > TILE_LONG4) {
+            if (lane == 0) long_list[atomicAdd(&long_cnt, 1u)] = seg;   // host guarantees <= TILE_LONGCAP
+          } else {
+            double acc = consume4(e[d], sl, 0.0);
+            for (u32 q = G + lane; q < l4[d]; q += G) acc = consume4(ent4[o0[d] + q], sl, acc);
+            acc = group_sum<G>(acc);
+            if (lane == 0) part[seg] = acc;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- pass B: long segments, one wave each ---------------------------------------------------
+    const u32 nlong = long_cnt;
+    for (u32 li = tid >> 6; li < nlong; li += TILED_THREADS / 64) {
+      const u32 seg = long_list[li];
+      const u32 o = off4[seg], l = off4[seg + 1] - o;
+      double acc = 0.0;
+      for (u32 q = tid & 63; q < l; q += 64) acc = consume4(ent4[o + q], sl, acc);
+      acc = group_sum<64>(acc);
+      if ((tid & 63) == 0) part[seg] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_finish_tiled(const double* __restrict__ part, i64 dim, u32 ntiles,
+                                                      double* __restrict__ g) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= dim) return;
+  double v = 0.0;
+  for (u32 t = 0; t < ntiles; t++) v += part[(i64)t * dim + j];
+  g[j] = v;
+}
+
+template <int G>
+static void sweep_tiled_launch(hipStream_t st, const klr_mat* m, const double* s, double* part) {
+  const size_t lds = (size_t)m->R * sizeof(double);
+  constexpr int D = G >= 32 ? 4 : 8;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_sweep_tiled<G, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_sweep_tiled<G, D>), dim3(m->nwg), dim3(TILED_THREADS), lds, st, (const uint4*)m->t_ent, m->t_off4,
+                     m->t_wgseg, (u32)m->dim, m->R, m->n, s, part);
+}
+
+static int launch_xt_s_tiled(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev) {
+  double* part;
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)mat->nseg * sizeof(double), (void**)&part));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof_on) {
+    KLR_HIP(ctx, hipEventCreate(&e0));
+    KLR_HIP(ctx, hipEventCreate(&e1));
+    KLR_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  }
+  switch (mat->tgroup) {
+    case 4:  sweep_tiled_launch<4>(ctx->stream, mat, s_dev, part); break;
+    case 8:  sweep_tiled_launch<8>(ctx->stream, mat, s_dev, part); break;
+    case 16: sweep_tiled_launch<16>(ctx->stream, mat, s_dev, part); break;
+    case 32: sweep_tiled_launch<32>(ctx->stream, mat, s_dev, part); break;
+    default: sweep_tiled_launch<64>(ctx->stream, mat, s_dev, part); break;
+  }
+  if (ctx->prof_on) {
+    KLR_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->prof_ev.emplace_back(e0, e1);
+  }
+  hipLaunchKernelGGL(k_finish_tiled, dim3((unsigned)ceil_div(mat->dim, 256)), dim3(256), 0, ctx->stream, part, mat->dim,
+                     mat->ntiles, g_raw_dev);
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
 int launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev, bool square) {
+  if (mat->tiled && !square) return launch_xt_s_tiled(ctx, mat, s_dev, g_raw_dev);
   double* part;
   KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<i64>(mat->nchunks, 1) * sizeof(double), (void**)&part));
   if (mat->nchunks > 0) {

@@ -278,3 +278,94 @@ def test_sharded_partials_sum_to_whole(ctx, synth_small):
         l_sum += K.loss(ctx, ms, theta, cw=cw)      # each shard already divides by n_total
     assert_g_close(g_sum, g_ref)
     assert abs(l_sum - O.loss(x, labels, theta, cw=cw)) < LOSS_ATOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# the row-tiled packed layout (large count matrices) -- the roofline kernel's own parity cases
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def synth_tiled():
+    # 3 row tiles (8192 rows each, last one ragged), long bias segments, ~1.6e6 nonzeros
+    x, labels = O.synth_csr(20261004, 0, 20000, 20000, 3000, 80, 24)
+    return x, labels
+
+
+def test_tiled_sweep_matches_oracle(ctx, synth_tiled):
+    x, labels = synth_tiled
+    m = upload(ctx, x, labels)
+    lay = m.layout()
+    assert lay["tiled"] and lay["tile_rows"] == 8192 and lay["nseg"] == 3 * x.dim and lay["value_bytes"] == 2
+    cw = O.class_weights(labels)
+    rng = np.random.default_rng(1)
+    for k in (0, 40):
+        theta = np.zeros(x.dim); theta[0] = -0.1
+        if k:
+            idx = 1 + rng.choice(x.dim - 1, size=k, replace=False)
+            theta[idx] = rng.normal(size=k) * 0.1
+        g = K.gradient_dense(ctx, m, theta, cw=cw)
+        assert_g_close(g, O.gradient(x, labels, theta, cw=cw))
+    # run-to-run bitwise reproducibility of the device path
+    g2 = K.gradient_dense(ctx, m, theta, cw=cw)
+    np.testing.assert_array_equal(g, g2)
+
+
+def test_tiled_dense_long_segments(ctx):
+    # every column is a long segment in every tile (dense count data): pass B only
+    rng = np.random.default_rng(2)
+    dense = rng.integers(0, 5, size=(9000, 130)).astype(np.float64)
+    x = O.Csr.from_dense(dense)
+    labels = (rng.uniform(size=9000) < 0.5).astype(np.uint8)
+    m = upload(ctx, x, labels)
+    assert m.layout()["tiled"]
+    theta = rng.normal(size=x.dim) * 0.01
+    assert_g_close(K.gradient_dense(ctx, m, theta), O.gradient(x, labels, theta))
+
+
+def test_tiled_large_counts_and_unpackable_values(ctx):
+    rng = np.random.default_rng(3)
+    x, labels = O.synth_csr(5, 0, 9000, 9000, 500, 150, 4)
+    v = x.val.copy()
+    v[1::7] = 65535.0                       # largest packable count
+    v[x.rowptr[:-1]] = 1.0                  # keep the bias entries
+    x1 = O.Csr(x.n, x.dim, x.rowptr, x.col, v)
+    m1 = upload(ctx, x1, labels)
+    assert m1.layout()["tiled"]
+    theta = np.zeros(x.dim); theta[0] = 0.2
+    assert_g_close(K.gradient_dense(ctx, m1, theta), O.gradient(x1, labels, theta))
+    v[3::11] = 65536.0                      # one past: the plain CSC path must take over
+    v[x.rowptr[:-1]] = 1.0
+    x2 = O.Csr(x.n, x.dim, x.rowptr, x.col, v)
+    m2 = upload(ctx, x2, labels)
+    assert not m2.layout()["tiled"]
+    assert_g_close(K.gradient_dense(ctx, m2, theta), O.gradient(x2, labels, theta))
+
+
+def test_full_size_properties(ctx):
+    """BASELINE configs[2] size (100k x 65,536, ~1e8 nonzeros): size-independent properties.
+    At theta = 0, cw = [1,1]:  g_j = (bg column sum - fg column sum) / (2n), exactly computable
+    from integer column sums; plus selection sortedness and sweep idempotence."""
+    n, m, draws, N = 100000, 65536, 993, 100
+    rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
+    mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
+    assert mat.layout()["tiled"]
+    rows_fg = int(rowptr[n // 2])
+    fg = np.bincount(col[:rows_fg], weights=val[:rows_fg], minlength=m + 1)
+    bg = np.bincount(col[rows_fg:], weights=val[rows_fg:], minlength=m + 1)
+    g_exact = (bg - fg) / (2.0 * n)
+    r = K.sweep_select(ctx, mat, None, None, np.zeros(1), (1.0, 1.0), N, want_g=True)
+    assert np.max(np.abs(r["g"] - g_exact)) <= 1e-12 * np.max(np.abs(g_exact))
+    assert abs(r["loss"] - np.log(2.0)) < 1e-12
+    # the selected set is exactly the N largest |g| (ties impossible to straddle: checked)
+    order = np.lexsort((np.arange(m), -np.abs(g_exact[1:])))
+    assert abs(g_exact[1:][order[N - 1]]) > abs(g_exact[1:][order[N]])
+    assert sorted(np.nonzero(r["b"])[0][1:] - 1) == sorted(order[:N])
+    v, w = abs(g_exact[1:][order[N - 1]]), np.max(np.abs(g_exact[1:])[np.abs(g_exact[1:]) < abs(g_exact[1:][order[N - 1]])])
+    assert abs(r["lam"] - (v + w) / 2) <= 1e-12 * r["lam"]
+    # idempotence / reproducibility: the same sweep twice gives bit-identical output
+    r2 = K.sweep_select(ctx, mat, None, None, np.zeros(1), (1.0, 1.0), N, want_g=True)
+    np.testing.assert_array_equal(r["g"], r2["g"])
+    assert r["lam"] == r2["lam"]
+    # linearity in the class weights: g(cw=[a,b]) = a*g_bg_part + b*g_fg_part
+    ra = K.sweep_select(ctx, mat, None, None, np.zeros(1), (2.0, 0.5), N, want_g=True)
+    g_lin = (2.0 * bg - 0.5 * fg) / (2.0 * n)
+    assert np.max(np.abs(ra["g"] - g_lin)) <= 1e-12 * np.max(np.abs(g_lin))
