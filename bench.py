@@ -130,10 +130,11 @@ def main():
     # ---- roofline of the dominant kernel (column sweep k_xt_s), per launch ----------------------------
     lay = full.layout()
     if lay["tiled"]:
-        # single pass over the row-tiled packed CSC: 4 B per stored nonzero ((count<<16)|row-in-tile),
-        # 4 B segment offset + 8 B partial sum per (tile, column) segment, s read once (8 B per row)
-        alg_bytes = 4.0 * nnz + 12.0 * lay["nseg"] + 8.0 * n_local
-        kname = "k_sweep_tiled<%d>" % lay["lanes_per_segment"]
+        # single pass over the 2-D tiled packed COO stream: 4 B per stored entry ((count:8|col:12|row:12),
+        # padding included); per (tile, workgroup) piece one 32 KiB tile of int64 s read and one 32 KiB
+        # vector of int64 column sums written
+        alg_bytes = 4.0 * lay["padded_entries"] + lay["nseg"] * 2.0 * 4096 * 8
+        kname = "k_sweep_coo"
     else:
         # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column
         alg_bytes = (4.0 + lay["value_bytes"]) * nnz + 12.0 * lay["nseg"] + 8.0 * n_local + 8.0 * (m + 1)

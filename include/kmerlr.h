@@ -51,10 +51,14 @@ const char* klr_last_error(const klr_ctx* ctx);
 int         klr_ctx_set_stream(klr_ctx* ctx, void* hip_stream);
 int         klr_ctx_synchronize(klr_ctx* ctx);
 
-/* all-reduce hook: sums `count` doubles in place across ranks.  `buf` is a DEVICE pointer; the
- * call is made after the producing kernels were enqueued on the ctx stream (also passed, as
- * void*), and the hook must leave the result visible to later work on that stream. */
-typedef int (*klr_allreduce_fn)(void* user, void* dev_buf, int64_t count, void* hip_stream);
+/* all-reduce hook: sums `count` elements of type dtype (KLR_F64 doubles or KLR_I64 int64) in place
+ * across ranks.  `buf` is a DEVICE pointer; the call is made after the producing kernels were
+ * enqueued on the ctx stream (also passed, as void*), and the hook must leave the result visible to
+ * later work on that stream.  Count data is reduced as int64 fixed point, so that sum is exact and
+ * independent of the number of ranks. */
+#define KLR_F64 0
+#define KLR_I64 1
+typedef int (*klr_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);
 int         klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* user, int rank, int nranks);
 /* built-in hook: RCCL over xGMI.  id = 128-byte ncclUniqueId obtained on rank 0 with
  * klr_rccl_unique_id and distributed by the launcher. */
@@ -70,9 +74,10 @@ int  klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int64_t* rowpt
                       int64_t n_total, klr_mat** out);
 void klr_mat_destroy(klr_mat* mat);
 int  klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total);
-/* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the row-tiled packed CSC
- * (4 B per stored nonzero) is in use, with its tile height, number of (tile, column) segments,
- * stored entries incl. padding and lanes per segment; tiled = 0: plain CSC (u32 row + f32|f64 value). */
+/* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the 2-D tiled packed COO stream
+ * (4 B per stored nonzero, count data) is in use, with its tile edge, number of (tile, workgroup)
+ * pieces, stored entries incl. padding; tiled = 0: plain CSC (u32 row + f32|f64 value) with its chunk
+ * count and lanes per chunk. */
 int  klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows, int64_t* nseg,
                     int64_t* padded_entries, int* lanes_per_segment, int* value_bytes);
 /* copy a (reduced) matrix back in the reference layout; any output pointer may be NULL.

@@ -19,7 +19,7 @@ class IterRec(C.Structure):
                 ("lambda_", C.c_double), ("loss", C.c_double), ("seconds", C.c_double)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); also the export list checked by tests/test_abi.py
 _vp, _i64, _dbl, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
@@ -122,10 +122,10 @@ class Context:
         self.check(lib().klr_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def set_allreduce(self, fn, rank, nranks):
-        """fn(dev_ptr:int, count:int, stream:int) -> None, sums `count` doubles in place."""
-        def tramp(user, buf, count, stream):
+        """fn(dev_ptr:int, count:int, dtype:int (0 f64, 1 int64), stream:int) -> None, sums in place."""
+        def tramp(user, buf, count, dtype, stream):
             try:
-                fn(buf, count, stream)
+                fn(buf, count, dtype, stream)
                 return 0
             except Exception as e:  # pragma: no cover
                 print("allreduce hook failed:", e)

@@ -93,10 +93,11 @@ extern "C" int klr_rccl_unique_id(void* id128) {
   return KLR_OK;
 }
 
-static int rccl_allreduce_hook(void* user, void* dev_buf, int64_t count, void* stream) {
+static int rccl_allreduce_hook(void* user, void* dev_buf, int64_t count, int dtype, void* stream) {
   RcclState* st = (RcclState*)user;
-  const int ncclFloat64 = 8, ncclSum = 0;
-  int rc = st->AllReduce(dev_buf, dev_buf, (size_t)count, ncclFloat64, ncclSum, st->comm, (hipStream_t)stream);
+  const int ncclInt64 = 4, ncclFloat64 = 8, ncclSum = 0;
+  int rc = st->AllReduce(dev_buf, dev_buf, (size_t)count, dtype == KLR_I64 ? ncclInt64 : ncclFloat64, ncclSum, st->comm,
+                         (hipStream_t)stream);
   return rc == 0 ? 0 : 1;
 }
 
@@ -133,10 +134,10 @@ extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* us
   return KLR_OK;
 }
 
-int klr_allreduce(klr_ctx* ctx, double* dev, i64 count) {
+int klr_allreduce(klr_ctx* ctx, void* dev, i64 count, int dtype) {
   if (!ctx->ar_fn || ctx->nranks <= 1) return KLR_OK;
-  int rc = ctx->ar_fn(ctx->ar_user, dev, count, (void*)ctx->stream);
-  if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "all-reduce hook failed (%d) on %lld doubles", rc, (long long)count);
+  int rc = ctx->ar_fn(ctx->ar_user, dev, count, dtype, (void*)ctx->stream);
+  if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "all-reduce hook failed (%d) on %lld elements", rc, (long long)count);
   return KLR_OK;
 }
 

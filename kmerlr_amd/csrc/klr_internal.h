@@ -85,16 +85,21 @@ struct klr_mat {
   i64* colchunk = nullptr;       // dim+1: chunks of column j are [colchunk[j], colchunk[j+1])
   int  group = 64;               // lanes per chunk
   uint8_t* labels = nullptr;     // n
-  // ---- row-tiled packed CSC for the full-width sweep (klr_sweep.hip, DESIGN.md "data layout"):
-  //      tile t = rows [t*R, (t+1)*R); segment (t, j) = entries of column j inside tile t, padded to a
-  //      multiple of 4; entry = (count << 16) | row-in-tile  (u32, 4 B per stored nonzero)
+  // ---- 2-D tiled packed COO stream for the full-width sweep (klr_sweep.hip, DESIGN.md "data layout"):
+  //      tile (rt, ct) = rows [rt*4096, +4096) x columns [ct*4096, +4096); entries row-major inside a
+  //      tile; entry = (count:8 << 24) | (col-in-tile:12 << 12) | row-in-tile:12   (4 B per stored nonzero;
+  //      counts > 255 are split, the bias column is not stored)
   bool tiled = false;
-  u32  R = 0, ntiles = 0, nwg = 0;
-  int  tgroup = 32;              // lanes per segment
-  i64  nseg = 0, total4 = 0;     // segments, entries/4
+  u32  nrt = 0, nct = 0, nwg = 0, npiece = 0;
+  i64  total4 = 0;               // quads (4 entries) incl. per-tile padding
+  i64  stored_entries = 0;       // entries before padding
+  double col_abs_max = 0.0;      // max over non-bias columns of sum_i |x_ij| (local rows)
+  double col_abs_max_global = -1.0;   // bound over all ranks (lazily all-reduced)
   u32* t_ent = nullptr;          // total4*4 packed entries
-  u32* t_off4 = nullptr;         // nseg+1 prefix offsets in units of 4 entries
-  u32* t_wgseg = nullptr;        // nwg+1 equal-bytes partition of the segment list
+  u32* t_piece = nullptr;        // npiece * 4: {tile id, quad begin, quad end, unused}
+  u32* t_wgpiece = nullptr;      // nwg+1: pieces of workgroup w
+  u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
+  u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile
   // ---- host metadata
   std::vector<i64> h_colptr;     // dim+1 padded offsets
   std::vector<u32> h_collen;     // dim   true lengths
@@ -135,7 +140,7 @@ int klr_fail(klr_ctx* ctx, int code, const char* fmt, ...);
 // ---------------------------------------------------------------------------------------
 int   ws_get(klr_ctx* ctx, int which, size_t bytes, void** out);
 int   pin_get(klr_ctx* ctx, size_t bytes, void** out);
-int   klr_allreduce(klr_ctx* ctx, double* dev, i64 count);   // no-op without hook
+int   klr_allreduce(klr_ctx* ctx, void* dev, i64 count, int dtype);   // dtype KLR_F64|KLR_I64; no-op without hook
 int   dev_alloc(klr_ctx* ctx, void** p, size_t bytes);
 int   h2d(klr_ctx* ctx, void* dst, const void* src, size_t bytes);     // async on ctx stream
 int   d2h_sync(klr_ctx* ctx, void* dst, const void* src, size_t bytes); // copies and waits
@@ -143,7 +148,7 @@ int   d2h_sync(klr_ctx* ctx, void* dst, const void* src, size_t bytes); // copie
 // row pass modes
 enum { ROW_SWEEP = 0, ROW_LOSS = 1, ROW_IRLS = 2, ROW_LOGPDF = 3 };
 // Row pass over mat's CSR with dense device theta (length mat->dim).
-//  ROW_SWEEP : out0[i] = s_i = cw[y]/n_total * (sigma - y); *loss_acc_dev += sum of loss terms
+//  ROW_SWEEP : out0[i] = s_i = cw[y]/n_total * (sigma - y); out1[i] (nullable) = loss term of row i
 //  ROW_LOSS  : *loss_acc_dev += sum_i cw[y] * (-log sigma(+-r))
 //  ROW_IRLS  : out0[i] = w_i*cw, out1[i] = z_i; loss as ROW_LOSS
 //  ROW_LOGPDF: out0[i] = log sigma(r_i)
@@ -156,6 +161,12 @@ int   launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode
 
 // column sweep: g_raw[j] = sum_i s[i] * x_ij (sq: x_ij^2) for every column of mat (length dim)
 int   launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev, bool square);
+
+// full-width sweep incl. the cross-rank reduction: gbuf[0..dim) = X's, gbuf[dim] = sum of loss terms.
+// Count data (mat->tiled): lterm_dev holds per-row loss terms; otherwise gbuf[dim] must already hold the
+// local loss partial (row pass loss_acc_dev).
+int   sweep_all(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev, const double* lterm_dev,
+                double* gbuf);
 
 // device exclusive scan of u32 counts into i64 offsets (out has n+1 entries)
 int   launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out);
@@ -174,7 +185,6 @@ int   build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, 
 
 static inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
 
-// row-tiled packed CSC (klr_mat.hip build_tiled, klr_sweep.hip k_sweep_tiled)
-static const u32 TILE_ROWS = 8192;        // s tile = 64 KiB of f64 in LDS
-static const u32 TILE_LONG4 = 512;        // segments longer than 2048 entries go to whole waves
-static const u32 TILE_LONGCAP = 2048;     // per-workgroup list of such segments
+// 2-D tiled packed COO (klr_mat.hip build_tiled, klr_sweep.hip k_sweep_coo)
+static const u32 TILE_BITS = 12;
+static const u32 TILE_DIM = 1u << TILE_BITS;   // 4096 rows x 4096 columns: 32 KiB of s + 32 KiB of g in LDS

@@ -24,7 +24,8 @@ void mat_free(klr_mat* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
-                m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->t_ent, m->t_off4, m->t_wgseg};
+                m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->t_ent, m->t_piece, m->t_wgpiece,
+                m->t_ctptr, m->t_ctlist};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete m;
 }
@@ -44,11 +45,11 @@ extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows
                                int64_t* padded_entries, int* lanes_per_segment, int* value_bytes) {
   if (!mat) return klr_fail(nullptr, KLR_EINVAL, "mat is NULL");
   if (tiled) *tiled = mat->tiled ? 1 : 0;
-  if (tile_rows) *tile_rows = mat->tiled ? (int64_t)mat->R : mat->n;
-  if (nseg) *nseg = mat->tiled ? mat->nseg : mat->nchunks;
+  if (tile_rows) *tile_rows = mat->tiled ? (int64_t)TILE_DIM : mat->n;
+  if (nseg) *nseg = mat->tiled ? (int64_t)mat->npiece : mat->nchunks;
   if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * 4 : mat->nnz_pad;
-  if (lanes_per_segment) *lanes_per_segment = mat->tiled ? mat->tgroup : mat->group;
-  if (value_bytes) *value_bytes = mat->tiled ? 2 : (mat->val_f64 ? 8 : 4);
+  if (lanes_per_segment) *lanes_per_segment = mat->tiled ? 0 : mat->group;
+  if (value_bytes) *value_bytes = mat->tiled ? 1 : (mat->val_f64 ? 8 : 4);
   return KLR_OK;
 }
 
@@ -90,88 +91,116 @@ int mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat) {
 }
 
 // =================================================================================================
-// row-tiled packed CSC for the full-width sweep.  Built when every value is an integer in
-// [0, 65535] (k-mer counts) and the matrix is large enough for the sweep to be bandwidth bound;
+// 2-D tiled packed COO stream for the full-width sweep.  Built when every value is a non-negative
+// integer (k-mer counts) and the matrix is large enough for the sweep to be bandwidth bound;
 // otherwise the plain CSC kernel is used.
+//   tile (rt, ct): rows [rt*4096, +4096) x columns [ct*4096, +4096), tile id = rt*nct + ct
+//   entry  = (count:8 << 24) | (col & 4095) << 12 | (row & 4095); counts > 255 are split into several
+//            entries (the sweep is additive); column 0 (bias, all ones) is not stored
+//   order  = row-major inside a tile (so consecutive entries share the row -> LDS broadcast reads of s
+//            and distinct columns -> few same-address LDS atomics); every tile padded to 4 entries
+//   pieces = the entry stream cut into nwg equal parts (one per workgroup), each part cut at tile
+//            boundaries; a piece produces one 4096-wide int64 partial column-sum vector
 // =================================================================================================
-
 static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* col, const double* val) {
   const i64 n = m->n, dim = m->dim;
-  if (n < (i64)TILE_ROWS / 2 || m->nnz < (1 << 20)) return KLR_OK;          // small: plain kernel
-  const u32 R = TILE_ROWS;
-  const i64 ntiles = ceil_div(n, (i64)R);
-  const i64 nseg = ntiles * dim;
-  if (nseg >= (i64)0xFFFFFFF0ll) return KLR_OK;
-  // packable?
-  int T = (int)std::min<i64>(std::max<unsigned>(1u, std::min(8u, std::thread::hardware_concurrency())), ntiles);
+  if (n < 2048 || m->nnz < (1 << 20)) return KLR_OK;          // small: plain kernel
+  const i64 nrt = ceil_div(n, (i64)TILE_DIM), nct = ceil_div(dim, (i64)TILE_DIM);
+  const i64 ntile = nrt * nct;
+  if (ntile >= (i64)1 << 31) return KLR_OK;
+  int T = (int)std::min<i64>(std::max<unsigned>(1u, std::min(8u, std::thread::hardware_concurrency())), nrt);
   std::vector<int> bad(T, 0);
-  std::vector<u32> len((size_t)nseg, 0u);          // entries per segment
+  std::vector<u64> tlen((size_t)ntile, 0);           // entries per tile (after splitting)
+  std::vector<std::vector<double>> colsum(T, std::vector<double>((size_t)dim, 0.0));
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
-      for (i64 tile = t; tile < ntiles; tile += T) {
-        u32* l = len.data() + (size_t)tile * dim;
-        const i64 r0 = tile * R, r1 = std::min<i64>(n, r0 + R);
+      for (i64 rt = t; rt < nrt; rt += T) {
+        u64* l = tlen.data() + (size_t)rt * nct;
+        const i64 r0 = rt * TILE_DIM, r1 = std::min<i64>(n, r0 + TILE_DIM);
         for (i64 a = rowptr[r0]; a < rowptr[r1]; a++) {
           const double v = val[a];
-          if (!(v >= 0.0 && v <= 65535.0 && v == (double)(u32)v)) { bad[t] = 1; return; }
-          l[col[a]]++;
+          if (!(v >= 0.0 && v <= 16777216.0 && v == (double)(u32)v)) { bad[t] = 1; return; }
+          const i64 c = col[a];
+          if (c == 0) continue;
+          const u32 iv = (u32)v;
+          l[c >> TILE_BITS] += (iv + 254u) / 255u;       // 0 -> no entry
+          colsum[t][(size_t)c] += v;
         }
       }
     });
     for (auto& x : th) x.join();
   }
   for (int t = 0; t < T; t++) if (bad[t]) return KLR_OK;      // not count data: keep the plain path
-  std::vector<u32> off4((size_t)nseg + 1);
-  u64 run = 0;
-  for (i64 sg = 0; sg < nseg; sg++) { off4[(size_t)sg] = (u32)run; run += (len[(size_t)sg] + 3u) / 4u; if (run >= 0xFFFFFFF0ull) return KLR_OK; }
-  off4[(size_t)nseg] = (u32)run;
+  double amax = 0.0;
+  for (i64 j = 1; j < dim; j++) { double sj = 0.0; for (int t = 0; t < T; t++) sj += colsum[t][(size_t)j]; amax = std::max(amax, sj); }
+  colsum.clear();
+  std::vector<u64> toff4((size_t)ntile + 1);
+  u64 run = 0, stored = 0;
+  for (i64 t = 0; t < ntile; t++) { toff4[(size_t)t] = run; run += (tlen[(size_t)t] + 3) / 4; stored += tlen[(size_t)t]; }
+  toff4[(size_t)ntile] = run;
+  if (run >= 0xFFFFFFF0ull || run == 0) return KLR_OK;
   const i64 total4 = (i64)run;
-  if ((u64)total4 * 4ull >= 0xFFFFFFF0ull) return KLR_OK;
-  std::vector<u32> ent((size_t)std::max<i64>(total4, 1) * 4, 0u);
+  std::vector<u32> ent((size_t)total4 * 4, 0u);
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
-      std::vector<u32> cur((size_t)dim);
-      for (i64 tile = t; tile < ntiles; tile += T) {
-        const u32* o = off4.data() + (size_t)tile * dim;
-        for (i64 j = 0; j < dim; j++) cur[(size_t)j] = o[j] * 4u;       // fits: total4*4 checked below
-        const i64 r0 = tile * R, r1 = std::min<i64>(n, r0 + R);
+      std::vector<u64> cur((size_t)nct);
+      for (i64 rt = t; rt < nrt; rt += T) {
+        for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)(rt * nct + ct)] * 4;
+        const i64 r0 = rt * TILE_DIM, r1 = std::min<i64>(n, r0 + TILE_DIM);
         for (i64 i = r0; i < r1; i++)
-          for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++)
-            ent[cur[(size_t)col[a]]++] = ((u32)val[a] << 16) | (u32)(i - r0);
+          for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
+            const i64 c = col[a];
+            if (c == 0) continue;
+            u32 iv = (u32)val[a];
+            const u32 base = (((u32)c & (TILE_DIM - 1)) << TILE_BITS) | (u32)(i - r0);
+            u64& cu = cur[(size_t)(c >> TILE_BITS)];
+            while (iv > 0) { const u32 q = std::min(iv, 255u); ent[cu++] = (q << 24) | base; iv -= q; }
+          }
       }
     });
     for (auto& x : th) x.join();
   }
-  // equal-bytes partition of the segment list over 2 workgroups per CU
+  // pieces: equal parts of the quad stream, cut at tile boundaries
   const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
-  std::vector<u32> wg((size_t)nwg + 1);
+  std::vector<u32> piece; piece.reserve((size_t)(nwg + ntile) * 4);
+  std::vector<u32> wgp((size_t)nwg + 1);
   {
-    i64 sg = 0;
+    i64 tile = 0;
     for (u32 w = 0; w < nwg; w++) {
-      const u64 target = (u64)total4 * w / nwg;
-      while (sg < nseg && off4[(size_t)sg] < target) sg++;
-      wg[w] = (u32)sg;
+      wgp[w] = (u32)(piece.size() / 4);
+      const u64 q0 = (u64)total4 * w / nwg, q1 = (u64)total4 * (w + 1) / nwg;
+      u64 q = q0;
+      while (q < q1) {
+        while (toff4[(size_t)tile + 1] <= q) tile++;
+        const u64 e = std::min<u64>(q1, toff4[(size_t)tile + 1]);
+        piece.push_back((u32)tile); piece.push_back((u32)q); piece.push_back((u32)e); piece.push_back(0u);
+        q = e;
+      }
     }
-    wg[0] = 0; wg[nwg] = (u32)nseg;
-    // the per-workgroup list of long segments must not overflow
-    for (u32 w = 0; w < nwg; w++) {
-      u32 nl = 0;
-      for (u32 q = wg[w]; q < wg[w + 1]; q++) if (off4[q + 1] - off4[q] > TILE_LONG4) nl++;
-      if (nl > TILE_LONGCAP) return KLR_OK;
-    }
+    wgp[nwg] = (u32)(piece.size() / 4);
   }
-  double avg = nseg ? (double)m->nnz / (double)nseg : 0.0;
-  int g = 4;
-  while (g < 64 && 4.0 * g < avg * 1.2) g *= 2;
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)std::max<i64>(total4, 1) * 16));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_off4, ((size_t)nseg + 1) * 4));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgseg, ((size_t)nwg + 1) * 4));
+  const u32 npiece = (u32)(piece.size() / 4);
+  std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(npiece);
+  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)(piece[(size_t)p * 4] % nct) + 1]++;
+  for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
+  {
+    std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
+    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)(piece[(size_t)p * 4] % nct)]++] = p;
+  }
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)total4 * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)npiece * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, ((size_t)nwg + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
   KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * 16, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_off4, off4.data(), ((size_t)nseg + 1) * 4, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_wgseg, wg.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
-  m->tiled = true; m->R = R; m->ntiles = (u32)ntiles; m->nwg = nwg; m->tgroup = g; m->nseg = nseg; m->total4 = total4;
+  KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, wgp.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
+  m->tiled = true; m->nrt = (u32)nrt; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
+  m->total4 = total4; m->stored_entries = (i64)stored; m->col_abs_max = amax;
   return KLR_OK;
 }
 
@@ -329,7 +358,7 @@ extern "C" int klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2])
     double* d;
     KLR_TRY(ws_get(ctx, WS_G, 2 * sizeof(double), (void**)&d));
     KLR_TRY(h2d(ctx, d, cnts, sizeof(cnts)));
-    KLR_TRY(klr_allreduce(ctx, d, 2));
+    KLR_TRY(klr_allreduce(ctx, d, 2, KLR_F64));
     KLR_TRY(d2h_sync(ctx, cnts, d, sizeof(cnts)));
   }
   const double n0 = cnts[0], n1 = cnts[1];

@@ -281,10 +281,6 @@ extern "C" int klr_select_fixed(klr_ctx* ctx, const double* g_full, int64_t m, u
 // fused leapfrog epoch step: kmerLr_estimator.go:235 (Select) with the gradient of
 // kmerLr_feature_selection.go:87 computed in a single pass over the full CSC.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_store_scalar(double* dst, const double* src) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src;
-}
-
 extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat* reduced,
                                 const int64_t* red_cols, const double* theta_red, int64_t c_plus_1,
                                 const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
@@ -296,13 +292,17 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   KLR_ARG(ctx, reduced == nullptr || (reduced->dim == c_plus_1 && reduced->n == full->n && red_cols != nullptr));
   KLR_HIP(ctx, hipSetDevice(ctx->device));
   const i64 n = full->n, dim = full->dim, m = dim - 1;
-  double *s, *gbuf, *thd;
+  double *s, *gbuf, *thd, *lt = nullptr;
   KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&s));
   KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&gbuf));
+  if (full->tiled) KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&lt));
   // restoreNonzero (:194-219): b[0] = 1 and b[j] = 1 where theta_j != 0; c = count
   i64 c_prev = 0;
   memset(b, 0, (size_t)dim);
   b[0] = 1;
+  // count data: per-row loss terms go to `lt` and are summed exactly by the integer sweep;
+  // otherwise the row pass leaves the local loss partial in gbuf[dim]
+  double* lacc = full->tiled ? nullptr : gbuf + dim;
   if (reduced) {
     for (i64 p = 1; p < c_plus_1; p++) {
       KLR_ARG(ctx, red_cols[p] > 0 && red_cols[p] < dim);
@@ -310,14 +310,12 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     }
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
     KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
-    KLR_TRY(launch_row_pass(ctx, reduced, thd, ROW_SWEEP, cw, s, nullptr, gbuf + dim + 1));
+    KLR_TRY(launch_row_pass(ctx, reduced, thd, ROW_SWEEP, cw, s, lt, lacc));
   } else {
-    KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, nullptr, gbuf + dim + 1));
+    KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, lt, lacc));
   }
-  KLR_TRY(launch_xt_s(ctx, full, s, gbuf, false));
-  // [g | loss] contiguous for ONE all-reduce per sweep
-  hipLaunchKernelGGL(k_store_scalar, dim3(1), dim3(64), 0, ctx->stream, gbuf + dim, gbuf + dim + 1);
-  KLR_TRY(klr_allreduce(ctx, gbuf, dim + 1));
+  // [g | loss] in ONE all-reduce per sweep
+  KLR_TRY(sweep_all(ctx, full, cw, s, lt, gbuf));
   if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   double loss_sum = 0.0;
   KLR_HIP(ctx, hipMemcpyAsync(&loss_sum, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -275,7 +275,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
                               (const double*)red->val, w, n, d, G);
     hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, a0, nm, d, G);
     KLR_HIP(ctx, hipGetLastError());
-    KLR_TRY(klr_allreduce(ctx, Gxy, (i64)d * d + d));
+    KLR_TRY(klr_allreduce(ctx, Gxy, (i64)d * d + d, KLR_F64));
     tp = th;
 
     // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
@@ -291,7 +291,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         hipLaunchKernelGGL(k_loss_multi, dim3((unsigned)nb), dim3(256), 0, st, red->rowptr, red->col, (const double*)red->val,
                            red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
         hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
-        KLR_TRY(klr_allreduce(ctx, losses, KSPEC));
+        KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
         KLR_HIP(ctx, hipMemcpyAsync(hloss.data(), losses, KSPEC * 8, hipMemcpyDeviceToHost, st));
       }
       KLR_HIP(ctx, hipGetLastError());
@@ -329,7 +329,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (!have_sum) {
         double* acc = lossb;
         KLR_TRY(launch_row_pass(ctx, red, thd, ROW_LOSS, cw, nullptr, nullptr, acc));
-        KLR_TRY(klr_allreduce(ctx, acc, 1));
+        KLR_TRY(klr_allreduce(ctx, acc, 1, KLR_F64));
         KLR_TRY(d2h_sync(ctx, &accepted_sum, acc, 8));
       }
       const double lc = full_loss(th.data(), accepted_sum);

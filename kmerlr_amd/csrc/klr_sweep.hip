@@ -49,6 +49,7 @@ __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i
     const double e = exp(lp);
     // Gradient weights (:174-178), same association as the reference: 1/n * cw * (...)
     a.out0[i] = y ? a.inv_n * a.cw1 * (e - 1.0) : a.inv_n * a.cw0 * e;
+    if (a.out1) a.out1[i] = loss_term;
   } else if (mode == ROW_IRLS) {
     // estimate_coordinate (:97-111) with the guarded weight of oracle KLO_IRLS_WMIN
     const double p = exp(lp);
@@ -220,147 +221,214 @@ static void xt_s_group(int g, dim3 grid, hipStream_t st, const klr_mat* m, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// tiled column sweep (the roofline kernel for k-mer count data)
+// tiled column sweep for k-mer count data (the roofline kernel)
 //
-// Random 8-byte gathers of s from L2 move a whole cache line per stored nonzero and cap the plain
-// kernel at ~20 % of HBM peak (profiles/r01).  Here the rows are cut into tiles of TILE_ROWS and
-// each workgroup stages its tile of s (64 KiB) in LDS, so the only HBM stream is the packed entry
-// array: 4 bytes per stored nonzero, ((count << 16) | row-in-tile), read with 16-byte loads.
-//   - the segment list (tile-major, one segment per (tile, column)) is cut into equal-byte ranges,
-//     one per workgroup (2 per CU), so every workgroup streams the same number of bytes
-//   - G lanes per segment; D segments in flight per group to keep ~100 KiB of loads outstanding per CU
-//   - segments longer than 4*TILE_LONG4 entries (the bias column, dense data) are deferred to a
-//     second pass where a whole wave takes each
-//   - partial sums land in part[tile*dim + column]; k_finish_tiled adds the tiles in order
-// Results do not depend on scheduling: every partial is produced by one lane group with a fixed
-// reduction tree.
+// Random 8-byte gathers of s from L2 move a whole cache line per stored nonzero and cap the plain CSC
+// kernel at ~20 % of HBM peak (profiles/r01_plain_csc.md).  Here both vectors the sweep touches at
+// random live in LDS: the matrix is cut into 4096 x 4096 tiles, a workgroup holds the tile's 4096
+// s values and 4096 column accumulators (32 KiB each), and the ONLY HBM stream is the packed entry
+// array, 4 bytes per stored nonzero, read with 16-byte loads, four per lane in flight.
+//
+// Accumulation is exact: s is converted to int64 fixed point (scale 2^E chosen from max|s| and the
+// largest column sum so that no column sum can overflow), products are integer, and the column
+// accumulators are LDS integer atomics.  Integer addition is associative, so the result does not
+// depend on lane scheduling, on how the stream is cut into pieces, or on the number of GPUs (the
+// cross-GPU all-reduce is int64 too): the gradient is bitwise reproducible and partition invariant.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double consume4(const uint4 e, const double* __restrict__ sl, double acc) {
-  acc = fma(sl[e.x & 0xFFFFu], (double)(e.x >> 16), acc);
-  acc = fma(sl[e.y & 0xFFFFu], (double)(e.y >> 16), acc);
-  acc = fma(sl[e.z & 0xFFFFu], (double)(e.z >> 16), acc);
-  acc = fma(sl[e.w & 0xFFFFu], (double)(e.w >> 16), acc);
-  return acc;
+#define COO_THREADS 512
+#define COO_UNROLL 4
+
+__device__ __forceinline__ void coo_consume(const u32 w, const i64* __restrict__ sS, unsigned long long* __restrict__ sG) {
+  const u32 row = w & (TILE_DIM - 1), col = (w >> TILE_BITS) & (TILE_DIM - 1), v = w >> 24;
+  const unsigned long long prod = (unsigned long long)sS[row] * (unsigned long long)v;   // mod 2^64 == two's complement
+  atomicAdd(&sG[col], prod);
 }
 
-#define TILED_THREADS 512
-
-template <int G, int D>
-__global__ __launch_bounds__(TILED_THREADS) void k_sweep_tiled(const uint4* __restrict__ ent4, const u32* __restrict__ off4,
-                                                               const u32* __restrict__ wgseg, u32 dim, u32 R, i64 n,
-                                                               const double* __restrict__ s, double* __restrict__ part) {
-  extern __shared__ double sl[];
-  __shared__ u32 long_list[TILE_LONGCAP];
-  __shared__ u32 long_cnt;
-  const int tid = threadIdx.x;
-  const int lane = tid % G, grp = tid / G;
-  constexpr int NG = TILED_THREADS / G;
-  const u32 sb = wgseg[blockIdx.x], se = wgseg[blockIdx.x + 1];
-  if (sb >= se) return;
-  const u32 t0 = sb / dim, t1 = (se - 1) / dim;
-  for (u32 t = t0; t <= t1; t++) {
-    const u32 a = max(sb, t * dim);
-    const u32 b = min(se, (t + 1) * dim);
-    __syncthreads();                                   // the previous tile is no longer read
-    const i64 r0 = (i64)t * R;
-    const i64 rn = min((i64)R, n - r0);
-    for (u32 i = tid; i < R; i += TILED_THREADS) sl[i] = (i64)i < rn ? s[r0 + i] : 0.0;
-    if (tid == 0) long_cnt = 0;
+__global__ __launch_bounds__(COO_THREADS) void k_sweep_coo(const uint4* __restrict__ ent4, const uint4* __restrict__ piece,
+                                                           const u32* __restrict__ wgpiece, u32 nct, i64 n,
+                                                           const i64* __restrict__ S, i64* __restrict__ part) {
+  extern __shared__ unsigned long long coo_lds[];
+  i64* sS = (i64*)coo_lds;
+  unsigned long long* sG = coo_lds + TILE_DIM;
+  const u32 tid = threadIdx.x;
+  const u32 p0 = wgpiece[blockIdx.x], p1 = wgpiece[blockIdx.x + 1];
+  u32 cur_rt = 0xFFFFFFFFu;
+  for (u32 p = p0; p < p1; p++) {
+    const uint4 d = piece[p];
+    const u32 rt = d.x / nct, q0 = d.y, q1 = d.z;
+    __syncthreads();                                   // previous piece written out
+    if (rt != cur_rt) {
+      const i64 r0 = (i64)rt * TILE_DIM;
+      for (u32 i = tid; i < TILE_DIM; i += COO_THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
+      cur_rt = rt;
+    }
+    for (u32 i = tid; i < TILE_DIM; i += COO_THREADS) sG[i] = 0ull;
     __syncthreads();
-    // ---- pass A: short segments, G lanes each, D segments in flight per group -----------------
-    for (u32 base = a + grp; base < b; base += NG * D) {
-      u32 o0[D], l4[D];
-      uint4 e[D];
+    for (u32 q = q0 + tid; q < q1; q += COO_THREADS * COO_UNROLL) {
+      uint4 e[COO_UNROLL];
 #pragma unroll
-      for (int d = 0; d < D; d++) {
-        const u32 seg = base + d * NG;
-        if (seg < b) { o0[d] = off4[seg]; l4[d] = off4[seg + 1] - o0[d]; }
-        else         { o0[d] = 0; l4[d] = 0; }
+      for (int u = 0; u < COO_UNROLL; u++) {
+        const u32 qq = q + u * COO_THREADS;
+        e[u] = qq < q1 ? ent4[qq] : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
-      for (int d = 0; d < D; d++) {
-        const bool act = (u32)lane < l4[d] && l4[d] <= TILE_LONG4;
-        e[d] = act ? ent4[o0[d] + lane] : make_uint4(0u, 0u, 0u, 0u);
-      }
-#pragma unroll
-      for (int d = 0; d < D; d++) {
-        const u32 seg = base + d * NG;
-        if (seg < b) {
-          if (l4[d] > TILE_LONG4) {
-            if (lane == 0) long_list[atomicAdd(&long_cnt, 1u)] = seg;   // host guarantees <= TILE_LONGCAP
-          } else {
-            double acc = consume4(e[d], sl, 0.0);
-            for (u32 q = G + lane; q < l4[d]; q += G) acc = consume4(ent4[o0[d] + q], sl, acc);
-            acc = group_sum<G>(acc);
-            if (lane == 0) part[seg] = acc;
-          }
-        }
+      for (int u = 0; u < COO_UNROLL; u++) {
+        coo_consume(e[u].x, sS, sG);
+        coo_consume(e[u].y, sS, sG);
+        coo_consume(e[u].z, sS, sG);
+        coo_consume(e[u].w, sS, sG);
       }
     }
     __syncthreads();
-    // ---- pass B: long segments, one wave each ---------------------------------------------------
-    const u32 nlong = long_cnt;
-    for (u32 li = tid >> 6; li < nlong; li += TILED_THREADS / 64) {
-      const u32 seg = long_list[li];
-      const u32 o = off4[seg], l = off4[seg + 1] - o;
-      double acc = 0.0;
-      for (u32 q = tid & 63; q < l; q += 64) acc = consume4(ent4[o + q], sl, acc);
-      acc = group_sum<64>(acc);
-      if ((tid & 63) == 0) part[seg] = acc;
-    }
+    i64* out = part + (i64)p * TILE_DIM;
+    for (u32 i = tid; i < TILE_DIM; i += COO_THREADS) out[i] = (i64)sG[i];
   }
 }
 
-__global__ __launch_bounds__(256) void k_finish_tiled(const double* __restrict__ part, i64 dim, u32 ntiles,
-                                                      double* __restrict__ g) {
+// ibuf layout (int64): [0, dim) column sums (slot 0 unused) | dim: bias hi | dim+1: bias lo |
+//                      dim+2: loss limb0 | dim+3: loss limb1 | dim+4: non-finite loss terms
+#define IB_EXTRA 5
+
+__global__ __launch_bounds__(256) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
+                                                    const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf) {
   const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (j >= dim) return;
-  double v = 0.0;
-  for (u32 t = 0; t < ntiles; t++) v += part[(i64)t * dim + j];
-  g[j] = v;
+  if (j >= dim || j == 0) return;
+  const u32 ct = (u32)(j >> TILE_BITS), c = (u32)(j & (TILE_DIM - 1));
+  i64 v = 0;
+  for (u32 k = ctptr[ct]; k < ctptr[ct + 1]; k++) v += part[(i64)ctlist[k] * TILE_DIM + c];
+  ibuf[j] = v;
 }
 
-template <int G>
-static void sweep_tiled_launch(hipStream_t st, const klr_mat* m, const double* s, double* part) {
-  const size_t lds = (size_t)m->R * sizeof(double);
-  constexpr int D = G >= 32 ? 4 : 8;
+// s -> int64 fixed point; bias sum and loss as exactly additive integer limbs
+__global__ __launch_bounds__(256) void k_fix_s(const double* __restrict__ s, const double* __restrict__ lterm, i64 n,
+                                               double scale, i64* __restrict__ S, unsigned long long* __restrict__ acc) {
+  __shared__ i64 sh[4][256 / 64 + 1];
+  __shared__ u32 shbad[256 / 64];
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 hi = 0, lo = 0, l0 = 0, l1 = 0; u32 bad = 0;
+  if (i < n) {
+    const i64 v = __double2ll_rn(s[i] * scale);
+    S[i] = v;
+    hi = v >> 32; lo = (i64)(v & 0xFFFFFFFFll);
+    if (lterm) {
+      const double t = lterm[i];
+      if (t >= 0.0 && t < 1099511627776.0) {            // finite and < 2^40
+        const double ts = t * 1048576.0;                  // * 2^20, exact
+        const double f = floor(ts);
+        l0 = (i64)f;
+        l1 = __double2ll_rn((ts - f) * 4398046511104.0);  // * 2^42
+      } else bad = 1;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64);
+    l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64);
+    bad += __shfl_xor(bad, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = hi; sh[1][w] = lo; sh[2][w] = l0; sh[3][w] = l1; shbad[w] = bad; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const i64 t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    if (t) atomicAdd(&acc[threadIdx.x], (unsigned long long)t);
+  }
+  if (threadIdx.x == 4) {
+    const u32 t = shbad[0] + shbad[1] + shbad[2] + shbad[3];
+    if (t) atomicAdd(&acc[4], (unsigned long long)t);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, i64 dim, double inv_scale,
+                                                  double* __restrict__ g) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j > dim) return;
+  if (j == 0) {
+    g[0] = ((double)ibuf[dim] * 4294967296.0 + (double)ibuf[dim + 1]) * inv_scale;
+  } else if (j < dim) {
+    g[j] = (double)ibuf[j] * inv_scale;                     // inv_scale is a power of two: exact
+  } else {
+    // loss sum = (limb0 + limb1 * 2^-42) * 2^-20; NaN if any term was not finite
+    const double l = ((double)ibuf[dim + 2] + (double)ibuf[dim + 3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
+    g[dim] = ibuf[dim + 4] ? nan("") : l;
+  }
+}
+
+// Fixed-point scale: 2^E with max|s| * A * 2^E < 2^62, A = bound on the largest non-bias column sum
+static double coo_scale(double smax, double amax) {
+  double b = smax * std::max(amax, 1.0);
+  if (!(b > 0.0) || !std::isfinite(b)) b = 1.0;
+  int e;
+  (void)std::frexp(b, &e);           // b < 2^e
+  int E = 62 - e;
+  if (E > 1000) E = 1000;
+  if (E < -1000) E = -1000;
+  return std::ldexp(1.0, E);
+}
+
+// s (f64, device) and optional per-row loss terms -> gbuf[0..dim) = X's, gbuf[dim] = sum of loss terms,
+// all-reduced across ranks as int64.  Exact and partition invariant.
+static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev,
+                     const double* lterm_dev, double* gbuf) {
+  const i64 n = mat->n, dim = mat->dim;
+  hipStream_t st = ctx->stream;
+  // global bound on the column sums: sum of the per-rank maxima (one collective per matrix)
+  klr_mat* mm = const_cast<klr_mat*>(mat);
+  if (mm->col_abs_max_global < 0.0) {
+    double a = mat->col_abs_max;
+    if (ctx->ar_fn && ctx->nranks > 1) {
+      KLR_TRY(h2d(ctx, gbuf, &a, sizeof(double)));
+      KLR_TRY(klr_allreduce(ctx, gbuf, 1, KLR_F64));
+      KLR_TRY(d2h_sync(ctx, &a, gbuf, sizeof(double)));
+    }
+    mm->col_abs_max_global = a;
+  }
+  const double smax = std::max(std::fabs(cw[0]), std::fabs(cw[1])) / (double)mat->n_total;
+  const double scale = coo_scale(smax, mat->col_abs_max_global);
+  i64 *S, *part, *ibuf;
+  KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * TILE_DIM * 8, (void**)&part));
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
+  KLR_HIP(ctx, hipMemsetAsync(ibuf + dim, 0, IB_EXTRA * 8, st));
+  if (n) hipLaunchKernelGGL(k_fix_s, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, s_dev, lterm_dev, n, scale, S,
+                            (unsigned long long*)(ibuf + dim));
+  const size_t lds = (size_t)TILE_DIM * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_sweep_tiled<G, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  hipLaunchKernelGGL((k_sweep_tiled<G, D>), dim3(m->nwg), dim3(TILED_THREADS), lds, st, (const uint4*)m->t_ent, m->t_off4,
-                     m->t_wgseg, (u32)m->dim, m->R, m->n, s, part);
-}
-
-static int launch_xt_s_tiled(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev) {
-  double* part;
-  KLR_TRY(ws_get(ctx, WS_PART, (size_t)mat->nseg * sizeof(double), (void**)&part));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof_on) {
     KLR_HIP(ctx, hipEventCreate(&e0));
     KLR_HIP(ctx, hipEventCreate(&e1));
-    KLR_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    KLR_HIP(ctx, hipEventRecord(e0, st));
   }
-  switch (mat->tgroup) {
-    case 4:  sweep_tiled_launch<4>(ctx->stream, mat, s_dev, part); break;
-    case 8:  sweep_tiled_launch<8>(ctx->stream, mat, s_dev, part); break;
-    case 16: sweep_tiled_launch<16>(ctx->stream, mat, s_dev, part); break;
-    case 32: sweep_tiled_launch<32>(ctx->stream, mat, s_dev, part); break;
-    default: sweep_tiled_launch<64>(ctx->stream, mat, s_dev, part); break;
-  }
+  hipLaunchKernelGGL(k_sweep_coo, dim3(mat->nwg), dim3(COO_THREADS), lds, st, (const uint4*)mat->t_ent,
+                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->nct, n, S, part);
   if (ctx->prof_on) {
-    KLR_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    KLR_HIP(ctx, hipEventRecord(e1, st));
     ctx->prof_ev.emplace_back(e0, e1);
   }
-  hipLaunchKernelGGL(k_finish_tiled, dim3((unsigned)ceil_div(mat->dim, 256)), dim3(256), 0, ctx->stream, part, mat->dim,
-                     mat->ntiles, g_raw_dev);
+  hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256)), dim3(256), 0, st, part, mat->t_ctptr, mat->t_ctlist,
+                     dim, ibuf);
+  KLR_HIP(ctx, hipGetLastError());
+  KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
+  hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)ceil_div(dim + 1, 256)), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }
 
+// Full-width sweep: gbuf[0..dim) = sum_i s_i x_ij over ALL ranks, gbuf[dim] = sum of the loss terms.
+// s_dev holds the per-row weights; lterm_dev (count data) or gbuf[dim] (otherwise) the loss partials.
+int sweep_all(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev, const double* lterm_dev,
+              double* gbuf) {
+  if (mat->tiled) return sweep_coo(ctx, mat, cw, s_dev, lterm_dev, gbuf);
+  KLR_TRY(launch_xt_s(ctx, mat, s_dev, gbuf, false));          // leaves gbuf[dim] (loss partial) untouched
+  KLR_TRY(klr_allreduce(ctx, gbuf, mat->dim + 1, KLR_F64));
+  return KLR_OK;
+}
+
 int launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev, bool square) {
-  if (mat->tiled && !square) return launch_xt_s_tiled(ctx, mat, s_dev, g_raw_dev);
   double* part;
   KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<i64>(mat->nchunks, 1) * sizeof(double), (void**)&part));
   if (mat->nchunks > 0) {
@@ -466,8 +534,9 @@ extern "C" int klr_gradient(klr_ctx* ctx, const klr_mat* mat, const int64_t* th_
     rc = upload_sparse_theta(ctx, dim, idx.data(), vv.data(), (i64)idx.size(), &thd);
     if (rc == KLR_OK) rc = launch_row_pass(ctx, mat, thd, ROW_SWEEP, cw, s, nullptr, nullptr);
   }
-  if (rc == KLR_OK) rc = launch_xt_s(ctx, mat, s, gbuf, false);
-  if (rc == KLR_OK) rc = klr_allreduce(ctx, gbuf, dim);
+  if (rc == KLR_OK && hipMemsetAsync(gbuf + dim, 0, sizeof(double), ctx->stream) != hipSuccess)
+    rc = klr_fail(ctx, KLR_EHIP, "memset failed");
+  if (rc == KLR_OK) rc = sweep_all(ctx, mat, cw, s, nullptr, gbuf);
   if (rc == KLR_OK && (scale || offset)) {
     double* tr;
     rc = ws_get(ctx, WS_TMP0, (size_t)dim * 2 * sizeof(double), (void**)&tr);
@@ -494,7 +563,7 @@ extern "C" int klr_loss(klr_ctx* ctx, const klr_mat* mat, const double* theta, c
   KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&acc));
   KLR_TRY(h2d(ctx, thd, theta, (size_t)dim * sizeof(double)));
   KLR_TRY(launch_row_pass(ctx, mat, thd, ROW_LOSS, cw, nullptr, nullptr, acc));
-  KLR_TRY(klr_allreduce(ctx, acc, 1));
+  KLR_TRY(klr_allreduce(ctx, acc, 1, KLR_F64));
   double sum = 0.0;
   KLR_TRY(d2h_sync(ctx, &sum, acc, sizeof(double)));
   if (mat->n_total == 0) { *loss_out = 0.0; return KLR_OK; }              // :251-253

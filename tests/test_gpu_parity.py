@@ -294,7 +294,7 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled):
     x, labels = synth_tiled
     m = upload(ctx, x, labels)
     lay = m.layout()
-    assert lay["tiled"] and lay["tile_rows"] == 8192 and lay["nseg"] == 3 * x.dim and lay["value_bytes"] == 2
+    assert lay["tiled"] and lay["tile_rows"] == 4096 and lay["value_bytes"] == 1
     cw = O.class_weights(labels)
     rng = np.random.default_rng(1)
     for k in (0, 40):
@@ -309,8 +309,8 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled):
     np.testing.assert_array_equal(g, g2)
 
 
-def test_tiled_dense_long_segments(ctx):
-    # every column is a long segment in every tile (dense count data): pass B only
+def test_tiled_dense_counts(ctx):
+    # dense count data: every (row, column) pair present, many same-column LDS atomics per wave
     rng = np.random.default_rng(2)
     dense = rng.integers(0, 5, size=(9000, 130)).astype(np.float64)
     x = O.Csr.from_dense(dense)
@@ -325,14 +325,15 @@ def test_tiled_large_counts_and_unpackable_values(ctx):
     rng = np.random.default_rng(3)
     x, labels = O.synth_csr(5, 0, 9000, 9000, 500, 150, 4)
     v = x.val.copy()
-    v[1::7] = 65535.0                       # largest packable count
+    v[1::7] = 70000.0                       # counts above 255 are split into several entries
+    v[2::13] = 255.0; v[5::17] = 256.0
     v[x.rowptr[:-1]] = 1.0                  # keep the bias entries
     x1 = O.Csr(x.n, x.dim, x.rowptr, x.col, v)
     m1 = upload(ctx, x1, labels)
     assert m1.layout()["tiled"]
     theta = np.zeros(x.dim); theta[0] = 0.2
     assert_g_close(K.gradient_dense(ctx, m1, theta), O.gradient(x1, labels, theta))
-    v[3::11] = 65536.0                      # one past: the plain CSC path must take over
+    v[3::11] = 2.5                          # not a count: the plain CSC path must take over
     v[x.rowptr[:-1]] = 1.0
     x2 = O.Csr(x.n, x.dim, x.rowptr, x.col, v)
     m2 = upload(ctx, x2, labels)
