@@ -61,6 +61,7 @@ struct klr_ctx {
   bool         prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   int          n_cu = 256;
+  void*        sel_hist_zeroed = nullptr;   // selection histogram known to be all zero
 };
 
 struct klr_mat {

@@ -185,44 +185,200 @@ __global__ __launch_bounds__(256) void k_sel_wmax(const u64* __restrict__ keys, 
 
 static inline double key_to_double(u64 k) { double d; memcpy(&d, &k, 8); return d; }
 
+// ---------------------------------------------------------------------------------------------------
+// fast path: ONE coarse histogram over the top 13 key bits (exponent + 2 mantissa bits) brackets the
+// K-th largest |g|; everything at or above the bracketing bin (usually K + a few hundred keys) is
+// compacted and sorted by one workgroup.  4 launches instead of 25.  Falls back to the exact 8-pass
+// radix select when the bracket holds more than FAST_CAP keys (e.g. K reaches into the zeros).
+// ---------------------------------------------------------------------------------------------------
+#define FAST_BINS 8192
+#define FAST_SHIFT 50
+#define FAST_CAP 8192
+
+struct FastState {
+  u64 lowkey;        // keys >= lowkey are candidates
+  u32 ncand;         // their number
+  u32 cursor;        // compaction cursor
+  u32 fallback;      // 1: too many candidates
+  u32 wfound;        // 1: wkey valid
+  u64 vkey, wkey;
+};
+
+__global__ __launch_bounds__(256) void k_fast_keys_hist(const double* __restrict__ g, i64 m, u64* __restrict__ keys,
+                                                        u32* __restrict__ hist) {
+  __shared__ u32 sh[FAST_BINS];
+  for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < m; j += (i64)gridDim.x * 256) {
+    const u64 k = abs_key(g[j + 1]);
+    keys[j] = k;
+    atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_fast_pickbin(u32* __restrict__ hist, u32 K, FastState* st) {
+  // suffix sums over 8192 bins: thread t owns bins [8t, 8t+8)
+  __shared__ u32 ssum[1024];
+  const int t = threadIdx.x;
+  u32 h[8], loc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; hist[t * 8 + i] = 0; }
+  ssum[t] = loc;
+  __syncthreads();
+  // inclusive suffix scan: ssum[t] = sum_{u >= t}
+  for (int o = 1; o < 1024; o <<= 1) {
+    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
+    __syncthreads();
+    ssum[t] += v;
+    __syncthreads();
+  }
+  const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;      // keys in bins of higher threads
+  if (above < K && ssum[t] >= K) {
+    // the K-th largest lies in one of this thread's 8 bins
+    u32 cum = above;
+    int b = 7;
+    for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
+    const u32 nc = cum + h[b];
+    st->lowkey = ((u64)(t * 8 + b)) << FAST_SHIFT;
+    st->ncand = nc;
+    st->cursor = 0;
+    st->fallback = nc > FAST_CAP ? 1u : 0u;
+    st->wfound = 0; st->vkey = 0; st->wkey = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fast_compact(const u64* __restrict__ keys, i64 m, FastState* st, Cand* __restrict__ cand) {
+  if (st->fallback) return;
+  const u64 low = st->lowkey;
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < m; j += (i64)gridDim.x * 256) {
+    const u64 k = keys[j];
+    if (k >= low) {
+      const u32 pos = atomicAdd(&st->cursor, 1u);
+      if (pos < FAST_CAP) { cand[pos].key = k; cand[pos].idx = (u32)j; cand[pos].pad = 0; }
+    }
+  }
+}
+
+// one workgroup: bitonic sort (LDS) of the <= FAST_CAP candidates by (|g| desc, column asc); v and w
+__global__ __launch_bounds__(1024) void k_fast_sort(Cand* __restrict__ c, u32 K, u32 Nth, FastState* st, Cand* __restrict__ out) {
+  extern __shared__ Cand sc[];
+  if (st->fallback) return;
+  const u32 n = st->ncand;
+  u32 P = 2; while (P < n) P <<= 1;
+  for (u32 i = threadIdx.x; i < P; i += 1024) {
+    if (i < n) sc[i] = c[i];
+    else { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
+  }
+  __syncthreads();
+  for (u32 size = 2; size <= P; size <<= 1) {
+    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+      for (u32 t = threadIdx.x; t < P / 2; t += 1024) {
+        const u32 lo = 2 * t - (t & (stride - 1));
+        const u32 hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        Cand a = sc[lo], b = sc[hi];
+        const bool swap = up ? cand_before(b, a) : cand_before(a, b);
+        if (swap) { sc[lo] = b; sc[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (u32 i = threadIdx.x; i < K && i < n; i += 1024) out[i] = sc[i];
+  __shared__ unsigned long long wbest;
+  if (threadIdx.x == 0) wbest = 0ull;
+  __syncthreads();
+  const u64 vkey = (Nth >= 1 && Nth <= n) ? sc[Nth - 1].key : 0ull;
+  // largest candidate key strictly below v (sorted: first position whose key < v)
+  for (u32 i = threadIdx.x; i < n; i += 1024)
+    if (sc[i].key < vkey && (i == 0 || sc[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sc[i].key | (1ull << 63));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->vkey = vkey;
+    st->wfound = (wbest >> 63) ? 1u : 0u;
+    st->wkey = wbest & ~(1ull << 63);
+  }
+}
+
+static int select_exact_device(klr_ctx* ctx, const double* g_dev, u64* keys, bool keys_ready, i64 m, i64 K, i64 N,
+                               std::vector<Cand>& hc, u64* vkey, u64* wkey) {
+  hipStream_t st = ctx->stream;
+  char* misc; Cand* cand;
+  const i64 nb = ceil_div(m, CMP_BLOCK);
+  u32 P = 1; while ((i64)P < K) P <<= 1; if (P < 2) P = 2;
+  const size_t misc_bytes = sizeof(SelState) + 256 * sizeof(u32) + (size_t)nb * 2 * sizeof(u32) + 64;
+  KLR_TRY(ws_get(ctx, WS_SEL_MISC, misc_bytes, (void**)&misc));
+  KLR_TRY(ws_get(ctx, WS_SEL_CAND, (size_t)P * sizeof(Cand), (void**)&cand));
+  SelState* dst = (SelState*)misc;
+  u32* hist = (u32*)(misc + sizeof(SelState));
+  u32* bgt = hist + 256;
+  u32* beq = bgt + nb;
+  SelState init; memset(&init, 0, sizeof(init));
+  init.kremain = (u32)K;
+  KLR_HIP(ctx, hipMemsetAsync(misc, 0, misc_bytes, st));
+  KLR_TRY(h2d(ctx, dst, &init, sizeof(init)));
+  if (!keys_ready) hipLaunchKernelGGL(k_sel_keys, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, g_dev, m, keys);
+  const unsigned hgrid = (unsigned)std::min<i64>(ceil_div(m, 256 * 8), 1024);
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(k_sel_hist, dim3(std::max(1u, hgrid)), dim3(256), 0, st, keys, m, dst, shift, hist);
+    hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, st, dst, shift, hist);
+  }
+  hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, keys, m, dst, bgt, beq);
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, bgt, beq, nb, dst);
+  hipLaunchKernelGGL(k_sel_compact, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, keys, m, dst, bgt, beq, cand);
+  hipLaunchKernelGGL(k_sel_sort, dim3(1), dim3(1024), 0, st, cand, (u32)K, P, (u32)N, dst);
+  hipLaunchKernelGGL(k_sel_wmax, dim3(std::max(1u, hgrid)), dim3(256), 0, st, keys, m, dst);
+  KLR_HIP(ctx, hipGetLastError());
+  SelState hs;
+  KLR_HIP(ctx, hipMemcpyAsync(hc.data(), cand, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
+  KLR_TRY(d2h_sync(ctx, &hs, dst, sizeof(hs)));
+  *vkey = hs.vkey; *wkey = hs.wkey;
+  return KLR_OK;
+}
+
 int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                        double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
                        int* ok_out, i64* picked_out) {
   KLR_ARG(ctx, m >= 0 && N >= 0 && b != nullptr);
   const i64 K = std::min<i64>(m, 2 * N);             // NLargestAbsFloat64(g_, 2N)
   std::vector<Cand> hc((size_t)std::max<i64>(K, 1));
-  SelState hs; memset(&hs, 0, sizeof(hs));
+  u64 vkey = 0, wkey = 0;
   if (K > 0) {
     hipStream_t st = ctx->stream;
-    u64* keys; char* misc; Cand* cand;
-    const i64 nb = ceil_div(m, CMP_BLOCK);
-    u32 P = 1; while ((i64)P < K) P <<= 1; if (P < 2) P = 2;
+    u64* keys; char* fm; Cand* cand;
     KLR_TRY(ws_get(ctx, WS_SEL_KEYS, (size_t)m * sizeof(u64), (void**)&keys));
-    const size_t misc_bytes = sizeof(SelState) + 256 * sizeof(u32) + (size_t)nb * 2 * sizeof(u32) + 64;
-    KLR_TRY(ws_get(ctx, WS_SEL_MISC, misc_bytes, (void**)&misc));
-    KLR_TRY(ws_get(ctx, WS_SEL_CAND, (size_t)P * sizeof(Cand), (void**)&cand));
-    SelState* dst = (SelState*)misc;
-    u32* hist = (u32*)(misc + sizeof(SelState));
-    u32* bgt = hist + 256;
-    u32* beq = bgt + nb;
-    SelState init; memset(&init, 0, sizeof(init));
-    init.kremain = (u32)K;
-    KLR_HIP(ctx, hipMemsetAsync(misc, 0, misc_bytes, st));
-    KLR_TRY(h2d(ctx, dst, &init, sizeof(init)));
-    hipLaunchKernelGGL(k_sel_keys, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, st, g_dev, m, keys);
-    const unsigned hgrid = (unsigned)std::min<i64>(ceil_div(m, 256 * 8), 1024);
-    for (int shift = 56; shift >= 0; shift -= 8) {
-      hipLaunchKernelGGL(k_sel_hist, dim3(std::max(1u, hgrid)), dim3(256), 0, st, keys, m, dst, shift, hist);
-      hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, st, dst, shift, hist);
+    const size_t fm_bytes = sizeof(FastState) + 64 + FAST_BINS * sizeof(u32);
+    KLR_TRY(ws_get(ctx, WS_MASK, fm_bytes, (void**)&fm));
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(FAST_CAP + K) * sizeof(Cand), (void**)&cand));
+    FastState* fs = (FastState*)fm;
+    u32* hist = (u32*)(fm + sizeof(FastState) + 64 - (sizeof(FastState) % 64));
+    if (ctx->sel_hist_zeroed != (void*)hist) {          // the pick kernel re-zeroes the bins after use
+      KLR_HIP(ctx, hipMemsetAsync(fm, 0, fm_bytes, st));
+      ctx->sel_hist_zeroed = (void*)hist;
     }
-    hipLaunchKernelGGL(k_sel_count, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, keys, m, dst, bgt, beq);
-    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, bgt, beq, nb, dst);
-    hipLaunchKernelGGL(k_sel_compact, dim3((unsigned)nb), dim3(CMP_BLOCK), 0, st, keys, m, dst, bgt, beq, cand);
-    hipLaunchKernelGGL(k_sel_sort, dim3(1), dim3(1024), 0, st, cand, (u32)K, P, (u32)N, dst);
-    hipLaunchKernelGGL(k_sel_wmax, dim3(std::max(1u, hgrid)), dim3(256), 0, st, keys, m, dst);
+    Cand* out = cand + FAST_CAP;
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
+    hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
+    hipLaunchKernelGGL(k_fast_pickbin, dim3(1), dim3(1024), 0, st, hist, (u32)K, fs);
+    hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(256), 0, st, keys, m, fs, cand);
+    static bool attr = false;
+    if (!attr) {
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(FAST_CAP * sizeof(Cand))));
+      attr = true;
+    }
+    hipLaunchKernelGGL(k_fast_sort, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, cand, (u32)K, (u32)N, fs, out);
     KLR_HIP(ctx, hipGetLastError());
-    KLR_HIP(ctx, hipMemcpyAsync(hc.data(), cand, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
-    KLR_TRY(d2h_sync(ctx, &hs, dst, sizeof(hs)));
+    FastState hs;
+    KLR_HIP(ctx, hipMemcpyAsync(hc.data(), out, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
+    KLR_TRY(d2h_sync(ctx, &hs, fs, sizeof(hs)));
+    vkey = hs.vkey; wkey = hs.wkey;
+    const bool need_w = !(N > K) && N >= 1;
+    if (hs.fallback || (need_w && !hs.wfound)) {
+      // exact 8-pass radix select (keys are already on the device)
+      KLR_TRY(select_exact_device(ctx, g_dev, keys, true, m, K, N, hc, &vkey, &wkey));
+    }
   }
   // ---- Select :95-119 on the sorted candidates ------------------------------------------------
   i64 c = c_prev;
@@ -241,7 +397,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
   // computeLambda :179-192
   double l = 0.0;
   if (!(N > K) && N >= 1) {
-    const double v = key_to_double(hs.vkey), w = key_to_double(hs.wkey);
+    const double v = key_to_double(vkey), w = key_to_double(wkey);
     l = (v + w) / 2.0;
   }
   if (picked_out) for (i64 k = 0; k < K; k++) picked_out[k] = (i64)hc[k].idx;

@@ -27,31 +27,59 @@ __global__ __launch_bounds__(256) void k_mul(const double* __restrict__ a, const
   if (i < n) o[i] = a[i] * b[i];
 }
 
-// off-diagonal, non-bias Gram cells from the short reduced rows:  G[ja][jb] += w_i v_a v_b
-__global__ __launch_bounds__(256) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
-                                                      const double* __restrict__ val, const double* __restrict__ w,
-                                                      i64 n, int d, double* __restrict__ G) {
-  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const i64 b = rowptr[i], e = rowptr[i + 1];
-  const double wi = w[i];
-  for (i64 a = b + 1; a < e; a++) {
-    const double wa = wi * val[a];
-    const i64 ja = col[a];
-    for (i64 c = b + 1; c < e; c++) {
-      if (c == a) continue;
-      unsafeAtomicAdd(&G[ja * d + col[c]], wa * val[c]);
-    }
+// Gram scale: 2^E with max_{j>=1} G_jj * 2^E < 2^61 (|G_jk| <= max diag by Cauchy-Schwarz).  Computed on
+// the device from the ALL-REDUCED diagonal, so every rank uses the same power of two.
+__global__ __launch_bounds__(256) void k_gram_scale(const double* __restrict__ nm, int d, double* __restrict__ sc) {
+  __shared__ double sh[256];
+  double v = 0.0;
+  for (int j = 1 + threadIdx.x; j < d; j += 256) v = fmax(v, fabs(nm[j]));
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double m = sh[0];
+    if (!(m > 0.0) || m != m || m > 1e300) m = 1.0;
+    int e;
+    (void)frexp(m, &e);                 // m < 2^e
+    sc[0] = ldexp(1.0, 61 - e);
+    sc[1] = ldexp(1.0, e - 61);
   }
 }
 
-// row 0 / column 0 / diagonal from the three column sweeps
-__global__ __launch_bounds__(256) void k_gram_assemble(const double* __restrict__ a0, const double* __restrict__ nm, int d,
+// off-diagonal, non-bias Gram cells from the short reduced rows, upper triangle only:
+//   Gi[min(ja,jb)][max(ja,jb)] += round(w_i v_a v_b 2^E)   (integer atomics: exact, order free)
+__global__ __launch_bounds__(256) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                      const double* __restrict__ val, const double* __restrict__ w,
+                                                      i64 n, int d, const double* __restrict__ sc,
+                                                      unsigned long long* __restrict__ Gi) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const i64 b = rowptr[i], e = rowptr[i + 1];
+  const double wi = w[i] * sc[0];
+  for (i64 a = b + 1; a < e; a++) {
+    const double wa = wi * val[a];
+    const i64 ja = col[a];                       // columns ascend inside a row: ja < col[c] for c > a
+    for (i64 c = a + 1; c < e; c++)
+      atomicAdd(&Gi[ja * d + col[c]], (unsigned long long)__double2ll_rn(wa * val[c]));
+  }
+}
+
+// G from its parts: row/column 0 and the diagonal from the column sweeps, the rest from the integers
+__global__ __launch_bounds__(256) void k_gram_assemble(const double* __restrict__ a0, const double* __restrict__ nm,
+                                                       const i64* __restrict__ Gi, const double* __restrict__ sc, int d,
                                                        double* __restrict__ G) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= d) return;
-  G[(i64)j * d + j] = nm[j];
-  if (j > 0) { G[j] = a0[j]; G[(i64)j * d] = a0[j]; }
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)d * d) return;
+  const int j = (int)(t / d), k = (int)(t % d);
+  double v;
+  if (j == k) v = nm[j];
+  else if (j == 0) v = a0[k];
+  else if (k == 0) v = a0[j];
+  else v = (double)(j < k ? Gi[(i64)j * d + k] : Gi[(i64)k * d + j]) * sc[1];
+  G[t] = v;
 }
 
 struct CdArgs {
@@ -144,13 +172,98 @@ __global__ __launch_bounds__(CD_THREADS) void k_cd_sweeps(CdArgs a) {
   if (tid == 0) *a.ndone = done;
 }
 
-// log-loss of up to KSPEC iterates in one pass over the reduced rows (thread per row)
+// Wave-synchronous variant for d <= 64*QPL: ONE wavefront, q = G theta held in registers (QPL values per
+// lane, coordinate i on lane i & 63, slot i >> 6), no barriers; the moving coordinate's q value reaches all
+// lanes through v_readlane.  Same arithmetic and order as k_cd_sweeps.
+template <int QPL>
+__global__ __launch_bounds__(64) void k_cd_wave(CdArgs a) {
+  extern __shared__ double lds[];
+  const int d = a.d, lane = threadIdx.x;
+  double* th = lds;
+  double* dg = th + d;
+  double* xyv = dg + d;
+  double* Gl = xyv + d;
+  const double* G = a.G;
+  if (a.g_in_lds) {
+    for (i64 i = lane; i < (i64)d * d; i += 64) Gl[i] = a.G[i];
+    G = Gl;
+  }
+  for (int i = lane; i < d; i += 64) { th[i] = a.theta[i]; xyv[i] = a.xy[i]; dg[i] = a.G[(i64)i * d + i]; }
+  __syncthreads();
+  double q[QPL];
+#pragma unroll
+  for (int s = 0; s < QPL; s++) {
+    const int i = s * 64 + lane;
+    double acc = 0.0;
+    if (i < d) for (int k = 0; k < d; k++) { const double t = th[k]; if (t != 0.0) acc += G[(i64)k * d + i] * t; }
+    q[s] = acc;
+  }
+  int done = 0;
+  for (int k = 0; k < a.K; k++) {
+    double max_x = 0.0, max_delta = 0.0;
+    int isnan_ = 0;
+    for (int j = 0; j < d; j++) {
+      // q_j from its owner lane (j uniform -> scalar lane index)
+      double qsel = q[0];
+#pragma unroll
+      for (int s = 1; s < QPL; s++) if ((j >> 6) == s) qsel = q[s];
+      const int lo = __builtin_amdgcn_readlane(__double2loint(qsel), j & 63);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(qsel), j & 63);
+      const double qj = __hiloint2double(hi, lo);
+      const double old = th[j];
+      double t = xyv[j] + dg[j] * old - qj;                       // coordinate.go:56-59
+      if (j > 0) {                                                // :60-67 soft threshold
+        const double m = fmax(fabs(t) - a.l1reg, 0.0);
+        t = (t >= 0.0) ? m : -m;
+      }
+      t /= (dg[j] + a.l2reg);                                     // :69
+      if (t != t) isnan_ = 1;
+      const double dl = t - old;
+      max_x = fmax(max_x, fabs(t));
+      max_delta = fmax(max_delta, fabs(dl));
+      if (dl != 0.0 || t != t) {                                  // uniform branch
+        if (lane == 0) th[j] = t;
+#pragma unroll
+        for (int s = 0; s < QPL; s++) {
+          const int i = s * 64 + lane;
+          if (i < d) q[s] += dl * G[(i64)j * d + i];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();            // single wave: orders the LDS writes of lane 0 before the reads below
+    for (int i = lane; i < d; i += 64) a.hist[(i64)k * d + i] = th[i];
+    double delta; int stop;
+    if (isnan_) { delta = nan(""); stop = 1; }
+    else {
+      delta = (max_x != 0.0) ? max_delta / max_x : max_delta;
+      stop = ((max_x != 0.0 && max_delta / max_x <= a.eps) || (max_x == 0.0 && max_delta == 0.0)) ? 1 : 0;
+    }
+    if (lane == 0) { a.delta[k] = delta; a.stopf[k] = stop; }
+    done = k + 1;
+    if (stop) break;
+  }
+  for (int i = lane; i < d; i += 64) a.theta[i] = th[i];
+  if (lane == 0) *a.ndone = done;
+}
+
+// log-loss of up to KSPEC iterates in one pass over the reduced rows (thread per row); the iterates
+// are staged in LDS, each stored entry is read once and applied to all of them
+template <bool LDS>
 __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                     const double* __restrict__ val, const uint8_t* __restrict__ labels,
                                                     i64 n, int d, const double* __restrict__ hist, const int* __restrict__ ndone,
                                                     double cw0, double cw1, double* __restrict__ blk) {
+  extern __shared__ double lm_lds[];            // KSPEC * d iterates, layout [column][k]
   __shared__ double sh[KSPEC][4];
   const int K = *ndone;
+  if (LDS) {
+    for (int t = threadIdx.x; t < KSPEC * d; t += 256) {
+      const int k = t / d, c = t % d;
+      lm_lds[c * KSPEC + k] = k < K ? hist[(i64)k * d + c] : 0.0;
+    }
+    __syncthreads();
+  }
   const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
   double term[KSPEC];
 #pragma unroll
@@ -158,17 +271,28 @@ __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowp
   if (i < n) {
     const i64 b = rowptr[i], e = rowptr[i + 1];
     const int y = labels[i] != 0;
+    double r[KSPEC];
+#pragma unroll
+    for (int k = 0; k < KSPEC; k++) r[k] = 0.0;
+    for (i64 p = b + 1; p < e; p++) {
+      const double v = val[p];
+      if (LDS) {
+        const double* t = lm_lds + (size_t)col[p] * KSPEC;
+#pragma unroll
+        for (int k = 0; k < KSPEC; k++) r[k] += v * t[k];
+      } else {
+        const double* t = hist + col[p];
+#pragma unroll
+        for (int k = 0; k < KSPEC; k++) if (k < K) r[k] += v * t[(i64)k * d];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < KSPEC; k++) {
       if (k < K) {
-        const double* th = hist + (i64)k * d;
-        double r = 0.0;
-        for (i64 p = b + 1; p < e; p++) r += val[p] * th[col[p]];
-        r = th[0] + r;
-        const double a = fabs(r);
-        const double l1p = log1p(exp(-a));
+        const double rr = (LDS ? lm_lds[k] : hist[(i64)k * d]) + r[k];     // theta[0] + sum
+        const double l1p = log1p(exp(-fabs(rr)));
         // y: -log sigma(r) = LogAdd(0,-r);  !y: LogAdd(0,r)
-        term[k] = y ? cw1 * (fmax(-r, 0.0) + l1p) : cw0 * (fmax(r, 0.0) + l1p);
+        term[k] = y ? cw1 * (fmax(-rr, 0.0) + l1p) : cw0 * (fmax(rr, 0.0) + l1p);
       }
     }
   }
@@ -227,24 +351,31 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     return klr_fail(ctx, KLR_EINVAL, "%d selected features exceed the device solver's limit (%zu)", d - 1, LDS_MAX / 32 - 1);
   const int g_in_lds = lds_big <= LDS_MAX;
   const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
+  // wave variant: theta, diag, xy (+ G) in LDS
+  const size_t lds_wave = (size_t)3 * d * sizeof(double) + (g_in_lds ? (size_t)d * d * sizeof(double) : 0);
   static bool attr_set = false;
   if (!attr_set) {
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     attr_set = true;
   }
 
   hipStream_t st = ctx->stream;
-  double *w, *z, *wz, *Gxy, *vec, *lossb;
+  double *w, *z, *wz, *G, *vec, *lossb;
+  i64* Gi;
   KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * 8, (void**)&w));
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&z));
   KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * 8, (void**)&wz));
-  KLR_TRY(ws_get(ctx, WS_CD_G, ((size_t)d * d + d) * 8, (void**)&Gxy));
-  double* G = Gxy; double* xy = Gxy + (size_t)d * d;
-  // vec: a0[d] nm[d] theta[d] hist[K*d] delta[K] | ints: stopf[K] ndone
-  const size_t vec_bytes = ((size_t)3 * d + (size_t)KSPEC * d + KSPEC) * 8 + (KSPEC + 8) * sizeof(int);
+  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8, (void**)&G));
+  Gi = (i64*)(G + (size_t)d * d);
+  // vec: a0[d] nm[d] xy[d] theta[d] hist[K*d] delta[K] gsc[2] | ints: stopf[K] ndone
+  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int);
   KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
-  double* a0 = vec; double* nm = a0 + d; double* thd = nm + d; double* hist = thd + d; double* delta = hist + (size_t)KSPEC * d;
-  int* stopf = (int*)(delta + KSPEC); int* ndone = stopf + KSPEC;
+  double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d; double* hist = thd + d;
+  double* delta = hist + (size_t)KSPEC * d; double* gsc = delta + KSPEC;
+  int* stopf = (int*)(gsc + 2); int* ndone = stopf + KSPEC;
   const i64 nb = std::max<i64>(1, ceil_div(n, 256));
   KLR_TRY(ws_get(ctx, WS_CD_LOSS, ((size_t)nb * KSPEC + KSPEC) * 8, (void**)&lossb));
   double* losses = lossb + (size_t)nb * KSPEC;
@@ -267,15 +398,17 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
     KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr));
     if (n) hipLaunchKernelGGL(k_mul, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, w, z, wz, n);
-    KLR_HIP(ctx, hipMemsetAsync(G, 0, (size_t)d * d * 8, st));
     KLR_TRY(launch_xt_s(ctx, red, w, a0, false));      // sum_i w_i x_ij      -> row/column 0
     KLR_TRY(launch_xt_s(ctx, red, w, nm, true));       // sum_i w_i x_ij^2    -> diagonal (norm)
     KLR_TRY(launch_xt_s(ctx, red, wz, xy, false));     // sum_i w_i z_i x_ij  -> inner_xy
+    KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
+    hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
+    KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     if (n) hipLaunchKernelGGL(k_gram_offdiag, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, red->rowptr, red->col,
-                              (const double*)red->val, w, n, d, G);
-    hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, a0, nm, d, G);
+                              (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
+    KLR_TRY(klr_allreduce(ctx, Gi, (i64)d * d, KLR_I64));
+    hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, a0, nm, Gi, gsc, d, G);
     KLR_HIP(ctx, hipGetLastError());
-    KLR_TRY(klr_allreduce(ctx, Gxy, (i64)d * d + d, KLR_F64));
     tp = th;
 
     // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
@@ -286,10 +419,17 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
-      hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
+      if (d <= 128)      hipLaunchKernelGGL(k_cd_wave<2>, dim3(1), dim3(64), lds_wave, st, a);
+      else if (d <= 256) hipLaunchKernelGGL(k_cd_wave<4>, dim3(1), dim3(64), lds_wave, st, a);
+      else if (d <= 512) hipLaunchKernelGGL(k_cd_wave<8>, dim3(1), dim3(64), lds_wave, st, a);
+      else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
-        hipLaunchKernelGGL(k_loss_multi, dim3((unsigned)nb), dim3(256), 0, st, red->rowptr, red->col, (const double*)red->val,
-                           red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
+        if ((size_t)KSPEC * d * 8 <= 48 * 1024)
+          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nb), dim3(256), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
+                             (const double*)red->val, red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
+        else
+          hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nb), dim3(256), 0, st, red->rowptr, red->col,
+                             (const double*)red->val, red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
         hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
         KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
         KLR_HIP(ctx, hipMemcpyAsync(hloss.data(), losses, KSPEC * 8, hipMemcpyDeviceToHost, st));

@@ -289,14 +289,21 @@ __global__ __launch_bounds__(COO_THREADS) void k_sweep_coo(const uint4* __restri
 //                      dim+2: loss limb0 | dim+3: loss limb1 | dim+4: non-finite loss terms
 #define IB_EXTRA 5
 
-__global__ __launch_bounds__(256) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
-                                                    const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf) {
-  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (j >= dim || j == 0) return;
-  const u32 ct = (u32)(j >> TILE_BITS), c = (u32)(j & (TILE_DIM - 1));
+// 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile, LDS combines
+__global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
+                                                     const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf) {
+  __shared__ i64 sh[4][256];
+  const int cx = threadIdx.x & 255, ly = threadIdx.x >> 8;
+  const i64 j = (i64)blockIdx.x * 256 + cx;
   i64 v = 0;
-  for (u32 k = ctptr[ct]; k < ctptr[ct + 1]; k++) v += part[(i64)ctlist[k] * TILE_DIM + c];
-  ibuf[j] = v;
+  if (j < dim) {
+    const u32 ct = (u32)(j >> TILE_BITS), c = (u32)(j & (TILE_DIM - 1));
+    const u32 k1 = ctptr[ct + 1];
+    for (u32 k = ctptr[ct] + ly; k < k1; k += 4) v += part[(i64)ctlist[k] * TILE_DIM + c];
+  }
+  sh[ly][cx] = v;
+  __syncthreads();
+  if (ly == 0 && j < dim && j > 0) ibuf[j] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
 }
 
 // s -> int64 fixed point; bias sum and loss as exactly additive integer limbs
@@ -409,7 +416,7 @@ static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const
     KLR_HIP(ctx, hipEventRecord(e1, st));
     ctx->prof_ev.emplace_back(e0, e1);
   }
-  hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256)), dim3(256), 0, st, part, mat->t_ctptr, mat->t_ctlist,
+  hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256)), dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist,
                      dim, ibuf);
   KLR_HIP(ctx, hipGetLastError());
   KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));

@@ -370,3 +370,22 @@ def test_full_size_properties(ctx):
     ra = K.sweep_select(ctx, mat, None, None, np.zeros(1), (2.0, 0.5), N, want_g=True)
     g_lin = (2.0 * bg - 0.5 * fg) / (2.0 * n)
     assert np.max(np.abs(ra["g"] - g_lin)) <= 1e-12 * np.max(np.abs(g_lin))
+
+
+@pytest.mark.parametrize("N", [40, 150, 300, 560])
+def test_cd_solve_solver_variants(ctx, N):
+    """d = N+1 selects the solver kernel: one wavefront with 2/4/8 q values per lane, or the workgroup
+    version; all must follow the oracle's iterate sequence."""
+    x, labels = O.synth_csr(77, 0, 3000, 3000, 8192, 400, 2 * N)
+    m = upload(ctx, x, labels)
+    cw = O.class_weights(labels)
+    r = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, N)
+    cols = np.nonzero(r["b"])[0]
+    assert len(cols) == N + 1
+    red = m.select_columns(cols); redo = O.select_columns(x, cols)
+    th, recs = K.cd_solve(ctx, red, np.zeros(N + 1), cw=cw, l1reg=r["lam"] * x.n, eps_loss=1e-9, max_iter=60)
+    tho, reco = O.cd_solve(redo, labels, np.zeros(N + 1), cw=cw, l1reg=r["lam"] * x.n, eps_loss=1e-9, max_iter=60)
+    assert [a["iteration"] for a in recs] == [a["iteration"] for a in reco]
+    assert [a["nonzero"] for a in recs] == [a["nonzero"] for a in reco]
+    np.testing.assert_allclose([a["loss"] for a in recs], [a["loss"] for a in reco], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(th, tho, rtol=THETA_RTOL, atol=1e-11)
