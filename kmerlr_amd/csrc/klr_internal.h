@@ -147,7 +147,7 @@ int   h2d(klr_ctx* ctx, void* dst, const void* src, size_t bytes);     // async 
 int   d2h_sync(klr_ctx* ctx, void* dst, const void* src, size_t bytes); // copies and waits
 
 // row pass modes
-enum { ROW_SWEEP = 0, ROW_LOSS = 1, ROW_IRLS = 2, ROW_LOGPDF = 3 };
+enum { ROW_SWEEP = 0, ROW_LOSS = 1, ROW_IRLS = 2, ROW_LOGPDF = 3, ROW_SWEEP_FIX = 4 };
 // Row pass over mat's CSR with dense device theta (length mat->dim).
 //  ROW_SWEEP : out0[i] = s_i = cw[y]/n_total * (sigma - y); out1[i] (nullable) = loss term of row i
 //  ROW_LOSS  : *loss_acc_dev += sum_i cw[y] * (-log sigma(+-r))
@@ -168,6 +168,24 @@ int   launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double*
 // local loss partial (row pass loss_acc_dev).
 int   sweep_all(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev, const double* lterm_dev,
                 double* gbuf);
+// count data, fused form used by klr_sweep_select: the row pass writes the fixed-point weights itself
+// (sweep_fix_begin gives it scale/S/acc), the conversion back to f64 also emits the selection keys and
+// their coarse histogram (keys/hist from sel_prepare; may be NULL).
+int   sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double* scale_out, i64** S_out,
+                      unsigned long long** acc_out);
+int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
+                       const unsigned long long* rowblk, i64 nrowblk);
+int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
+                          const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk);
+int   sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist);
+
+// selection keys: bit pattern of |g| (NaN -> 0); coarse histogram over the top 13 bits
+#define FAST_BINS 8192
+#define FAST_SHIFT 50
+__device__ __forceinline__ u64 abs_key(double g) {
+  if (g != g) return 0ull;
+  return (u64)__double_as_longlong(fabs(g));
+}
 
 // device exclusive scan of u32 counts into i64 offsets (out has n+1 entries)
 int   launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out);
@@ -175,7 +193,7 @@ int   launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out);
 // selection on a device gradient (g_dev[0..dim), feature j at g_dev[j+1]); finishes Select on host
 int   select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                          double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
-                         int* ok_out, i64* picked_out);
+                         int* ok_out, i64* picked_out, bool keys_hist_ready = false);
 
 // matrix construction helpers
 int   mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat);   // uses h_colptr/h_collen

@@ -24,11 +24,7 @@ struct SelState {
   u64 wkey;        // largest key < vkey
 };
 
-__device__ __forceinline__ u64 abs_key(double g) {
-  // NaN is treated as a zero gradient (never preferred); documented in DESIGN.md
-  if (g != g) return 0ull;
-  return (u64)__double_as_longlong(fabs(g));
-}
+// abs_key (klr_internal.h): NaN is treated as a zero gradient (never preferred); see DESIGN.md
 
 __global__ __launch_bounds__(256) void k_sel_keys(const double* __restrict__ g, i64 m, u64* __restrict__ keys) {
   const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -191,8 +187,6 @@ static inline double key_to_double(u64 k) { double d; memcpy(&d, &k, 8); return 
 // compacted and sorted by one workgroup.  4 launches instead of 25.  Falls back to the exact 8-pass
 // radix select when the bracket holds more than FAST_CAP keys (e.g. K reaches into the zeros).
 // ---------------------------------------------------------------------------------------------------
-#define FAST_BINS 8192
-#define FAST_SHIFT 50
 #define FAST_CAP 8192
 
 struct FastState {
@@ -337,29 +331,36 @@ static int select_exact_device(klr_ctx* ctx, const double* g_dev, u64* keys, boo
   return KLR_OK;
 }
 
+// buffers of the fast path; the histogram is kept all-zero between uses
+int sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist) {
+  char* fm;
+  KLR_TRY(ws_get(ctx, WS_SEL_KEYS, (size_t)std::max<i64>(m, 1) * sizeof(u64), (void**)keys));
+  const size_t fm_bytes = 64 + FAST_BINS * sizeof(u32);
+  KLR_TRY(ws_get(ctx, WS_MASK, fm_bytes, (void**)&fm));
+  *hist = (u32*)(fm + 64);
+  if (ctx->sel_hist_zeroed != (void*)*hist) {          // the pick kernel re-zeroes the bins after use
+    KLR_HIP(ctx, hipMemsetAsync(fm, 0, fm_bytes, ctx->stream));
+    ctx->sel_hist_zeroed = (void*)*hist;
+  }
+  return KLR_OK;
+}
+
 int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                        double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
-                       int* ok_out, i64* picked_out) {
+                       int* ok_out, i64* picked_out, bool keys_hist_ready) {
   KLR_ARG(ctx, m >= 0 && N >= 0 && b != nullptr);
   const i64 K = std::min<i64>(m, 2 * N);             // NLargestAbsFloat64(g_, 2N)
   std::vector<Cand> hc((size_t)std::max<i64>(K, 1));
   u64 vkey = 0, wkey = 0;
   if (K > 0) {
     hipStream_t st = ctx->stream;
-    u64* keys; char* fm; Cand* cand;
-    KLR_TRY(ws_get(ctx, WS_SEL_KEYS, (size_t)m * sizeof(u64), (void**)&keys));
-    const size_t fm_bytes = sizeof(FastState) + 64 + FAST_BINS * sizeof(u32);
-    KLR_TRY(ws_get(ctx, WS_MASK, fm_bytes, (void**)&fm));
+    u64* keys; u32* hist; Cand* cand;
+    KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
     KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(FAST_CAP + K) * sizeof(Cand), (void**)&cand));
-    FastState* fs = (FastState*)fm;
-    u32* hist = (u32*)(fm + sizeof(FastState) + 64 - (sizeof(FastState) % 64));
-    if (ctx->sel_hist_zeroed != (void*)hist) {          // the pick kernel re-zeroes the bins after use
-      KLR_HIP(ctx, hipMemsetAsync(fm, 0, fm_bytes, st));
-      ctx->sel_hist_zeroed = (void*)hist;
-    }
+    FastState* fs = (FastState*)((char*)hist - 64);
     Cand* out = cand + FAST_CAP;
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
-    hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
+    if (!keys_hist_ready) hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
     hipLaunchKernelGGL(k_fast_pickbin, dim3(1), dim3(1024), 0, st, hist, (u32)K, fs);
     hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(256), 0, st, keys, m, fs, cand);
     static bool attr = false;
@@ -370,9 +371,15 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     }
     hipLaunchKernelGGL(k_fast_sort, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, cand, (u32)K, (u32)N, fs, out);
     KLR_HIP(ctx, hipGetLastError());
+    // one pinned staging block: [64 B reserved for the caller | FastState | K candidates]
+    char* pin;
+    KLR_TRY(pin_get(ctx, 64 + 64 + (size_t)K * sizeof(Cand), (void**)&pin));
+    KLR_HIP(ctx, hipMemcpyAsync(pin + 64, fs, sizeof(FastState), hipMemcpyDeviceToHost, st));
+    KLR_HIP(ctx, hipMemcpyAsync(pin + 128, out, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
+    KLR_HIP(ctx, hipStreamSynchronize(st));
     FastState hs;
-    KLR_HIP(ctx, hipMemcpyAsync(hc.data(), out, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
-    KLR_TRY(d2h_sync(ctx, &hs, fs, sizeof(hs)));
+    memcpy(&hs, pin + 64, sizeof(hs));
+    memcpy(hc.data(), pin + 128, (size_t)K * sizeof(Cand));
     vkey = hs.vkey; wkey = hs.wkey;
     const bool need_w = !(N > K) && N >= 1;
     if (hs.fallback || (need_w && !hs.wfound)) {
@@ -448,17 +455,13 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   KLR_ARG(ctx, reduced == nullptr || (reduced->dim == c_plus_1 && reduced->n == full->n && red_cols != nullptr));
   KLR_HIP(ctx, hipSetDevice(ctx->device));
   const i64 n = full->n, dim = full->dim, m = dim - 1;
-  double *s, *gbuf, *thd, *lt = nullptr;
+  double *s, *gbuf, *thd = nullptr;
   KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&s));
   KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&gbuf));
-  if (full->tiled) KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * sizeof(double), (void**)&lt));
   // restoreNonzero (:194-219): b[0] = 1 and b[j] = 1 where theta_j != 0; c = count
   i64 c_prev = 0;
   memset(b, 0, (size_t)dim);
   b[0] = 1;
-  // count data: per-row loss terms go to `lt` and are summed exactly by the integer sweep;
-  // otherwise the row pass leaves the local loss partial in gbuf[dim]
-  double* lacc = full->tiled ? nullptr : gbuf + dim;
   if (reduced) {
     for (i64 p = 1; p < c_plus_1; p++) {
       KLR_ARG(ctx, red_cols[p] > 0 && red_cols[p] < dim);
@@ -466,17 +469,35 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     }
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
     KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
-    KLR_TRY(launch_row_pass(ctx, reduced, thd, ROW_SWEEP, cw, s, lt, lacc));
-  } else {
-    KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, lt, lacc));
   }
-  // [g | loss] in ONE all-reduce per sweep
-  KLR_TRY(sweep_all(ctx, full, cw, s, lt, gbuf));
+  const i64 Ksel = std::min<i64>(m, 2 * N);
+  char* pin;
+  KLR_TRY(pin_get(ctx, 64 + 64 + (size_t)std::max<i64>(Ksel, 1) * 16, (void**)&pin));
+  bool keys_ready = false;
+  if (full->tiled) {
+    // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
+    // all-reduce of [g | bias | loss]; conversion to f64 emits the selection keys + histogram
+    double scale; i64* S; unsigned long long* acc; u64* keys; u32* hist;
+    KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
+    KLR_TRY(sweep_fix_begin(ctx, full, cw, &scale, &S, &acc));
+    unsigned long long* rowblk; i64 nrowblk;
+    (void)acc;
+    KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale, S,
+                                &rowblk, &nrowblk));
+    KLR_TRY(sweep_fix_finish(ctx, full, scale, gbuf, keys, hist, rowblk, nrowblk));
+    keys_ready = m > 0;
+  } else {
+    // the row pass leaves the local loss partial in gbuf[dim]; [g | loss] in ONE f64 all-reduce
+    if (reduced) KLR_TRY(launch_row_pass(ctx, reduced, thd, ROW_SWEEP, cw, s, nullptr, gbuf + dim));
+    else         KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, nullptr, gbuf + dim));
+    KLR_TRY(sweep_all(ctx, full, cw, s, nullptr, gbuf));
+  }
   if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  double loss_sum = 0.0;
-  KLR_HIP(ctx, hipMemcpyAsync(&loss_sum, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr));
+  KLR_HIP(ctx, hipMemcpyAsync(pin, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready));
   KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out / loss copies (select may not have synchronised)
+  double loss_sum;
+  memcpy(&loss_sum, ctx->pin, sizeof(double));
   if (loss_out) *loss_out = full->n_total ? loss_sum / (double)full->n_total : 0.0;
   return KLR_OK;
 }

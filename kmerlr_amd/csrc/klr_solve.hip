@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void k_gram_offdiag(const i64* __restrict__ ro
   }
 }
 
+// same, with the d x d integer Gram privatised in LDS (d*d*8 bytes <= 128 KiB): LDS atomics absorb the
+// hot cells (popular column pairs), one global atomic per nonzero cell and workgroup at the end
+__global__ __launch_bounds__(1024) void k_gram_offdiag_lds(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                           const double* __restrict__ val, const double* __restrict__ w,
+                                                           i64 n, int d, const double* __restrict__ sc,
+                                                           unsigned long long* __restrict__ Gi) {
+  extern __shared__ unsigned long long gl[];
+  const int dd = d * d;
+  for (int t = threadIdx.x; t < dd; t += 1024) gl[t] = 0ull;
+  __syncthreads();
+  const double s0 = sc[0];
+  for (i64 i = (i64)blockIdx.x * 1024 + threadIdx.x; i < n; i += (i64)gridDim.x * 1024) {
+    const i64 b = rowptr[i], e = rowptr[i + 1];
+    const double wi = w[i] * s0;
+    for (i64 a = b + 1; a < e; a++) {
+      const double wa = wi * val[a];
+      const int ja = (int)col[a];
+      for (i64 c = a + 1; c < e; c++)
+        atomicAdd(&gl[ja * d + (int)col[c]], (unsigned long long)__double2ll_rn(wa * val[c]));
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < dd; t += 1024) { const unsigned long long v = gl[t]; if (v) atomicAdd(&Gi[t], v); }
+}
+
 // G from its parts: row/column 0 and the diagonal from the column sweeps, the rest from the integers
 __global__ __launch_bounds__(256) void k_gram_assemble(const double* __restrict__ a0, const double* __restrict__ nm,
                                                        const i64* __restrict__ Gi, const double* __restrict__ sc, int d,
@@ -172,67 +197,83 @@ __global__ __launch_bounds__(CD_THREADS) void k_cd_sweeps(CdArgs a) {
   if (tid == 0) *a.ndone = done;
 }
 
-// Wave-synchronous variant for d <= 64*QPL: ONE wavefront, q = G theta held in registers (QPL values per
-// lane, coordinate i on lane i & 63, slot i >> 6), no barriers; the moving coordinate's q value reaches all
-// lanes through v_readlane.  Same arithmetic and order as k_cd_sweeps.
+// Wave-synchronous variant for d <= 64*QPL: ONE wavefront, no barriers.  q = G theta, theta, xy and the
+// diagonal live in registers (QPL values per lane; coordinate i on lane i & 63, slot i >> 6) and reach all
+// lanes through v_readlane (j is wave-uniform); row j of G is requested at the top of the step so its
+// latency hides behind the scalar update.  Same arithmetic and order as k_cd_sweeps.
+__device__ __forceinline__ double bcast_lane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 template <int QPL>
 __global__ __launch_bounds__(64) void k_cd_wave(CdArgs a) {
   extern __shared__ double lds[];
   const int d = a.d, lane = threadIdx.x;
-  double* th = lds;
-  double* dg = th + d;
-  double* xyv = dg + d;
-  double* Gl = xyv + d;
+  double* Gl = lds;
   const double* G = a.G;
   if (a.g_in_lds) {
     for (i64 i = lane; i < (i64)d * d; i += 64) Gl[i] = a.G[i];
     G = Gl;
+    __syncthreads();
   }
-  for (int i = lane; i < d; i += 64) { th[i] = a.theta[i]; xyv[i] = a.xy[i]; dg[i] = a.G[(i64)i * d + i]; }
-  __syncthreads();
-  double q[QPL];
+  double q[QPL], th[QPL], xy[QPL], dg[QPL];
 #pragma unroll
   for (int s = 0; s < QPL; s++) {
     const int i = s * 64 + lane;
-    double acc = 0.0;
-    if (i < d) for (int k = 0; k < d; k++) { const double t = th[k]; if (t != 0.0) acc += G[(i64)k * d + i] * t; }
-    q[s] = acc;
+    th[s] = i < d ? a.theta[i] : 0.0;
+    xy[s] = i < d ? a.xy[i] : 0.0;
+    dg[s] = i < d ? a.G[(i64)i * d + i] : 1.0;
+    q[s] = 0.0;
+  }
+  // q = G theta (skipping zero coefficients)
+  for (int k = 0; k < d; k++) {
+    double tsel = th[0];
+#pragma unroll
+    for (int s = 1; s < QPL; s++) if ((k >> 6) == s) tsel = th[s];
+    const double t = bcast_lane(tsel, k & 63);
+    if (t != 0.0) {
+#pragma unroll
+      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) q[s] += G[(i64)k * d + i] * t; }
+    }
   }
   int done = 0;
   for (int k = 0; k < a.K; k++) {
     double max_x = 0.0, max_delta = 0.0;
     int isnan_ = 0;
     for (int j = 0; j < d; j++) {
-      // q_j from its owner lane (j uniform -> scalar lane index)
-      double qsel = q[0];
+      double grow[QPL];
 #pragma unroll
-      for (int s = 1; s < QPL; s++) if ((j >> 6) == s) qsel = q[s];
-      const int lo = __builtin_amdgcn_readlane(__double2loint(qsel), j & 63);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(qsel), j & 63);
-      const double qj = __hiloint2double(hi, lo);
-      const double old = th[j];
-      double t = xyv[j] + dg[j] * old - qj;                       // coordinate.go:56-59
+      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; grow[s] = i < d ? G[(i64)j * d + i] : 0.0; }
+      double qs = q[0], ts = th[0], xs = xy[0], ds = dg[0];
+#pragma unroll
+      for (int s = 1; s < QPL; s++) if ((j >> 6) == s) { qs = q[s]; ts = th[s]; xs = xy[s]; ds = dg[s]; }
+      const int l = j & 63;
+      const double qj = bcast_lane(qs, l), old = bcast_lane(ts, l), xj = bcast_lane(xs, l), dj = bcast_lane(ds, l);
+      double t = xj + dj * old - qj;                              // coordinate.go:56-59
+      // a penalised coordinate sitting at zero whose |t| does not exceed l1reg stays at (+-)0: the
+      // threshold gives 0, 0/(norm+l2) = 0, delta 0 -- skip the rest of the step (exactly the same result)
+      if (j > 0 && old == 0.0 && fabs(t) <= a.l1reg && (dj + a.l2reg) != 0.0) continue;
       if (j > 0) {                                                // :60-67 soft threshold
         const double m = fmax(fabs(t) - a.l1reg, 0.0);
         t = (t >= 0.0) ? m : -m;
       }
-      t /= (dg[j] + a.l2reg);                                     // :69
+      t /= (dj + a.l2reg);                                        // :69
       if (t != t) isnan_ = 1;
       const double dl = t - old;
       max_x = fmax(max_x, fabs(t));
       max_delta = fmax(max_delta, fabs(dl));
-      if (dl != 0.0 || t != t) {                                  // uniform branch
-        if (lane == 0) th[j] = t;
+      if (dl != 0.0 || t != t) {                                  // wave-uniform
 #pragma unroll
         for (int s = 0; s < QPL; s++) {
-          const int i = s * 64 + lane;
-          if (i < d) q[s] += dl * G[(i64)j * d + i];
+          if ((j >> 6) == s && lane == l) th[s] = t;
+          q[s] += dl * grow[s];
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
-    __syncthreads();            // single wave: orders the LDS writes of lane 0 before the reads below
-    for (int i = lane; i < d; i += 64) a.hist[(i64)k * d + i] = th[i];
+#pragma unroll
+    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.hist[(i64)k * d + i] = th[s]; }
     double delta; int stop;
     if (isnan_) { delta = nan(""); stop = 1; }
     else {
@@ -243,7 +284,8 @@ __global__ __launch_bounds__(64) void k_cd_wave(CdArgs a) {
     done = k + 1;
     if (stop) break;
   }
-  for (int i = lane; i < d; i += 64) a.theta[i] = th[i];
+#pragma unroll
+  for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.theta[i] = th[s]; }
   if (lane == 0) *a.ndone = done;
 }
 
@@ -352,13 +394,14 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const int g_in_lds = lds_big <= LDS_MAX;
   const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
   // wave variant: theta, diag, xy (+ G) in LDS
-  const size_t lds_wave = (size_t)3 * d * sizeof(double) + (g_in_lds ? (size_t)d * d * sizeof(double) : 0);
+  const size_t lds_wave = g_in_lds ? (size_t)d * d * sizeof(double) : 16;
   static bool attr_set = false;
   if (!attr_set) {
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
 
@@ -404,8 +447,16 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
     hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
     KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
-    if (n) hipLaunchKernelGGL(k_gram_offdiag, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, red->rowptr, red->col,
-                              (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
+    if (n) {
+      if ((size_t)d * d * 8 <= 128 * 1024) {
+        const unsigned gb = (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n, 1024)));
+        hipLaunchKernelGGL(k_gram_offdiag_lds, dim3(gb), dim3(1024), (size_t)d * d * 8, st, red->rowptr, red->col,
+                           (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
+      } else {
+        hipLaunchKernelGGL(k_gram_offdiag, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, red->rowptr, red->col,
+                           (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
+      }
+    }
     KLR_TRY(klr_allreduce(ctx, Gi, (i64)d * d, KLR_I64));
     hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, a0, nm, Gi, gsc, d, G);
     KLR_HIP(ctx, hipGetLastError());

@@ -37,6 +37,7 @@ struct RowPassArgs {
   const double* theta; i64 n; double inv_n; double cw0, cw1;
   double* out0; double* out1; double* blk;   // blk: per-block loss partials
   double theta0_only; int const_mode;
+  double fix_scale; i64* S; unsigned long long* acc;     // ROW_SWEEP_FIX
 };
 
 __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i, double r, double& loss_term) {
@@ -45,11 +46,12 @@ __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i
   if (mode == ROW_LOGPDF) { a.out0[i] = lp; loss_term = 0.0; return; }
   // Loss: r -= cw[y] * ClassLogPdf (:258-264)
   loss_term = y ? a.cw1 * (-lp) : a.cw0 * d_log_add0(r);
-  if (mode == ROW_SWEEP) {
+  if (mode == ROW_SWEEP || mode == ROW_SWEEP_FIX) {
     const double e = exp(lp);
     // Gradient weights (:174-178), same association as the reference: 1/n * cw * (...)
-    a.out0[i] = y ? a.inv_n * a.cw1 * (e - 1.0) : a.inv_n * a.cw0 * e;
-    if (a.out1) a.out1[i] = loss_term;
+    const double sv = y ? a.inv_n * a.cw1 * (e - 1.0) : a.inv_n * a.cw0 * e;
+    if (mode == ROW_SWEEP) { a.out0[i] = sv; if (a.out1) a.out1[i] = loss_term; }
+    else a.S[i] = __double2ll_rn(sv * a.fix_scale);
   } else if (mode == ROW_IRLS) {
     // estimate_coordinate (:97-111) with the guarded weight of oracle KLO_IRLS_WMIN
     const double p = exp(lp);
@@ -81,6 +83,37 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
     }
     if (lane == 0) row_finish(a, MODE, gid, r, loss_term);
   }
+  if (MODE == ROW_SWEEP_FIX) {
+    // exact integer partials: bias sum as hi/lo halves of S, loss as two limbs (see k_fix_s)
+    __shared__ i64 shi[4][4];
+    __shared__ u32 shbad[4];
+    i64 hi = 0, lo = 0, l0 = 0, l1 = 0; u32 bad = 0;
+    if (gid < a.n && lane == 0) {
+      const i64 v = a.S[gid];
+      hi = v >> 32; lo = (i64)(v & 0xFFFFFFFFll);
+      const double t = loss_term;
+      if (t >= 0.0 && t < 1099511627776.0) {
+        const double ts = t * 1048576.0;
+        const double f = floor(ts);
+        l0 = (i64)f;
+        l1 = __double2ll_rn((ts - f) * 4398046511104.0);
+      } else bad = 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64);
+      l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64);
+      bad += __shfl_xor(bad, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { shi[0][w] = hi; shi[1][w] = lo; shi[2][w] = l0; shi[3][w] = l1; shbad[w] = bad; }
+    __syncthreads();
+    // per-block integer partials (summed by k_finish_coo; integer sums are order free)
+    if (threadIdx.x < 4)
+      a.acc[(size_t)blockIdx.x * 5 + threadIdx.x] =
+          (unsigned long long)(shi[threadIdx.x][0] + shi[threadIdx.x][1] + shi[threadIdx.x][2] + shi[threadIdx.x][3]);
+    if (threadIdx.x == 4) a.acc[(size_t)blockIdx.x * 5 + 4] = (unsigned long long)(shbad[0] + shbad[1] + shbad[2] + shbad[3]);
+    return;
+  }
   if (MODE != ROW_LOGPDF) {
     // block partial of the loss: fixed order -> deterministic
     double v = loss_term;
@@ -111,6 +144,7 @@ static void row_pass_mode(int mode, dim3 grid, hipStream_t st, const RowPassArgs
     case ROW_SWEEP:  hipLaunchKernelGGL((k_row_pass<VT, G, ROW_SWEEP>), grid, dim3(256), 0, st, a); break;
     case ROW_LOSS:   hipLaunchKernelGGL((k_row_pass<VT, G, ROW_LOSS>), grid, dim3(256), 0, st, a); break;
     case ROW_IRLS:   hipLaunchKernelGGL((k_row_pass<VT, G, ROW_IRLS>), grid, dim3(256), 0, st, a); break;
+    case ROW_SWEEP_FIX: hipLaunchKernelGGL((k_row_pass<VT, G, ROW_SWEEP_FIX>), grid, dim3(256), 0, st, a); break;
     default:         hipLaunchKernelGGL((k_row_pass<VT, G, ROW_LOGPDF>), grid, dim3(256), 0, st, a); break;
   }
 }
@@ -127,7 +161,8 @@ static void row_pass_group(int g, int mode, i64 n, hipStream_t st, const RowPass
 }
 
 static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
-                           int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev) {
+                           int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev,
+                           double fix_scale = 0.0, i64* S = nullptr, unsigned long long* acc = nullptr) {
   const i64 n = mat->n;
   int g = 64;
   if (const_mode || mat->avg_row <= 4.0) g = 1;
@@ -135,17 +170,18 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
   else if (mat->avg_row <= 160.0) g = 16;
   const i64 nb = std::max<i64>(1, ceil_div(n * g, 256));
   double* blk;
-  KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * sizeof(double), (void**)&blk));
+  KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(double), (void**)&blk));
   RowPassArgs a;
   a.rowptr = mat->rowptr; a.col = mat->col; a.val = mat->val; a.labels = mat->labels;
   a.theta = theta_dev; a.n = n; a.inv_n = 1.0 / (double)mat->n_total; a.cw0 = cw[0]; a.cw1 = cw[1];
   a.out0 = out0; a.out1 = out1; a.blk = blk; a.theta0_only = theta0; a.const_mode = const_mode ? 1 : 0;
+  a.fix_scale = fix_scale; a.S = S; a.acc = acc;
   if (n > 0) {
     if (mat->val_f64) row_pass_group<double>(g, mode, n, ctx->stream, a);
     else              row_pass_group<float>(g, mode, n, ctx->stream, a);
   }
   if (loss_acc_dev) {
-    if (n > 0 && mode != ROW_LOGPDF)
+    if (n > 0 && mode != ROW_LOGPDF && mode != ROW_SWEEP_FIX)
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, ctx->stream, blk, nb, loss_acc_dev);
     else
       KLR_HIP(ctx, hipMemsetAsync(loss_acc_dev, 0, sizeof(double), ctx->stream));
@@ -157,6 +193,20 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
 int launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, int mode, const double cw[2],
                     double* out0, double* out1, double* loss_acc_dev) {
   return row_pass_common(ctx, mat, theta_dev, 0.0, false, mode, cw, out0, out1, loss_acc_dev);
+}
+
+int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
+                        const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk) {
+  // the kernel writes 5 integer partials per block into the WS_BLK block-partial buffer
+  int g = 64;
+  if (const_mode || mat->avg_row <= 4.0) g = 1;
+  else if (mat->avg_row <= 24.0) g = 4;
+  else if (mat->avg_row <= 160.0) g = 16;
+  const i64 nb = std::max<i64>(1, ceil_div(mat->n * g, 256));
+  unsigned long long* blk;
+  KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(unsigned long long), (void**)&blk));
+  *rowblk = blk; *nrowblk = mat->n > 0 ? nb : 0;
+  return row_pass_common(ctx, mat, theta_dev, theta0, const_mode, ROW_SWEEP_FIX, cw, nullptr, nullptr, nullptr, scale, S, blk);
 }
 
 int launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
@@ -291,8 +341,26 @@ __global__ __launch_bounds__(COO_THREADS) void k_sweep_coo(const uint4* __restri
 
 // 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile, LDS combines
 __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
-                                                     const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf) {
+                                                     const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
+                                                     const i64* __restrict__ rowblk, i64 nrowblk) {
   __shared__ i64 sh[4][256];
+  if (blockIdx.x == gridDim.x - 1) {
+    // last block: bias halves, loss limbs and the non-finite count from the row pass's block partials
+    if (rowblk) {
+      const int q = threadIdx.x & 7, l = threadIdx.x >> 3;         // 5 quantities x 128 lanes
+      i64 v = 0;
+      if (q < 5) for (i64 b = l; b < nrowblk; b += 128) v += rowblk[b * 5 + q];
+      __shared__ i64 sq[8][128];
+      sq[q][l] = v;
+      __syncthreads();
+      if (threadIdx.x < 5) {
+        i64 t = 0;
+        for (int i = 0; i < 128; i++) t += sq[threadIdx.x][i];
+        ibuf[dim + threadIdx.x] += t;
+      }
+    }
+    return;
+  }
   const int cx = threadIdx.x & 255, ly = threadIdx.x >> 8;
   const i64 j = (i64)blockIdx.x * 256 + cx;
   i64 v = 0;
@@ -346,17 +414,33 @@ __global__ __launch_bounds__(256) void k_fix_s(const double* __restrict__ s, con
 }
 
 __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, i64 dim, double inv_scale,
-                                                  double* __restrict__ g) {
-  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (j > dim) return;
-  if (j == 0) {
-    g[0] = ((double)ibuf[dim] * 4294967296.0 + (double)ibuf[dim + 1]) * inv_scale;
-  } else if (j < dim) {
-    g[j] = (double)ibuf[j] * inv_scale;                     // inv_scale is a power of two: exact
-  } else {
-    // loss sum = (limb0 + limb1 * 2^-42) * 2^-20; NaN if any term was not finite
-    const double l = ((double)ibuf[dim + 2] + (double)ibuf[dim + 3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
-    g[dim] = ibuf[dim + 4] ? nan("") : l;
+                                                  double* __restrict__ g, u64* __restrict__ keys, u32* __restrict__ hist) {
+  // grid-stride; the coarse key histogram is privatised in LDS (most keys share a few bins)
+  __shared__ u32 sh[FAST_BINS];
+  if (keys) {
+    for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
+    __syncthreads();
+  }
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j <= dim; j += (i64)gridDim.x * 256) {
+    if (j == 0) {
+      g[0] = ((double)ibuf[dim] * 4294967296.0 + (double)ibuf[dim + 1]) * inv_scale;
+    } else if (j < dim) {
+      const double v = (double)ibuf[j] * inv_scale;           // inv_scale is a power of two: exact
+      g[j] = v;
+      if (keys) {                                             // selection key of feature j-1
+        const u64 k = abs_key(v);
+        keys[j - 1] = k;
+        atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+      }
+    } else {
+      // loss sum = (limb0 + limb1 * 2^-42) * 2^-20; NaN if any term was not finite
+      const double l = ((double)ibuf[dim + 2] + (double)ibuf[dim + 3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
+      g[dim] = ibuf[dim + 4] ? nan("") : l;
+    }
+  }
+  if (keys) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
   }
 }
 
@@ -372,32 +456,43 @@ static double coo_scale(double smax, double amax) {
   return std::ldexp(1.0, E);
 }
 
-// s (f64, device) and optional per-row loss terms -> gbuf[0..dim) = X's, gbuf[dim] = sum of loss terms,
-// all-reduced across ranks as int64.  Exact and partition invariant.
-static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev,
-                     const double* lterm_dev, double* gbuf) {
+// scale, S and the integer accumulator block of one count-data sweep
+int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double* scale_out, i64** S_out,
+                    unsigned long long** acc_out) {
   const i64 n = mat->n, dim = mat->dim;
-  hipStream_t st = ctx->stream;
   // global bound on the column sums: sum of the per-rank maxima (one collective per matrix)
   klr_mat* mm = const_cast<klr_mat*>(mat);
   if (mm->col_abs_max_global < 0.0) {
     double a = mat->col_abs_max;
     if (ctx->ar_fn && ctx->nranks > 1) {
-      KLR_TRY(h2d(ctx, gbuf, &a, sizeof(double)));
-      KLR_TRY(klr_allreduce(ctx, gbuf, 1, KLR_F64));
-      KLR_TRY(d2h_sync(ctx, &a, gbuf, sizeof(double)));
+      double* t;
+      KLR_TRY(ws_get(ctx, WS_BLK, 64, (void**)&t));
+      KLR_TRY(h2d(ctx, t, &a, sizeof(double)));
+      KLR_TRY(klr_allreduce(ctx, t, 1, KLR_F64));
+      KLR_TRY(d2h_sync(ctx, &a, t, sizeof(double)));
     }
     mm->col_abs_max_global = a;
   }
   const double smax = std::max(std::fabs(cw[0]), std::fabs(cw[1])) / (double)mat->n_total;
-  const double scale = coo_scale(smax, mat->col_abs_max_global);
+  *scale_out = coo_scale(smax, mat->col_abs_max_global);
+  i64 *S, *ibuf;
+  KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
+  KLR_HIP(ctx, hipMemsetAsync(ibuf + dim, 0, IB_EXTRA * 8, ctx->stream));
+  *S_out = S;
+  *acc_out = (unsigned long long*)(ibuf + dim);
+  return KLR_OK;
+}
+
+// integer sweep over the packed stream, int64 all-reduce of [column sums | bias | loss], back to f64
+int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
+                     const unsigned long long* rowblk, i64 nrowblk) {
+  const i64 n = mat->n, dim = mat->dim;
+  hipStream_t st = ctx->stream;
   i64 *S, *part, *ibuf;
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
-  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * TILE_DIM * 8, (void**)&part));
   KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
-  KLR_HIP(ctx, hipMemsetAsync(ibuf + dim, 0, IB_EXTRA * 8, st));
-  if (n) hipLaunchKernelGGL(k_fix_s, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, s_dev, lterm_dev, n, scale, S,
-                            (unsigned long long*)(ibuf + dim));
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * TILE_DIM * 8, (void**)&part));
   const size_t lds = (size_t)TILE_DIM * 16;
   static bool attr = false;
   if (!attr) {
@@ -416,13 +511,25 @@ static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const
     KLR_HIP(ctx, hipEventRecord(e1, st));
     ctx->prof_ev.emplace_back(e0, e1);
   }
-  hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256)), dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist,
-                     dim, ibuf);
+  hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256) + 1), dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist,
+                     dim, ibuf, (const i64*)rowblk, nrowblk);
   KLR_HIP(ctx, hipGetLastError());
   KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
-  hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)ceil_div(dim + 1, 256)), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf);
+  hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,
+                     keys, hist);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
+}
+
+// s (f64, device) and optional per-row loss terms -> gbuf[0..dim) = X's, gbuf[dim] = sum of loss terms,
+// all-reduced across ranks as int64.  Exact and partition invariant.
+static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev,
+                     const double* lterm_dev, double* gbuf) {
+  double scale; i64* S; unsigned long long* acc;
+  KLR_TRY(sweep_fix_begin(ctx, mat, cw, &scale, &S, &acc));
+  if (mat->n) hipLaunchKernelGGL(k_fix_s, dim3((unsigned)ceil_div(mat->n, 256)), dim3(256), 0, ctx->stream, s_dev, lterm_dev,
+                                 mat->n, scale, S, acc);
+  return sweep_fix_finish(ctx, mat, scale, gbuf, nullptr, nullptr, nullptr, 0);
 }
 
 // Full-width sweep: gbuf[0..dim) = sum_i s_i x_ij over ALL ranks, gbuf[dim] = sum of the loss terms.
