@@ -130,12 +130,16 @@ int  klr_mat_select_columns(klr_ctx* ctx, const klr_mat* full, const int64_t* co
  * X.theta / sigmoid / loss from the REDUCED matrix of the previous epoch (theta lives on its
  * columns), per-feature gradient over the FULL matrix, one all-reduce of [g | loss], then
  * top-2N selection and lambda on the device.  reduced may be NULL (theta = theta0 on the bias
- * only, first epoch).  red_cols[c_plus_1] maps reduced columns to full columns.
+ * only, first epoch).  red_cols[c_plus_1] maps reduced columns to full columns.  With a data transform
+ * the reduced matrix already holds transformed values (klr_mat_select_columns) and scale/offset finish
+ * the full-width gradient on the fly (kmerLr_logistic_regression.go:196-222).
  * Outputs as klr_select; picked_out (length >= min(m,2N)) receives the sorted candidate
  * columns (0-based feature ids), loss_out the mean log-loss without penalty. */
 int  klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat* reduced,
                       const int64_t* red_cols, const double* theta_red, int64_t c_plus_1,
                       const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
+                      const double* scale /* nullable, length dim: TransformFull.Scale  */,
+                      const double* offset /* nullable, length dim: TransformFull.Offset */,
                       uint8_t* b, double* lambda_out, int64_t* c_out, int* ok_out,
                       double* loss_out, double* g_out /* nullable, length dim */);
 

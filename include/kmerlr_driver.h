@@ -1,0 +1,108 @@
+/*
+ * kmerlr_driver.h -- host side of the path above the kernels: the leapfrog path driver and feature
+ * selection bookkeeping of KmerLrEstimator / ScoresLrEstimator, the hook records, and the .trace /
+ * .path / model writers.  Plain C ABI.
+ *
+ * Mirrors (reference file:line):
+ *   KmerLrEstimator.Estimate / estimate_loop / estimate_fixed / estimate / reestimate
+ *                                   kmerLr_estimator.go:147-270, scoresLr_estimator.go:126-240
+ *   featureSelection.Theta / restoreNonzero bookkeeping   kmerLr_feature_selection.go:194-219,299-307
+ *   Trace.Export                    kmerLr_estimator_trace.go:49-78
+ *   {Kmer,Scores}RegularizationPath kmerLr_estimator_path.go:41-117, scoresLr_estimator_path.go
+ *   Config (hot-path fields)        kmerLr.go:32-62
+ *
+ * The driver is backend agnostic: it reaches the device only through the klr_backend function table,
+ * whose entries have exactly the signatures of include/kmerlr.h.  The shipped table is
+ * klr_hip_backend() (libkmerlr_hip.so); there is no CPU table in the product.
+ */
+#ifndef KMERLR_DRIVER_H
+#define KMERLR_DRIVER_H
+
+#include "kmerlr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct klr_backend {
+  klr_ctx* ctx;
+  const char* (*last_error)(const klr_ctx*);
+  int  (*mat_shape)(const klr_mat*, int64_t*, int64_t*, int64_t*, int64_t*);
+  void (*mat_destroy)(klr_mat*);
+  int  (*class_weights)(klr_ctx*, const klr_mat*, double[2]);
+  int  (*gradient)(klr_ctx*, const klr_mat*, const int64_t*, const double*, int64_t, const double[2],
+                   const double*, const double*, double*);
+  int  (*loss)(klr_ctx*, const klr_mat*, const double*, const double[2], double, double*);
+  int  (*select_columns)(klr_ctx*, const klr_mat*, const int64_t*, int64_t, const double*, const double*,
+                         klr_mat**);
+  int  (*sweep_select)(klr_ctx*, const klr_mat*, const klr_mat*, const int64_t*, const double*, int64_t,
+                       const double[2], int64_t, double, double, const double*, const double*, uint8_t*,
+                       double*, int64_t*, int*, double*, double*);
+  int  (*cd_solve)(klr_ctx*, const klr_mat*, double*, const double[2], double, double, double, double, int,
+                   int64_t, klr_iter_rec*, int64_t, int64_t*);
+} klr_backend;
+
+/* the HIP table for an existing context */
+int klr_hip_backend(klr_ctx* ctx, klr_backend* out);
+
+/* hot-path fields of Config (kmerLr.go:32-62); defaults = the CLI defaults (kmerLr_learn.go:116-149) */
+typedef struct klr_config {
+  double  lambda;            /* --lambda; NaN = use lambda_auto                      */
+  int64_t max_features;      /* --max-features (fixed lambda only)                   */
+  int64_t max_epochs;        /* --max-epochs, 0 = unbounded                          */
+  int64_t max_iterations;    /* --max-iterations, 0 = solver default                 */
+  double  epsilon;           /* --epsilon                                            */
+  double  epsilon_lambda;    /* --epsilon-lambda                                     */
+  double  epsilon_loss;      /* --epsilon-loss (default 1e-8)                        */
+  int     eval_loss;         /* --eval-loss (forced on when epsilon_loss != 0)       */
+  int     balance;           /* --balance: class weights n/(2 n_c), else [1,1]       */
+  int     penalty_free;      /* --penalty-free                                       */
+  int     save_trace;        /* --save-trace                                         */
+  int     save_path;         /* --save-path                                          */
+  int     verbose;           /* -v / -vv                                             */
+  double  l2reg;             /* L2Reg of the estimator (0 in the reference's CLI)    */
+} klr_config;
+
+void klr_config_default(klr_config* cfg);
+
+typedef struct klr_estimator klr_estimator;
+
+/* NewKmerLrEstimator / NewScoresLrEstimator (kmerLr_estimator.go:45-67) */
+int  klr_estimator_create(const klr_backend* be, const klr_config* cfg, klr_estimator** out);
+void klr_estimator_destroy(klr_estimator* est);
+const char* klr_estimator_error(const klr_estimator* est);
+/* warm start from a model (kmerLr_estimator.go:62-64): cols ascending incl. 0 */
+int  klr_estimator_set_model(klr_estimator* est, const int64_t* cols, const double* theta, int64_t c_plus_1);
+
+/* KmerLrEstimator.Estimate (kmerLr_estimator.go:257-270): for every lambda_auto (ascending) run
+ * estimate_loop on the SAME estimator (warm start); with cfg.lambda set run estimate_fixed instead.
+ * scale/offset: TransformFull vectors (length dim) or NULL.  One classifier per lambda_auto is kept and
+ * read back with klr_estimator_classifier. */
+int  klr_estimator_estimate(klr_estimator* est, const klr_mat* data, const int64_t* lambda_auto,
+                            int64_t n_lambda_auto, const double* scale, const double* offset);
+
+/* i-th classifier: selected columns (ascending, incl. 0), coefficients, its lambda (= L1Reg/n) and the
+ * selected transform.  Pointers stay valid until the next estimate/destroy; any may be NULL. */
+int  klr_estimator_classifier(const klr_estimator* est, int64_t i, int64_t* c_plus_1, const int64_t** cols,
+                              const double** theta, double* lambda, const double** scale, const double** offset);
+int64_t klr_estimator_n_classifiers(const klr_estimator* est);
+
+/* hook records of all solver iterations so far (Trace, kmerLr_estimator_trace.go:40-47) */
+int  klr_estimator_trace(const klr_estimator* est, const klr_iter_rec** recs, int64_t* n);
+/* number of leapfrog epochs of the last estimate call and their lambdas (the "Estimating parameters
+ * with lambda=..." lines of kmerLr_estimator.go:246) */
+int  klr_estimator_epochs(const klr_estimator* est, const double** lambdas, const int64_t** nonzero, int64_t* n);
+
+/* Trace.Export (kmerLr_estimator_trace.go:49-78) */
+int  klr_estimator_save_trace(const klr_estimator* est, const char* filename);
+/* RegularizationPath.Export (kmerLr_estimator_path.go:41-73): lambda norm theta,... */
+int  klr_estimator_save_path(const klr_estimator* est, const char* filename);
+/* model JSON of classifier i ("scoresLr" / "kmerLr" ConfigDistribution; schema parity unpinned, see
+ * DESIGN.md): names may be NULL; index_base0[k] = 0-based feature id of selected column k+1 */
+int  klr_estimator_save_model(const klr_estimator* est, int64_t i, const char* filename, const char* type_name,
+                              const char* const* names);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -5,3 +5,4 @@ plumbing around it (ctypes binding, torch.distributed launcher glue).  There is 
 """
 from ._capi import (Context, Matrix, KlrError, gradient, gradient_dense, loss, log_pdf, select,  # noqa: F401
                     select_fixed, sweep_select, cd_solve, synth_csr, rccl_unique_id, lib, LIB_PATH, SIGNATURES)
+from ._driver import Estimator, hip_estimator, Config, Backend, bind_driver  # noqa: F401,E402

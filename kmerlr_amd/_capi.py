@@ -47,7 +47,7 @@ SIGNATURES = {
                           C.POINTER(_int)]),
     "klr_select_fixed": (_int, [_vp, _vp, _i64, _vp, _i64, _dbl, _i64, C.POINTER(_i64), C.POINTER(_int)]),
     "klr_mat_select_columns": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _PVP]),
-    "klr_sweep_select": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _vp, C.POINTER(_dbl),
+    "klr_sweep_select": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, C.POINTER(_dbl),
                                 C.POINTER(_i64), C.POINTER(_int), C.POINTER(_dbl), _vp]),
     "klr_cd_solve": (_int, [_vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _int, _i64, _vp, _i64, C.POINTER(_i64)]),
     "klr_synth_csr": (_int, [C.c_uint64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int]),
@@ -261,15 +261,17 @@ def select_fixed(ctx, g_full, b, c_prev, lam, max_features=0):
     return bool(ok.value), c.value, b
 
 
-def sweep_select(ctx, full, reduced, red_cols, theta_red, cw, N, lambda_prev=0.0, eps_lambda=0.0, want_g=False):
+def sweep_select(ctx, full, reduced, red_cols, theta_red, cw, N, lambda_prev=0.0, eps_lambda=0.0, want_g=False,
+                 scale=None, offset=None):
     """Returns dict(ok, lam, c, b, loss, g)."""
-    theta_red, cw = _f64(theta_red), _f64(cw)
+    theta_red, cw, scale, offset = _f64(theta_red), _f64(cw), _f64(scale), _f64(offset)
     red_cols = None if red_cols is None else np.ascontiguousarray(red_cols, dtype=np.int64)
     b = np.zeros(full.dim, dtype=np.uint8)
     g = np.zeros(full.dim) if want_g else None
     lam, c, ok, ls = C.c_double(0.0), C.c_int64(0), C.c_int(0), C.c_double(0.0)
     ctx.check(lib().klr_sweep_select(ctx._h, full._h, None if reduced is None else reduced._h, _p(red_cols),
-                                     _p(theta_red), len(theta_red), _p(cw), N, lambda_prev, eps_lambda, _p(b),
+                                     _p(theta_red), len(theta_red), _p(cw), N, lambda_prev, eps_lambda,
+                                     _p(scale), _p(offset), _p(b),
                                      C.byref(lam), C.byref(c), C.byref(ok), C.byref(ls), _p(g)))
     return dict(ok=bool(ok.value), lam=lam.value, c=c.value, b=b, loss=ls.value, g=g)
 

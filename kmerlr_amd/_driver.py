@@ -1,0 +1,165 @@
+"""ctypes binding of include/kmerlr_driver.h: the leapfrog path driver (KmerLrEstimator.Estimate).
+
+`Estimator` works with any library that exports the klr_estimator_* entry points and a klr_backend
+table; the product passes libkmerlr_hip.so + klr_hip_backend (see `hip_estimator`)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class Backend(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ctx", "last_error", "mat_shape", "mat_destroy", "class_weights", "gradient",
+                                          "loss", "select_columns", "sweep_select", "cd_solve")]
+
+
+class Config(C.Structure):
+    """klr_config: hot-path fields of the reference's Config (kmerLr.go:32-62)."""
+    _fields_ = [("lambda_", C.c_double), ("max_features", C.c_int64), ("max_epochs", C.c_int64),
+                ("max_iterations", C.c_int64), ("epsilon", C.c_double), ("epsilon_lambda", C.c_double),
+                ("epsilon_loss", C.c_double), ("eval_loss", C.c_int), ("balance", C.c_int), ("penalty_free", C.c_int),
+                ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double)]
+
+
+def bind_driver(L):
+    vp, i64 = C.c_void_p, C.c_int64
+    L.klr_config_default.argtypes = [C.POINTER(Config)]
+    L.klr_estimator_create.restype = C.c_int
+    L.klr_estimator_create.argtypes = [C.POINTER(Backend), C.POINTER(Config), C.POINTER(vp)]
+    L.klr_estimator_destroy.argtypes = [vp]
+    L.klr_estimator_error.restype = C.c_char_p
+    L.klr_estimator_error.argtypes = [vp]
+    L.klr_estimator_set_model.restype = C.c_int
+    L.klr_estimator_set_model.argtypes = [vp, vp, vp, i64]
+    L.klr_estimator_estimate.restype = C.c_int
+    L.klr_estimator_estimate.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.klr_estimator_n_classifiers.restype = i64
+    L.klr_estimator_n_classifiers.argtypes = [vp]
+    L.klr_estimator_classifier.restype = C.c_int
+    L.klr_estimator_classifier.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_double),
+                                           C.POINTER(vp), C.POINTER(vp)]
+    L.klr_estimator_trace.restype = C.c_int
+    L.klr_estimator_trace.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.klr_estimator_epochs.restype = C.c_int
+    L.klr_estimator_epochs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    for name in ("klr_estimator_save_trace", "klr_estimator_save_path"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, C.c_char_p]
+    L.klr_estimator_save_model.restype = C.c_int
+    L.klr_estimator_save_model.argtypes = [vp, i64, C.c_char_p, C.c_char_p, vp]
+    return L
+
+
+def default_config(L, **kw):
+    cfg = Config()
+    L.klr_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        key = "lambda_" if k == "lambda_" or k == "lam" else k
+        if not hasattr(cfg, key):
+            raise TypeError("unknown config field %s" % k)
+        setattr(cfg, key, v)
+    return cfg
+
+
+class Estimator:
+    """KmerLrEstimator / ScoresLrEstimator: leapfrog path driver over a backend table."""
+
+    def __init__(self, L, backend, **config):
+        self.L = L
+        self.backend = backend
+        self.cfg = default_config(L, **config)
+        self._h = C.c_void_p()
+        rc = L.klr_estimator_create(C.byref(backend), C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            raise _capi.KlrError("klr_estimator_create failed (%d)" % rc)
+
+    def close(self):
+        if self._h:
+            self.L.klr_estimator_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _capi.KlrError("driver error %d: %s" % (rc, (self.L.klr_estimator_error(self._h) or b"").decode()))
+
+    def set_model(self, cols, theta):
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        self._check(self.L.klr_estimator_set_model(self._h, cols.ctypes.data, theta.ctypes.data, len(cols)))
+
+    def estimate(self, mat_handle, lambda_auto=(), scale=None, offset=None):
+        la = np.ascontiguousarray(list(lambda_auto), dtype=np.int64)
+        scale = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+        offset = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
+        self._check(self.L.klr_estimator_estimate(self._h, mat_handle, la.ctypes.data if len(la) else None, len(la),
+                                                  None if scale is None else scale.ctypes.data,
+                                                  None if offset is None else offset.ctypes.data))
+        return self.classifiers()
+
+    def classifiers(self):
+        out = []
+        for i in range(self.L.klr_estimator_n_classifiers(self._h)):
+            c1, lam = C.c_int64(), C.c_double()
+            cols, th, sc, of = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            self._check(self.L.klr_estimator_classifier(self._h, i, C.byref(c1), C.byref(cols), C.byref(th), C.byref(lam),
+                                                        C.byref(sc), C.byref(of)))
+            n = c1.value
+
+            def arr(p, t):
+                if not p:
+                    return None
+                return np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), shape=(n,)).copy()
+            out.append(dict(cols=arr(cols.value, C.c_int64), theta=arr(th.value, C.c_double), lam=lam.value,
+                            scale=arr(sc.value, C.c_double), offset=arr(of.value, C.c_double)))
+        return out
+
+    def trace(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.L.klr_estimator_trace(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return []
+        recs = C.cast(p, C.POINTER(_capi.IterRec))
+        return [dict(iteration=recs[i].iteration, nonzero=recs[i].nonzero, change=recs[i].change,
+                     lambda_=recs[i].lambda_, loss=recs[i].loss, seconds=recs[i].seconds) for i in range(n.value)]
+
+    def epochs(self):
+        pl, pn, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._check(self.L.klr_estimator_epochs(self._h, C.byref(pl), C.byref(pn), C.byref(n)))
+        if n.value == 0:
+            return [], []
+        lam = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_double)), shape=(n.value,)).copy()
+        nz = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_int64)), shape=(n.value,)).copy()
+        return list(lam), list(nz)
+
+    def save_trace(self, filename):
+        self._check(self.L.klr_estimator_save_trace(self._h, filename.encode()))
+
+    def save_path(self, filename):
+        self._check(self.L.klr_estimator_save_path(self._h, filename.encode()))
+
+    def save_model(self, i, filename, type_name="scoresLr", names=None):
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+        self._check(self.L.klr_estimator_save_model(self._h, i, filename.encode(), type_name.encode(),
+                                                    None if arr is None else C.cast(arr, C.c_void_p)))
+
+
+def hip_estimator(ctx, **config):
+    """Estimator over the HIP backend of a kmerlr_amd.Context."""
+    L = bind_driver(_capi.lib())
+    L.klr_hip_backend.restype = C.c_int
+    L.klr_hip_backend.argtypes = [C.c_void_p, C.POINTER(Backend)]
+    be = Backend()
+    rc = L.klr_hip_backend(ctx._h, C.byref(be))
+    if rc != 0:
+        raise _capi.KlrError("klr_hip_backend failed (%d)" % rc)
+    return Estimator(L, be, **config)

@@ -255,3 +255,21 @@ extern "C" int klr_prof_read(klr_ctx* ctx, int64_t* launches, double* total_ms, 
   }
   return KLR_OK;
 }
+
+// ---- backend table of the host driver (include/kmerlr_driver.h) ---------------------------------
+#include "../../include/kmerlr_driver.h"
+
+extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
+  if (!ctx || !out) return klr_fail(ctx, KLR_EINVAL, "klr_hip_backend: NULL argument");
+  out->ctx = ctx;
+  out->last_error = klr_last_error;
+  out->mat_shape = klr_mat_shape;
+  out->mat_destroy = klr_mat_destroy;
+  out->class_weights = klr_class_weights;
+  out->gradient = klr_gradient;
+  out->loss = klr_loss;
+  out->select_columns = klr_mat_select_columns;
+  out->sweep_select = klr_sweep_select;
+  out->cd_solve = klr_cd_solve;
+  return KLR_OK;
+}

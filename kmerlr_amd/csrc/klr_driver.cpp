@@ -1,0 +1,398 @@
+// klr_driver.cpp -- leapfrog path driver, feature-selection bookkeeping, hook trace and the .trace /
+// .path / model writers (include/kmerlr_driver.h).  Backend agnostic: plain C++17, no HIP; every
+// device operation goes through the klr_backend table.
+//
+// Mirrors KmerLrEstimator / ScoresLrEstimator (kmerLr_estimator.go:147-270,
+// scoresLr_estimator.go:126-240), featureSelection.Theta (kmerLr_feature_selection.go:299-307),
+// Trace.Export (kmerLr_estimator_trace.go:49-78) and RegularizationPath
+// (kmerLr_estimator_path.go:41-117).
+#include "../../include/kmerlr_driver.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Classifier {
+  std::vector<int64_t> cols;
+  std::vector<double> theta;
+  double lambda = 0.0;
+  std::vector<double> scale, offset;
+};
+
+struct Path {   // ScoresRegularizationPath / KmerRegularizationPath
+  std::vector<double> lambda, norm;
+  std::vector<std::vector<double>> theta;
+  std::vector<int64_t> idx;
+  std::map<int64_t, size_t> index;
+
+  void append(double lam, const std::vector<int64_t>& feat, const std::vector<double>& th) {   // path.go:79-110
+    double v = 0.0;
+    std::vector<double> t(index.size(), 0.0);
+    for (size_t j = 0; j < th.size(); j++) {
+      if (th[j] == 0.0) continue;
+      v += std::fabs(th[j]);
+      auto it = index.find(feat[j]);
+      if (it == index.end()) {
+        index[feat[j]] = index.size();
+        idx.push_back(feat[j]);
+        t.push_back(th[j]);
+      } else {
+        t[it->second] = th[j];
+      }
+    }
+    lambda.push_back(lam); norm.push_back(v); theta.push_back(t);
+    for (auto& row : theta) row.resize(t.size(), 0.0);    // augment previous entries with zeroes
+  }
+};
+
+}  // namespace
+
+struct klr_estimator {
+  klr_backend be;
+  klr_config cfg;
+  std::string err;
+  // estimator state, kept across lambda_auto values (warm start, kmerLr_estimator.go:263-267)
+  std::vector<int64_t> cols{0};
+  std::vector<double> theta{0.0};
+  double l1reg = 0.0;
+  double cw[2] = {1.0, 1.0};
+  std::vector<Classifier> out;
+  std::vector<klr_iter_rec> trace;
+  Path path;
+  std::vector<double> ep_lambda;
+  std::vector<int64_t> ep_nonzero;
+};
+
+static int fail(klr_estimator* e, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  e->err = buf;
+  return code;
+}
+
+static int be_fail(klr_estimator* e, int code, const char* what) {
+  const char* m = e->be.last_error ? e->be.last_error(e->be.ctx) : "";
+  return fail(e, code, "%s failed: %s", what, m ? m : "");
+}
+
+static void say(const klr_estimator* e, int level, const char* fmt, ...) {   // PrintStderr, kmerLr_io.go:30-34
+  if (e->cfg.verbose < level) return;
+  va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
+}
+
+extern "C" void klr_config_default(klr_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->lambda = NAN;
+  c->epsilon_loss = 1e-8;       // kmerLr_learn.go:136
+  c->eval_loss = 1;             // :331-333
+}
+
+extern "C" int klr_estimator_create(const klr_backend* be, const klr_config* cfg, klr_estimator** out) {
+  if (!be || !cfg || !out) return KLR_EINVAL;
+  if (!be->sweep_select || !be->select_columns || !be->cd_solve || !be->mat_shape || !be->mat_destroy ||
+      !be->gradient || !be->class_weights)
+    return KLR_EINVAL;
+  klr_estimator* e = new klr_estimator();
+  e->be = *be;
+  e->cfg = *cfg;
+  if (e->cfg.epsilon_loss != 0.0) e->cfg.eval_loss = 1;      // kmerLr_learn.go:331-333
+  *out = e;
+  return KLR_OK;
+}
+
+extern "C" void klr_estimator_destroy(klr_estimator* e) { delete e; }
+
+extern "C" const char* klr_estimator_error(const klr_estimator* e) { return e ? e->err.c_str() : "estimator is NULL"; }
+
+extern "C" int klr_estimator_set_model(klr_estimator* e, const int64_t* cols, const double* theta, int64_t c1) {
+  if (!e) return KLR_EINVAL;
+  if (!cols || !theta || c1 < 1 || cols[0] != 0) return fail(e, KLR_EINVAL, "model must start with the bias column");
+  for (int64_t p = 1; p < c1; p++) if (cols[p] <= cols[p - 1]) return fail(e, KLR_EINVAL, "model columns must ascend");
+  e->cols.assign(cols, cols + c1);
+  e->theta.assign(theta, theta + c1);
+  return KLR_OK;
+}
+
+// selected transform = TransformFull.Select(b) (kmerLr_transform.go:290-306)
+static void select_transform(const std::vector<int64_t>& cols, const double* scale, const double* offset,
+                             std::vector<double>& sc, std::vector<double>& of) {
+  sc.clear(); of.clear();
+  if (scale) for (int64_t c : cols) sc.push_back(scale[c]);
+  if (offset) for (int64_t c : cols) of.push_back(offset[c]);
+}
+
+// After a selection mask b: new column list and featureSelection.Theta() (:299-307): the restored
+// nonzero coefficients on their columns, zero on the new ones.
+static void adopt_selection(klr_estimator* e, const std::vector<uint8_t>& b) {
+  std::vector<int64_t> nc;
+  std::vector<double> nt;
+  size_t q = 0;
+  for (int64_t j = 0; j < (int64_t)b.size(); j++) {
+    if (!b[j]) continue;
+    while (q < e->cols.size() && e->cols[q] < j) q++;
+    double t = 0.0;
+    if (q < e->cols.size() && e->cols[q] == j) t = e->theta[q];
+    nc.push_back(j); nt.push_back(t);
+  }
+  e->cols.swap(nc); e->theta.swap(nt);
+}
+
+// KmerLrEstimator.estimate (kmerLr_estimator.go:147-173): solve on the reduced data, append the path
+static int solve_reduced(klr_estimator* e, const klr_mat* red, int64_t n_total, double l1reg, std::vector<double>& theta) {
+  const int64_t cap = 1 << 16;
+  std::vector<klr_iter_rec> recs((size_t)cap);
+  int64_t nrec = 0;
+  int rc = e->be.cd_solve(e->be.ctx, red, theta.data(), e->cw, l1reg, e->cfg.l2reg, e->cfg.epsilon, e->cfg.epsilon_loss,
+                          e->cfg.eval_loss, e->cfg.max_iterations, recs.data(), cap, &nrec);
+  if (rc != KLR_OK) return be_fail(e, rc, "cd_solve");
+  const int64_t keep = std::min(nrec, cap);
+  if (e->cfg.save_trace || e->cfg.verbose > 1) {
+    for (int64_t i = 0; i < keep; i++) {
+      e->trace.push_back(recs[(size_t)i]);                                          // hook.go:74-76
+      if (e->cfg.verbose > 1) {                                                     // hook.go:77-92
+        const klr_iter_rec& r = recs[(size_t)i];
+        fprintf(stdout, "{ iteration: %d, coefficients: %d, lambda: %e, ", r.iteration, r.nonzero - 1, r.lambda);
+        if (e->cfg.eval_loss) fprintf(stdout, "loss: %f, ", r.loss);
+        fprintf(stdout, "delta-theta: %e, time: %.6fs }\n", r.change, r.seconds);
+      }
+    }
+  }
+  (void)n_total;
+  return KLR_OK;
+}
+
+static int estimate_common(klr_estimator* e, const klr_mat* data, const double* scale, const double* offset,
+                           int64_t lambda_auto /* 0: fixed lambda */) {
+  int64_t n = 0, dim = 0, nnz = 0, n_total = 0;
+  if (e->be.mat_shape(data, &n, &dim, &nnz, &n_total) != KLR_OK) return fail(e, KLR_EINVAL, "bad data matrix");
+  if (n_total == 0) return fail(e, KLR_EINVAL, "no training data given");        // kmerLr_learn.go:100-102
+  for (int64_t c : e->cols) if (c >= dim) return fail(e, KLR_EINVAL, "model column %lld outside the data", (long long)c);
+  const int64_t m = dim - 1;
+  const int64_t N = lambda_auto;                                                    // n_params :91-101
+  // SetLabels (kmerLr_estimator.go:219): class weights; Balance -> compute_class_weights, else [1,1]
+  if (e->cfg.balance) {
+    if (e->be.class_weights(e->be.ctx, data, e->cw) != KLR_OK) return be_fail(e, KLR_EHIP, "class_weights");
+  } else { e->cw[0] = 1.0; e->cw[1] = 1.0; }
+
+  klr_mat* red = nullptr;
+  std::vector<double> sc, of;
+  int rc = KLR_OK;
+  bool have = false;
+  auto rebuild = [&]() -> int {
+    if (red) { e->be.mat_destroy(red); red = nullptr; }
+    select_transform(e->cols, scale, offset, sc, of);
+    int r = e->be.select_columns(e->be.ctx, data, e->cols.data(), (int64_t)e->cols.size(), sc.empty() ? nullptr : sc.data(),
+                                 of.empty() ? nullptr : of.data(), &red);
+    return r == KLR_OK ? KLR_OK : be_fail(e, r, "select_columns");
+  };
+  // warm start: theta lives on e->cols; its reduced rows are needed for X.theta
+  if (e->cols.size() > 1) { if ((rc = rebuild()) != KLR_OK) return rc; }
+
+  std::vector<uint8_t> b((size_t)dim);
+  for (int64_t epoch = 0; e->cfg.max_epochs == 0 || epoch < e->cfg.max_epochs; epoch++) {   // :225
+    if (have && lambda_auto) {
+      int64_t d = 0;
+      for (size_t j = 1; j < e->theta.size(); j++) if (e->theta[j] != 0.0) d++;             // r.Nonzero()
+      if (d > N) say(e, 1, "Estimated classifier has %lld non-zero coefficients, removing %lld features...\n", (long long)d, (long long)(d - N));
+      else       say(e, 1, "Estimated classifier has %lld non-zero coefficients, selecting %lld new features...\n", (long long)d, (long long)(N - d));
+    }
+    double lambda = 0.0; int64_t c = 0; int ok = 0;
+    if (lambda_auto) {
+      // featureSelector.Select (kmerLr_estimator.go:235)
+      rc = e->be.sweep_select(e->be.ctx, data, red, e->cols.data(), e->theta.data(), (int64_t)e->cols.size(), e->cw, N,
+                              e->l1reg, e->cfg.epsilon_lambda, scale, offset, b.data(), &lambda, &c, &ok, nullptr, nullptr);
+      if (rc != KLR_OK) { rc = be_fail(e, rc, "sweep_select"); break; }
+    } else {
+      // featureSelector.SelectFixed (kmerLr_feature_selection.go:136-159)
+      std::vector<int64_t> ti; std::vector<double> tv;
+      std::fill(b.begin(), b.end(), 0); b[0] = 1;
+      for (size_t p = 0; p < e->cols.size(); p++) {
+        if (p == 0 || e->theta[p] != 0.0) { ti.push_back(e->cols[p]); tv.push_back(e->theta[p]); }
+        if (p > 0 && e->theta[p] != 0.0) { b[(size_t)e->cols[p]] = 1; c++; }                  // restoreNonzero
+      }
+      std::vector<double> g((size_t)dim);
+      rc = e->be.gradient(e->be.ctx, data, ti.data(), tv.data(), (int64_t)ti.size(), e->cw, scale, offset, g.data());
+      if (rc != KLR_OK) { rc = be_fail(e, rc, "gradient"); break; }
+      lambda = e->cfg.lambda;
+      for (int64_t k = 1; k < m + 1; k++) {                                                   // :146-155
+        if (std::fabs(g[(size_t)k]) >= lambda && !b[(size_t)k]) { ok = 1; b[(size_t)k] = 1; c++; }
+        if (e->cfg.max_features > 0 && c >= e->cfg.max_features && ok) break;
+      }
+    }
+    if (!ok && have) break;                                                                   // :236-238
+    e->l1reg = lambda * (double)n_total;                                                      // :239
+    adopt_selection(e, b);                                                                    // :240-242
+    if ((rc = rebuild()) != KLR_OK) break;                                                    // :244 selection.Data
+    if (lambda_auto) say(e, 1, "Estimating parameters with lambda=%e...\n", lambda);          // :246
+    else say(e, 1, "Estimating parameters with lambda=%e and %lld features...\n", lambda, (long long)(e->cols.size() - 1));
+    if ((rc = solve_reduced(e, red, n_total, e->l1reg, e->theta)) != KLR_OK) break;           // :247
+    if (e->cfg.save_path) {                                                                   // :168-170
+      std::vector<int64_t> feat; std::vector<double> th;
+      for (size_t p = 1; p < e->cols.size(); p++) { feat.push_back(e->cols[p] - 1); th.push_back(e->theta[p]); }
+      e->path.append(e->l1reg / (double)n_total, feat, th);
+    }
+    int64_t nz = 0;
+    for (size_t j = 1; j < e->theta.size(); j++) if (e->theta[j] != 0.0) nz++;
+    e->ep_lambda.push_back(lambda); e->ep_nonzero.push_back(nz);
+    have = true;
+  }
+  if (rc == KLR_OK && have) {
+    Classifier cl;
+    cl.cols = e->cols; cl.theta = e->theta; cl.lambda = e->l1reg / (double)n_total;
+    select_transform(e->cols, scale, offset, cl.scale, cl.offset);
+    if (e->cfg.penalty_free && lambda_auto) {                                                 // :249-252 reestimate
+      say(e, 1, "Re-estimating parameters without penalty...\n");
+      std::vector<double> t = e->theta;
+      rc = solve_reduced(e, red, n_total, 0.0, t);
+      if (rc == KLR_OK) cl.theta = t;
+    }
+    if (rc == KLR_OK) e->out.push_back(cl);
+  } else if (rc == KLR_OK) {
+    rc = fail(e, KLR_EINVAL, "no classifier was estimated (max_epochs = %lld)", (long long)e->cfg.max_epochs);
+  }
+  if (red) e->be.mat_destroy(red);
+  return rc;
+}
+
+extern "C" int klr_estimator_estimate(klr_estimator* e, const klr_mat* data, const int64_t* lambda_auto,
+                                      int64_t n_lambda_auto, const double* scale, const double* offset) {
+  if (!e) return KLR_EINVAL;
+  if (!data) return fail(e, KLR_EINVAL, "data is NULL");
+  e->out.clear(); e->ep_lambda.clear(); e->ep_nonzero.clear();
+  if (!std::isnan(e->cfg.lambda)) {                                                           // :258-261
+    for (int64_t i = 0; i < n_lambda_auto; i++)
+      if (lambda_auto[i] != 0) return fail(e, KLR_EINVAL, "options --lambda and --lambda-auto are incompatible");
+    return estimate_common(e, data, scale, offset, 0);
+  }
+  if (n_lambda_auto <= 0 || !lambda_auto) return fail(e, KLR_EINVAL, "lambda_auto is empty");
+  std::vector<int64_t> la(lambda_auto, lambda_auto + n_lambda_auto);
+  std::sort(la.begin(), la.end());                                                            // kmerLr_learn.go:275
+  for (int64_t N : la) {                                                                      // :263-267
+    if (N <= 0) return fail(e, KLR_EINVAL, "lambda_auto must be positive");
+    say(e, 1, "Estimating classifier with %lld non-zero coefficients...\n", (long long)N);
+    int rc = estimate_common(e, data, scale, offset, N);
+    if (rc != KLR_OK) return rc;
+  }
+  return KLR_OK;
+}
+
+extern "C" int64_t klr_estimator_n_classifiers(const klr_estimator* e) { return e ? (int64_t)e->out.size() : 0; }
+
+extern "C" int klr_estimator_classifier(const klr_estimator* e, int64_t i, int64_t* c1, const int64_t** cols,
+                                        const double** theta, double* lambda, const double** scale, const double** offset) {
+  if (!e || i < 0 || i >= (int64_t)e->out.size()) return KLR_EINVAL;
+  const Classifier& c = e->out[(size_t)i];
+  if (c1) *c1 = (int64_t)c.cols.size();
+  if (cols) *cols = c.cols.data();
+  if (theta) *theta = c.theta.data();
+  if (lambda) *lambda = c.lambda;
+  if (scale) *scale = c.scale.empty() ? nullptr : c.scale.data();
+  if (offset) *offset = c.offset.empty() ? nullptr : c.offset.data();
+  return KLR_OK;
+}
+
+extern "C" int klr_estimator_trace(const klr_estimator* e, const klr_iter_rec** recs, int64_t* n) {
+  if (!e) return KLR_EINVAL;
+  if (recs) *recs = e->trace.data();
+  if (n) *n = (int64_t)e->trace.size();
+  return KLR_OK;
+}
+
+extern "C" int klr_estimator_epochs(const klr_estimator* e, const double** lambdas, const int64_t** nonzero, int64_t* n) {
+  if (!e) return KLR_EINVAL;
+  if (lambdas) *lambdas = e->ep_lambda.data();
+  if (nonzero) *nonzero = e->ep_nonzero.data();
+  if (n) *n = (int64_t)e->ep_lambda.size();
+  return KLR_OK;
+}
+
+// format_duration, kmerLr_estimator_trace.go:29-36
+static std::string format_duration(double seconds) {
+  const double hours_total = seconds / 3600.0;
+  const int days = (int)(hours_total / 24.0);
+  const int hours = (int)std::fmod(hours_total, 24.0);
+  const int minutes = (int)std::fmod(seconds / 60.0, 60.0);
+  const int secs = (int)std::fmod(seconds, 60.0);
+  const int msecs = (int)std::fmod(std::floor(seconds * 1000.0), 1000.0);
+  char buf[64];
+  snprintf(buf, sizeof(buf), "%02d:%02d:%02d:%02d.%03d", days, hours, minutes, secs, msecs);
+  return buf;
+}
+
+extern "C" int klr_estimator_save_trace(const klr_estimator* e, const char* filename) {
+  if (!e || !filename) return KLR_EINVAL;
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  bool any_loss = false;
+  for (const auto& r : e->trace) if (!std::isnan(r.loss)) any_loss = true;
+  const bool any_lambda = !e->trace.empty();
+  fprintf(f, "%15s %9s %12s %8s", "duration", "iteration", "change", "nonzero");       // trace.go:61
+  if (any_lambda) fprintf(f, " %12s", "lambda");
+  if (any_loss) fprintf(f, " %12s", "loss");
+  fprintf(f, "\n");
+  for (const auto& r : e->trace) {                                                       // :69-77
+    fprintf(f, "%15s %9d %12e %8d", format_duration(r.seconds).c_str(), r.iteration, r.change, r.nonzero);
+    if (any_lambda) fprintf(f, " %12e", r.lambda);
+    if (any_loss) fprintf(f, " %12e", r.loss);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+  return KLR_OK;
+}
+
+extern "C" int klr_estimator_save_path(const klr_estimator* e, const char* filename) {
+  if (!e || !filename) return KLR_EINVAL;
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  fprintf(f, "%13s %13s %s\n", "lambda", "norm", "theta");                              // path.go:55
+  for (size_t i = 0; i < e->path.lambda.size(); i++) {                                   // :58-71
+    fprintf(f, "%13e %13e", e->path.lambda[i], e->path.norm[i]);
+    for (size_t j = 0; j < e->path.theta[i].size(); j++) fprintf(f, j == 0 ? " %e" : ",%e", e->path.theta[i][j]);
+    fprintf(f, "\n");
+  }
+  fclose(f);
+  return KLR_OK;
+}
+
+static void json_str(FILE* f, const char* s) {
+  fputc('"', f);
+  for (; *s; s++) { if (*s == '"' || *s == '\\') fputc('\\', f); fputc(*s, f); }
+  fputc('"', f);
+}
+
+// ConfigDistribution{Name, Parameters, Distributions} as written by ExportDistribution
+// (kmerLr_io.go:105-112; scoresLr_classifier_ensemble.go:409-427, scoresLr_feature.go:72-86,
+// kmerLr_transform.go:646-648).  The third-party serialiser's exact key order / number format is
+// not available here: schema parity unpinned.
+extern "C" int klr_estimator_save_model(const klr_estimator* e, int64_t i, const char* filename, const char* type_name,
+                                        const char* const* names) {
+  if (!e || !filename || i < 0 || i >= (int64_t)e->out.size()) return KLR_EINVAL;
+  const Classifier& c = e->out[(size_t)i];
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  const size_t nf = c.cols.size() - 1;
+  fprintf(f, "{\n  \"Name\": ");
+  json_str(f, type_name ? type_name : "scoresLr");
+  fprintf(f, ",\n  \"Parameters\": {\n    \"Cooccurrence\": false,\n    \"Features\": [");
+  for (size_t k = 0; k < nf; k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", k, k);          // non-co-occurrence: [k,k]
+  fprintf(f, "],\n    \"Index\": [");
+  for (size_t k = 0; k < nf; k++) fprintf(f, "%s%lld", k ? "," : "", (long long)(c.cols[k + 1] - 1));
+  fprintf(f, "],\n    \"Names\": [");
+  if (names) for (size_t k = 0; k < nf; k++) { if (k) fputc(',', f); json_str(f, names[c.cols[k + 1] - 1]); }
+  fprintf(f, "]\n  },\n  \"Distributions\": [\n    {\"Name\": \"vector:logistic regression\", \"Parameters\": [");
+  for (size_t k = 0; k < c.theta.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.theta[k]);
+  fprintf(f, "], \"Distributions\": null},\n    {\"Name\": \"transform\", \"Parameters\": {\"Offset\": [");
+  for (size_t k = 0; k < c.offset.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.offset[k]);
+  fprintf(f, "], \"Scale\": [");
+  for (size_t k = 0; k < c.scale.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.scale[k]);
+  fprintf(f, "]}, \"Distributions\": null}\n  ]\n}\n");
+  fclose(f);
+  return KLR_OK;
+}

@@ -178,6 +178,7 @@ int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* g
 int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                           const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk);
 int   sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist);
+int   apply_transform_dev(klr_ctx* ctx, double* gbuf, i64 dim, const double* scale, const double* offset);
 
 // selection keys: bit pattern of |g| (NaN -> 0); coarse histogram over the top 13 bits
 #define FAST_BINS 8192

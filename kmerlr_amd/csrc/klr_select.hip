@@ -447,6 +447,7 @@ extern "C" int klr_select_fixed(klr_ctx* ctx, const double* g_full, int64_t m, u
 extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat* reduced,
                                 const int64_t* red_cols, const double* theta_red, int64_t c_plus_1,
                                 const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
+                                const double* scale, const double* offset,
                                 uint8_t* b, double* lambda_out, int64_t* c_out, int* ok_out,
                                 double* loss_out, double* g_out) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
@@ -477,15 +478,16 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   if (full->tiled) {
     // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
     // all-reduce of [g | bias | loss]; conversion to f64 emits the selection keys + histogram
-    double scale; i64* S; unsigned long long* acc; u64* keys; u32* hist;
+    double scale_fx; i64* S; unsigned long long* acc; u64* keys; u32* hist;
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
-    KLR_TRY(sweep_fix_begin(ctx, full, cw, &scale, &S, &acc));
+    KLR_TRY(sweep_fix_begin(ctx, full, cw, &scale_fx, &S, &acc));
     unsigned long long* rowblk; i64 nrowblk;
     (void)acc;
-    KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale, S,
+    KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale_fx, S,
                                 &rowblk, &nrowblk));
-    KLR_TRY(sweep_fix_finish(ctx, full, scale, gbuf, keys, hist, rowblk, nrowblk));
-    keys_ready = m > 0;
+    const bool tr = scale != nullptr || offset != nullptr;
+    KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk));
+    keys_ready = m > 0 && !tr;
   } else {
     // the row pass leaves the local loss partial in gbuf[dim]; [g | loss] in ONE f64 all-reduce
     if (reduced) KLR_TRY(launch_row_pass(ctx, reduced, thd, ROW_SWEEP, cw, s, nullptr, gbuf + dim));
@@ -493,6 +495,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     KLR_TRY(sweep_all(ctx, full, cw, s, nullptr, gbuf));
   }
   if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (scale || offset) KLR_TRY(apply_transform_dev(ctx, gbuf, dim, scale, offset));
   KLR_HIP(ctx, hipMemcpyAsync(pin, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready));
   KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out / loss copies (select may not have synchronised)

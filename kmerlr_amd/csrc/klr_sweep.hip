@@ -583,6 +583,18 @@ __global__ __launch_bounds__(256) void k_apply_transform(double* __restrict__ g,
   if (j > 0) g[j] = v;
 }
 
+// uploads the TransformFull vectors (host, length dim) and finishes g on the device
+int apply_transform_dev(klr_ctx* ctx, double* gbuf, i64 dim, const double* scale, const double* offset) {
+  double* tr;
+  KLR_TRY(ws_get(ctx, WS_CD_LOSS, (size_t)dim * 2 * sizeof(double), (void**)&tr));
+  if (scale) KLR_TRY(h2d(ctx, tr, scale, (size_t)dim * sizeof(double)));
+  if (offset) KLR_TRY(h2d(ctx, tr + dim, offset, (size_t)dim * sizeof(double)));
+  hipLaunchKernelGGL(k_apply_transform, dim3((unsigned)ceil_div(dim, 256)), dim3(256), 0, ctx->stream, gbuf, dim,
+                     scale ? tr : nullptr, offset ? tr + dim : nullptr);
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
 // dense theta (device) from a sparse host theta
 static int upload_sparse_theta(klr_ctx* ctx, i64 dim, const i64* idx, const double* val, i64 nnz, double** out) {
   double* th;

@@ -13,6 +13,20 @@
 #include <time.h>
 
 /* ---------------------------------------------------------------------------------- */
+/* row sharding (tests of the multi-rank driver only): when set, the rows held here are a shard of */
+/* a data set with n_total rows and every sum over samples goes through the hook before use.      */
+/* ---------------------------------------------------------------------------------- */
+static int64_t g_n_total = 0;
+static klo_allreduce_fn g_ar = NULL;
+static void* g_ar_user = NULL;
+
+void klo_set_sharding(int64_t n_total, klo_allreduce_fn fn, void* user) {
+  g_n_total = n_total; g_ar = fn; g_ar_user = user;
+}
+static inline double eff_n(int64_t n) { return (double)(g_n_total > 0 ? g_n_total : n); }
+static inline void ar(double* buf, int64_t cnt) { if (g_ar) g_ar(buf, cnt, g_ar_user); }
+
+/* ---------------------------------------------------------------------------------- */
 /* third-party arithmetic restated from its published semantics                       */
 /* ---------------------------------------------------------------------------------- */
 
@@ -71,6 +85,7 @@ double klo_class_log_pdf(const klo_csr* x, int64_t i, const double* theta,
 void klo_class_weights(const uint8_t* labels, int64_t n, double cw[2]) {
   int64_t n1 = 0, n0 = 0;
   for (int64_t i = 0; i < n; i++) { if (labels[i]) n1++; else n0++; }
+  if (g_ar) { double c[2] = {(double)n0, (double)n1}; ar(c, 2); n0 = (int64_t)c[0]; n1 = (int64_t)c[1]; }
   cw[0] = (double)(n0 + n1) / (double)(2 * n0);
   cw[1] = (double)(n0 + n1) / (double)(2 * n1);
 }
@@ -81,7 +96,8 @@ int klo_gradient(const klo_csr* x, const uint8_t* labels, const double* theta,
                  const double cw[2], double lambda,
                  const double* scale, const double* offset, double* g) {
   const int64_t n = x->n, dim = x->dim;
-  if (n == 0) return 1;                                                   /* :152-154 */
+  if (n == 0 && !g_ar) return 1;                                          /* :152-154 */
+  const double nn = eff_n(n);                                             /* len(data) of the whole set */
   for (int64_t j = 0; j < dim; j++) g[j] = 0.0;                           /* :162-164 */
   for (int64_t i = 0; i < n; i++) {                                       /* :166 */
     const double r = klo_class_log_pdf(x, i, theta, scale, offset, 1);    /* :168 LogPdf */
@@ -89,8 +105,8 @@ int klo_gradient(const klo_csr* x, const uint8_t* labels, const double* theta,
     const int64_t* ci = x->col + b;
     const double*  cv = x->val + b;
     double w;
-    if (labels[i]) w = 1.0 / (double)n * cw[1] * (exp(r) - 1.0);          /* :175 */
-    else           w = 1.0 / (double)n * cw[0] * (exp(r));                /* :177 */
+    if (labels[i]) w = 1.0 / nn * cw[1] * (exp(r) - 1.0);                 /* :175 */
+    else           w = 1.0 / nn * cw[0] * (exp(r));                       /* :177 */
     if (!scale && !offset) {
       for (int64_t j = 0; j < q; j++) g[ci[j]] += w * cv[j];              /* :180-182 */
     } else if (!offset) {
@@ -103,6 +119,7 @@ int klo_gradient(const klo_csr* x, const uint8_t* labels, const double* theta,
       }
     }
   }
+  ar(g, dim);
   if (!isnan(lambda) && lambda != 0.0) {                                  /* :237-246 */
     for (int64_t j = 1; j < dim; j++) {
       if (theta[j] < 0) g[j] -= lambda; else if (theta[j] > 0) g[j] += lambda;
@@ -116,13 +133,14 @@ double klo_loss(const klo_csr* x, const uint8_t* labels, const double* theta,
                 const double cw[2], double lambda,
                 const double* scale, const double* offset) {
   const int64_t n = x->n;
-  if (n == 0) return 0.0;
+  if (n == 0 && !g_ar) return 0.0;
   double r = 0.0;
   for (int64_t i = 0; i < n; i++) {                                       /* :258-264 */
     const int y = labels[i] != 0;
     r -= cw[y] * klo_class_log_pdf(x, i, theta, scale, offset, y);
   }
-  r = r / (double)n;                                                      /* :265 */
+  ar(&r, 1);
+  r = r / eff_n(n);                                                       /* :265 */
   if (!isnan(lambda) && lambda != 0.0) {
     for (int64_t j = 1; j < x->dim; j++) r += lambda * fabs(theta[j]);    /* :267-269 */
   }
@@ -293,7 +311,7 @@ typedef struct {
 
 /* NewHook closure, kmerLr_estimator_hook.go:33-101 (adaptive step size is SAGA-only) */
 static int hook_call(hook_state* h, const double* theta, double change, double l1reg, int64_t iteration) {
-  const double lambda = l1reg / (double)h->x->n;                          /* :47 */
+  const double lambda = l1reg / eff_n(h->x->n);                           /* :47 */
   double t = h->loss_old; h->loss_old = h->loss_new; h->loss_new = t;     /* :48 */
   if (h->eval_loss) h->loss_new = klo_loss(h->x, h->labels, theta, h->cw, lambda, NULL, NULL); /* :50-51 */
   int64_t nz = 0;
@@ -330,6 +348,7 @@ static int64_t coordinate_loop(const klo_csr* x, const double* z, const double* 
         G[j1 * d + x->col[bq]] += w[i] * v1 * x->val[bq];
     }
   }
+  ar(xy, d); ar(norm, d); ar(G, d * d);
   for (; iter < max_iter; iter++) {                                       /* :53 */
     for (int64_t j = 0; j < d; j++) {                                     /* :55-72 */
       double t = xy[j] + norm[j] * theta1[j];
@@ -398,7 +417,7 @@ int klo_cd_solve(const klo_csr* x, const uint8_t* labels, double* theta,
     double delta;
     if (klo_eval_stopping(tp, theta, d, eps, &delta)) break;              /* :119-120 */
     if (eval_loss && eps_loss != 0.0) {
-      const double lc = klo_loss(x, labels, theta, cw, l1reg / (double)n, NULL, NULL);
+      const double lc = klo_loss(x, labels, theta, cw, l1reg / eff_n(n), NULL, NULL);
       if (fabs(loss_outer_prev - lc) < eps_loss) break;
       loss_outer_prev = lc;
     }

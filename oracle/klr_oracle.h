@@ -52,6 +52,11 @@ typedef struct {
 
 #define KLO_IRLS_WMIN 1e-12   /* guard for the unguarded 1/w of coordinate.go:100-105 */
 
+/* row sharding for the multi-rank driver tests: rows here are a shard of n_total rows; sums over
+ * samples pass through fn (in place, all ranks) before use.  n_total = 0 / fn = NULL: off. */
+typedef void (*klo_allreduce_fn)(double* buf, int64_t count, void* user);
+void   klo_set_sharding(int64_t n_total, klo_allreduce_fn fn, void* user);
+
 double klo_log_add(double a, double b);
 double klo_linear_pdf(const klo_csr* x, int64_t i, const double* theta,
                       const double* scale, const double* offset);

@@ -1,0 +1,108 @@
+"""GPU: the host driver over the HIP backend must follow the same leapfrog path as over the oracle
+backend; the all-reduce hook plumbing (f64 and int64) is exercised with an emulated second rank."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import kmerlr_amd as K
+from oracle import oracle as O
+from tests import oracle_driver as OD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def run_both(ctx, x, labels, lambda_auto, scale=None, **cfg):
+    m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    eg = K.hip_estimator(ctx, **cfg)
+    cg = eg.estimate(m._h, lambda_auto, scale=scale)
+    h = OD.matrix(x, labels)
+    eo = OD.estimator(**cfg)
+    co = eo.estimate(h, lambda_auto, scale=scale)
+    OD.free_matrix(h)
+    return eg, cg, eo, co
+
+
+def assert_same_path(eg, cg, eo, co):
+    lg, ng = eg.epochs(); lo, no = eo.epochs()
+    assert list(ng) == list(no)                                     # identical path sequence
+    np.testing.assert_allclose(lg, lo, rtol=1e-6)
+    assert len(cg) == len(co)
+    for a, b in zip(cg, co):
+        np.testing.assert_array_equal(a["cols"], b["cols"])         # identical selected feature indices
+        np.testing.assert_allclose(a["theta"], b["theta"], rtol=1e-6, atol=1e-10)
+
+
+def test_readme_scores_on_gpu(ctx, scores_data):
+    x, labels, _ = scores_data
+    eg, cg, eo, co = run_both(ctx, x, labels, [2, 5], save_trace=1, save_path=1)
+    assert_same_path(eg, cg, eo, co)
+    assert "%e" % eg.epochs()[0][0] == "2.496875e+00"
+    assert list(cg[0]["cols"]) == [0, 2, 7]
+    tg, to = eg.trace(), eo.trace()
+    assert [r["iteration"] for r in tg] == [r["iteration"] for r in to]
+    assert [r["nonzero"] for r in tg] == [r["nonzero"] for r in to]
+
+
+def test_synthetic_leapfrog_path_on_gpu(ctx):
+    x, labels = O.synth_csr(20261004, 0, 5000, 5000, 4096, 300, 40)      # tiled count-data layout
+    eg, cg, eo, co = run_both(ctx, x, labels, [5, 20], balance=1)
+    assert_same_path(eg, cg, eo, co)
+    assert len(cg[1]["cols"]) == 21
+
+
+def test_fixed_lambda_and_scale_transform_on_gpu(ctx):
+    x, labels = O.synth_csr(3, 0, 1500, 1500, 600, 100, 10)
+    g = O.gradient(x, labels, np.zeros(x.dim))
+    lam = float(np.sort(np.abs(g[1:]))[-8])
+    eg, cg, eo, co = run_both(ctx, x, labels, [0], lambda_=lam, max_features=6)
+    assert_same_path(eg, cg, eo, co)
+    d = x.to_dense()
+    sd = d[:, 1:].std(axis=0, ddof=1); sd[sd == 0] = 1.0
+    scale = np.r_[1.0, 1.0 / sd]
+    eg, cg, eo, co = run_both(ctx, x, labels, [6], scale=scale)
+    assert_same_path(eg, cg, eo, co)
+
+
+def test_allreduce_hook_f64_and_int64(ctx):
+    """Emulated second rank: the hook doubles the buffer (as if an identical shard had been added) while
+    n_total = 2n; the results must equal the single-rank ones.  Checks that the hook sees every reduction
+    of gradient, loss, Gram and class counts, in both element types."""
+    hip = C.CDLL("libamdhip64.so")
+    seen = []
+
+    def hook(buf, count, dtype, stream):
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        host = np.empty(count, dtype=np.int64 if dtype == 1 else np.float64)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(buf), C.c_size_t(count * 8), 2) == 0
+        host *= 2
+        assert hip.hipMemcpy(C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), C.c_size_t(count * 8), 1) == 0
+        seen.append(dtype)
+
+    for shape in ((5000, 4096, 300, 24), (700, 300, 60, 8)):           # tiled (int64) and plain (f64) layouts
+        x, labels = O.synth_csr(11, 0, *shape)
+        cw = O.class_weights(labels)
+        base = K.Context(0)
+        m1 = K.Matrix.from_csr(base, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+        r1 = K.sweep_select(base, m1, None, None, np.zeros(1), cw, 10, want_g=True)
+        c2 = K.Context(0)
+        c2.set_allreduce(hook, 0, 2)
+        m2 = K.Matrix.from_csr(c2, x.n, x.dim, x.rowptr, x.col, x.val, labels, n_total=2 * x.n)
+        np.testing.assert_allclose(m2.class_weights(), cw)
+        r2 = K.sweep_select(c2, m2, None, None, np.zeros(1), cw, 10, want_g=True)
+        np.testing.assert_allclose(r2["g"], r1["g"], rtol=1e-12, atol=1e-18)
+        np.testing.assert_array_equal(r2["b"], r1["b"])
+        assert abs(r2["loss"] - r1["loss"]) < 1e-12
+        cols = np.nonzero(r1["b"])[0]
+        t1, _ = K.cd_solve(base, m1.select_columns(cols), np.zeros(len(cols)), cw=cw, l1reg=r1["lam"] * x.n)
+        t2, _ = K.cd_solve(c2, m2.select_columns(cols), np.zeros(len(cols)), cw=cw, l1reg=r1["lam"] * 2 * x.n)
+        np.testing.assert_allclose(t2, t1, rtol=1e-6, atol=1e-12)
+        m1.close(); m2.close(); c2.close(); base.close()
+    assert 0 in seen and 1 in seen
