@@ -22,6 +22,7 @@ def libpath():
 def declared_symbols(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"typedef struct klr_backend \{.*?\} klr_backend;", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(klr_[a-z0-9_]+)\s*\(", txt)) - {"klr_allreduce_fn"})
 
 
@@ -33,6 +34,11 @@ def test_library_exports_every_declared_symbol(libpath):
         assert hasattr(L, name), "libkmerlr_hip.so lacks %s" % name
     # and the Python binding covers exactly the declared surface
     assert sorted(K.SIGNATURES.keys()) == names
+    # the host driver's ABI (include/kmerlr_driver.h) ships in the same library
+    dnames = declared_symbols("kmerlr_driver.h")
+    assert "klr_estimator_estimate" in dnames and "klr_hip_backend" in dnames
+    for name in dnames:
+        assert hasattr(L, name), "libkmerlr_hip.so lacks %s" % name
 
 
 def test_version_and_error_paths(libpath):

@@ -86,7 +86,7 @@ def test_allreduce_hook_f64_and_int64(ctx):
         assert hip.hipMemcpy(C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), C.c_size_t(count * 8), 1) == 0
         seen.append(dtype)
 
-    for shape in ((5000, 4096, 300, 24), (700, 300, 60, 8)):           # tiled (int64) and plain (f64) layouts
+    for shape in ((5000, 5000, 4096, 300, 24), (700, 700, 300, 60, 8)):           # tiled (int64) and plain (f64) layouts
         x, labels = O.synth_csr(11, 0, *shape)
         cw = O.class_weights(labels)
         base = K.Context(0)
