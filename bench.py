@@ -139,11 +139,20 @@ def main():
         # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column
         alg_bytes = (4.0 + lay["value_bytes"]) * nnz + 12.0 * lay["nseg"] + 8.0 * n_local + 8.0 * (m + 1)
         kname = "k_xt_s<%d>" % lay["lanes_per_segment"]
+    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/): valid for this exact workload
+    traffic = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if lay["tiled"] and pj["workload"]["nnz"] == nnz and pj["workload"]["features"] == m:
+            traffic = pj["kernels"]["k_sweep_coo"]["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     kern_avg_ms = kern_ms / max(launches, 1)
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
     two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)" if traffic else None,
                 "kernel": kname, "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "survey_two_pass_bytes": two_pass_bytes,

@@ -65,6 +65,12 @@ def build(force=False, verbose=False):
     if force or jobs or _stale(LIB, objs):
         run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs +
             ["-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    # command line (plain C++ against the C ABI)
+    cli_src = os.path.join(HERE, "cli", "kmerlr_main.cpp")
+    cli = os.path.join(LIBDIR, "kmerlr")
+    if os.path.exists(cli_src) and (force or jobs or _stale(cli, [cli_src, LIB] + HEADERS)):
+        run(["g++", "-O2", "-std=c++17", cli_src, "-o", cli, "-L" + LIBDIR, "-lkmerlr_hip",
+             "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

@@ -1,0 +1,372 @@
+// kmerlr -- command line of the MI355X build: `learn` and `loss` for --type=kmerLr|scoresLr, mirroring the
+// reference CLI for the hot path (kmerLr.go:79-175, kmerLr_learn.go:112-338, scoresLr_learn.go:106-286,
+// kmerLr_loss.go:32-106).  Host-side ingest (CSV tables, FASTA k-mer counts, transform fitting) feeds the
+// C ABI of libkmerlr_hip.so; all training arithmetic runs on the GPU.  There is no CPU fallback.
+//
+//   kmerlr [--type=kmerLr|scoresLr] [-v|-vv] [--device=N] learn [options] [<M> <N>] FG BG BASENAME
+//   kmerlr [--type=...] loss [--lambda=F] MODEL.json FG BG
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/kmerlr_driver.h"
+
+struct DataSet {                       // ScoresDataSet / KmerDataSet: fg rows first (labels true)
+  std::vector<int64_t> rowptr{0}, col;
+  std::vector<double> val;
+  std::vector<uint8_t> labels;
+  int64_t dim = 0;
+  std::vector<std::string> names;
+};
+
+[[noreturn]] static void die(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
+  fputc('\n', stderr);
+  exit(1);
+}
+
+static int g_verbose = 0;
+static void say(int level, const char* fmt, ...) {
+  if (g_verbose < level) return;
+  va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
+}
+
+// ---- scores tables: read_scores_table + convert_scores (scoresLr_data.go:56-145) ---------------------
+static void read_scores(const std::string& fn, bool header, uint8_t label, DataSet& d) {
+  say(1, "Reading scores from `%s'... ", fn.c_str());
+  std::ifstream f(fn);
+  if (!f) die("failed\ncannot open `%s'", fn.c_str());
+  std::string line;
+  bool need_header = header;
+  int64_t lineno = 0;
+  while (std::getline(f, line)) {
+    lineno++;
+    if (line.empty()) continue;
+    std::vector<std::string> fields;
+    { std::stringstream ss(line); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) fields.push_back(t); }
+    if (need_header) { if (d.names.empty()) d.names = fields; need_header = false; continue; }
+    if (d.dim == 0) d.dim = (int64_t)fields.size() + 1;
+    if ((int64_t)fields.size() + 1 != d.dim) die("failed\nError: data has variable number of features");
+    d.col.push_back(0); d.val.push_back(1.0);                      // bias
+    for (size_t j = 0; j < fields.size(); j++) {
+      char* end = nullptr;
+      std::string t = fields[j];
+      size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r");
+      t = a == std::string::npos ? "" : t.substr(a, b - a + 1);
+      const double v = strtod(t.c_str(), &end);
+      if (t.empty() || *end) die("failed\nparsing scores failed at line `%lld'", (long long)lineno);
+      d.col.push_back((int64_t)j + 1); d.val.push_back(v);         // every column stored, zeros included
+    }
+    d.rowptr.push_back((int64_t)d.col.size());
+    d.labels.push_back(label);
+  }
+  say(1, "done\n");
+}
+
+// ---- FASTA -> k-mer counts (host; SURVEY 8(f)1: the device version is a later row) --------------------
+// Column ids: for k = M..N in turn, the base-4 value of the k-mer (a=0,c=1,g=2,t=3), upper/lower case
+// folded, windows containing any other character skipped; --revcomp merges a k-mer with its reverse
+// complement (class id = the smaller of the two codes, classes renumbered densely per k); --binarize
+// stores 1 for every present class.  gonetics' own class order is not verifiable offline.
+struct KmerSpec { int M = 0, N = 0; bool revcomp = false, binarize = false; std::vector<std::vector<int64_t>> cls; std::vector<int64_t> base; int64_t m = 0; };
+
+static int64_t revcomp_code(int64_t c, int k) {
+  int64_t r = 0;
+  for (int i = 0; i < k; i++) { r = (r << 2) | (3 - (c & 3)); c >>= 2; }
+  return r;
+}
+
+static void kmer_prepare(KmerSpec& s, std::vector<std::string>* names) {
+  s.cls.clear(); s.base.clear(); s.m = 0;
+  static const char L[] = "acgt";
+  for (int k = s.M; k <= s.N; k++) {
+    const int64_t n = (int64_t)1 << (2 * k);
+    std::vector<int64_t> map((size_t)n, -1);
+    int64_t next = 0;
+    for (int64_t c = 0; c < n; c++) {
+      int64_t rep = c;
+      if (s.revcomp) rep = std::min(c, revcomp_code(c, k));
+      if (map[(size_t)rep] < 0) {
+        map[(size_t)rep] = next++;
+        if (names) {
+          std::string nm((size_t)k, 'a');
+          for (int i = 0; i < k; i++) nm[(size_t)(k - 1 - i)] = L[(rep >> (2 * i)) & 3];
+          if (s.revcomp && revcomp_code(rep, k) != rep) {
+            std::string rc((size_t)k, 'a'); const int64_t r2 = revcomp_code(rep, k);
+            for (int i = 0; i < k; i++) rc[(size_t)(k - 1 - i)] = L[(r2 >> (2 * i)) & 3];
+            nm += "|" + rc;
+          }
+          names->push_back(nm);
+        }
+      }
+      map[(size_t)c] = map[(size_t)rep];
+    }
+    s.base.push_back(s.m);
+    s.m += next;
+    s.cls.push_back(std::move(map));
+  }
+}
+
+static void read_fasta(const std::string& fn, const KmerSpec& s, uint8_t label, DataSet& d) {
+  say(1, "Reading sequences from `%s'... ", fn.c_str());
+  std::ifstream f(fn);
+  if (!f) die("failed\ncannot open `%s'", fn.c_str());
+  std::vector<std::string> seqs;
+  std::string line, cur; bool have = false;
+  while (std::getline(f, line)) {
+    if (!line.empty() && line[0] == '>') { if (have) seqs.push_back(cur); cur.clear(); have = true; continue; }
+    for (char c : line) if (!isspace((unsigned char)c)) cur.push_back(c);
+  }
+  if (have) seqs.push_back(cur);
+  say(1, "done\n");
+  d.dim = s.m + 1;
+  std::map<int64_t, double> cnt;
+  for (const std::string& q : seqs) {
+    cnt.clear();
+    for (int ki = 0; ki < (int)s.cls.size(); ki++) {
+      const int k = s.M + ki;
+      const int64_t mask = ((int64_t)1 << (2 * k)) - 1;
+      int64_t code = 0; int valid = 0;
+      for (size_t p = 0; p < q.size(); p++) {
+        int b;
+        switch (tolower((unsigned char)q[p])) { case 'a': b = 0; break; case 'c': b = 1; break; case 'g': b = 2; break; case 't': b = 3; break; default: b = -1; }
+        if (b < 0) { valid = 0; code = 0; continue; }
+        code = ((code << 2) | b) & mask; valid++;
+        if (valid >= k) cnt[s.base[(size_t)ki] + s.cls[(size_t)ki][(size_t)code]] += 1.0;
+      }
+    }
+    d.col.push_back(0); d.val.push_back(1.0);
+    for (auto& kv : cnt) { d.col.push_back(kv.first + 1); d.val.push_back(s.binarize ? 1.0 : kv.second); }
+    d.rowptr.push_back((int64_t)d.col.size());
+    d.labels.push_back(label);
+  }
+}
+
+// ---- TransformFull.Fit (kmerLr_transform.go:59-252), host side ---------------------------------------
+static void fit_transform(const std::string& kind_, const DataSet& d, std::vector<double>& scale, std::vector<double>& offset) {
+  std::string kind = kind_;
+  for (auto& c : kind) c = (char)tolower((unsigned char)c);
+  scale.clear(); offset.clear();
+  if (kind.empty() || kind == "none") return;
+  const int64_t n = (int64_t)d.labels.size(), dim = d.dim;
+  if (kind == "standardizer" || kind == "variance-scaler") {
+    if (kind == "standardizer") say(1, "WARNING: Standardizing data will result in dense data and slow down computations!\n");
+    offset.assign((size_t)dim, 0.0); scale.assign((size_t)dim, 0.0);
+    std::vector<int64_t> k((size_t)dim, 0);
+    for (int64_t i = 0; i < n; i++) for (int64_t a = d.rowptr[(size_t)i] + 1; a < d.rowptr[(size_t)i + 1]; a++) offset[(size_t)d.col[(size_t)a]] += d.val[(size_t)a];
+    for (int64_t j = 1; j < dim; j++) offset[(size_t)j] /= (double)n;
+    for (int64_t i = 0; i < n; i++) for (int64_t a = d.rowptr[(size_t)i] + 1; a < d.rowptr[(size_t)i + 1]; a++) {
+      const int64_t j = d.col[(size_t)a]; k[(size_t)j]++;
+      const double t = d.val[(size_t)a] - offset[(size_t)j]; scale[(size_t)j] += t * t;
+    }
+    for (int64_t j = 1; j < dim; j++) {
+      const double sj = scale[(size_t)j] + (double)(n - k[(size_t)j]) * offset[(size_t)j] * offset[(size_t)j];
+      scale[(size_t)j] = sj == 0.0 ? 1.0 : 1.0 / std::sqrt(sj / (double)(n - 1));
+    }
+    offset[0] = 0.0; scale[0] = 1.0;
+    if (kind == "variance-scaler") offset.clear();
+  } else if (kind == "max-abs-scaler" || kind == "mean-scaler") {
+    scale.assign((size_t)dim, 0.0);
+    for (int64_t i = 0; i < n; i++) for (int64_t a = d.rowptr[(size_t)i] + 1; a < d.rowptr[(size_t)i + 1]; a++) {
+      const int64_t j = d.col[(size_t)a];
+      if (kind == "max-abs-scaler") scale[(size_t)j] = std::max(scale[(size_t)j], std::fabs(d.val[(size_t)a]));
+      else scale[(size_t)j] += d.val[(size_t)a];
+    }
+    for (int64_t j = 1; j < dim; j++) scale[(size_t)j] = (kind == "max-abs-scaler" ? 1.0 : (double)n) / scale[(size_t)j];
+    scale[0] = 1.0;
+  } else die("invalid data transform");
+}
+
+// ---- tiny reader for the model JSON written by klr_estimator_save_model ---------------------------------
+static std::vector<double> json_numbers_after(const std::string& s, const std::string& key, size_t from, size_t* endpos) {
+  std::vector<double> out;
+  size_t p = s.find("\"" + key + "\"", from);
+  if (p == std::string::npos) die("invalid config file: missing %s", key.c_str());
+  p = s.find('[', p);
+  size_t e = p;
+  int depth = 0;
+  for (; e < s.size(); e++) { if (s[e] == '[') depth++; else if (s[e] == ']') { if (--depth == 0) break; } }
+  std::string body = s.substr(p + 1, e - p - 1);
+  for (auto& c : body) if (c == '[' || c == ']' || c == ',') c = ' ';
+  std::stringstream ss(body); double v;
+  while (ss >> v) out.push_back(v);
+  if (endpos) *endpos = e;
+  return out;
+}
+
+struct Options { std::map<std::string, std::string> kv; std::vector<std::string> pos; };
+static Options parse(int argc, char** argv, int from) {
+  Options o;
+  for (int i = from; i < argc; i++) {
+    std::string a = argv[i];
+    if (a.rfind("--", 0) == 0) {
+      size_t eq = a.find('=');
+      if (eq == std::string::npos) o.kv[a.substr(2)] = "true"; else o.kv[a.substr(2, eq - 2)] = a.substr(eq + 1);
+    } else if (a == "-v") g_verbose = std::max(g_verbose, 1);
+    else if (a == "-vv") g_verbose = 2;
+    else o.pos.push_back(a);
+  }
+  return o;
+}
+static std::string opt(const Options& o, const char* k, const char* def) { auto it = o.kv.find(k); return it == o.kv.end() ? def : it->second; }
+static bool flag(const Options& o, const char* k) { return o.kv.count(k) != 0; }
+
+int main(int argc, char** argv) {
+  std::string type = "kmerLr";
+  int device = 0;
+  int ci = 1;
+  for (; ci < argc; ci++) {
+    std::string a = argv[ci];
+    if (a.rfind("--type=", 0) == 0) type = a.substr(7);
+    else if (a.rfind("--device=", 0) == 0) device = atoi(a.c_str() + 9);
+    else if (a == "-v") g_verbose = std::max(g_verbose, 1);
+    else if (a == "-vv") g_verbose = 2;
+    else if (a.rfind("--threads", 0) == 0 || a.rfind("--seed", 0) == 0) continue;      // accepted, unused
+    else break;
+  }
+  if (ci >= argc) {
+    printf("usage: kmerlr [--type=kmerLr|scoresLr] [-v] [--device=N] <learn|loss> ...\n");
+    return 0;
+  }
+  const std::string cmd = argv[ci];
+  Options o = parse(argc, argv, ci + 1);
+  const bool scores = type == "scoresLr" || type == "scoreslr";
+  if (!scores && type != "kmerLr" && type != "kmerlr") die("invalid type `%s'", type.c_str());
+
+  klr_ctx* ctx = nullptr;
+  if (klr_ctx_create(device, &ctx) != KLR_OK) die("%s", klr_last_error(nullptr));
+  klr_backend be;
+  if (klr_hip_backend(ctx, &be) != KLR_OK) die("%s", klr_last_error(ctx));
+
+  if (cmd == "learn") {
+    klr_config cfg;
+    klr_config_default(&cfg);
+    cfg.lambda = strtod(opt(o, "lambda", "NaN").c_str(), nullptr);
+    std::vector<int64_t> la;
+    { std::stringstream ss(opt(o, "lambda-auto", "0")); std::string t; while (std::getline(ss, t, ',')) la.push_back(atoll(t.c_str())); }
+    std::sort(la.begin(), la.end());
+    if (!std::isnan(cfg.lambda) && !(la.size() == 1 && la[0] == 0)) die("options --lambda and --lambda-auto are incompatible");
+    cfg.max_features = atoll(opt(o, "max-features", "0").c_str());
+    cfg.max_epochs = atoll(opt(o, "max-epochs", "0").c_str());
+    cfg.max_iterations = atoll(opt(o, "max-iterations", "0").c_str());
+    cfg.epsilon = strtod(opt(o, "epsilon", "0").c_str(), nullptr);
+    cfg.epsilon_lambda = strtod(opt(o, "epsilon-lambda", "0").c_str(), nullptr);
+    cfg.epsilon_loss = strtod(opt(o, "epsilon-loss", "1e-8").c_str(), nullptr);
+    cfg.eval_loss = flag(o, "eval-loss") || cfg.epsilon_loss != 0.0;
+    cfg.balance = flag(o, "balance");
+    cfg.penalty_free = flag(o, "penalty-free");
+    cfg.save_trace = flag(o, "save-trace");
+    cfg.save_path = flag(o, "save-path");
+    cfg.verbose = g_verbose;
+    if (atoi(opt(o, "k-fold-cv", "1").c_str()) != 1 || atoi(opt(o, "ensemble-size", "1").c_str()) != 1)
+      die("--k-fold-cv / --ensemble-size are not part of this build (DESIGN.md, out of scope)");
+    if (flag(o, "co-occurrence")) die("--co-occurrence is not part of this build (DESIGN.md, out of scope)");
+
+    DataSet d;
+    std::string base;
+    KmerSpec ks;
+    if (scores) {
+      if (o.pos.size() != 3) die("usage: kmerlr --type=scoresLr learn [options] FG.table BG.table BASENAME");
+      read_scores(o.pos[0], flag(o, "header"), 1, d);
+      read_scores(o.pos[1], flag(o, "header"), 0, d);
+      base = o.pos[2];
+    } else {
+      if (o.pos.size() != 5) die("usage: kmerlr learn [options] M N FG.fa BG.fa BASENAME");
+      ks.M = atoi(o.pos[0].c_str()); ks.N = atoi(o.pos[1].c_str());
+      if (ks.M < 1 || ks.N < ks.M || ks.N > 12) die("invalid k-mer lengths");
+      ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+      kmer_prepare(ks, &d.names);
+      read_fasta(o.pos[2], ks, 1, d);
+      read_fasta(o.pos[3], ks, 0, d);
+      base = o.pos[4];
+    }
+    const int64_t n = (int64_t)d.labels.size();
+    if (n == 0) die("Error: no training data given");
+    std::vector<double> scale, offset;
+    fit_transform(opt(o, "data-transform", ""), d, scale, offset);
+
+    klr_mat* mat = nullptr;
+    if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+      die("%s", klr_last_error(ctx));
+    klr_estimator* est = nullptr;
+    if (klr_estimator_create(&be, &cfg, &est) != KLR_OK) die("cannot create estimator");
+    if (klr_estimator_estimate(est, mat, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
+                               offset.empty() ? nullptr : offset.data()) != KLR_OK)
+      die("%s", klr_estimator_error(est));
+    if (cfg.save_trace) {
+      const std::string fn = base + ".trace";
+      say(1, "Exporting trace to `%s'... ", fn.c_str());
+      if (klr_estimator_save_trace(est, fn.c_str()) != KLR_OK) die("failed");
+      say(1, "done\n");
+    }
+    if (cfg.save_path) {
+      const std::string fn = base + ".path";
+      say(1, "Exporting regularization path to `%s'... ", fn.c_str());
+      if (klr_estimator_save_path(est, fn.c_str()) != KLR_OK) die("failed");
+      say(1, "done\n");
+    }
+    std::vector<const char*> names;
+    for (auto& s : d.names) names.push_back(s.c_str());
+    const int64_t nc = klr_estimator_n_classifiers(est);
+    for (int64_t i = 0; i < nc; i++) {                                    // kmerLr_learn.go:60-66
+      char fn[4096];
+      if (nc == 1) snprintf(fn, sizeof(fn), "%s.json", base.c_str());
+      else snprintf(fn, sizeof(fn), "%s_%lld.json", base.c_str(), (long long)la[(size_t)i]);
+      say(1, "Exporting model to `%s'... ", fn);
+      if (klr_estimator_save_model(est, i, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data()) != KLR_OK) die("failed");
+      say(1, "done\n");
+    }
+    klr_estimator_destroy(est);
+    klr_mat_destroy(mat);
+  } else if (cmd == "loss") {
+    if (o.pos.size() != 3) die("usage: kmerlr loss [--lambda=F] MODEL.json FG BG");
+    std::ifstream jf(o.pos[0]);
+    if (!jf) die("cannot open `%s'", o.pos[0].c_str());
+    std::stringstream buf; buf << jf.rdbuf();
+    const std::string js = buf.str();
+    size_t pos = 0;
+    std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
+    size_t dpos = js.find("\"Distributions\"");
+    std::vector<double> theta = json_numbers_after(js, "Parameters", dpos, &pos);
+    std::vector<double> offset = json_numbers_after(js, "Offset", pos, nullptr);
+    std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
+    if (theta.size() != index.size() + 1) die("invalid config file");
+    DataSet d;
+    if (scores) { read_scores(o.pos[1], flag(o, "header"), 1, d); read_scores(o.pos[2], flag(o, "header"), 0, d); }
+    else {
+      KmerSpec ks;
+      ks.M = atoi(opt(o, "m", "0").c_str()); ks.N = atoi(opt(o, "n", "0").c_str());
+      if (ks.M < 1) die("kmerlr loss --type=kmerLr needs --m=M --n=N (the k-mer lengths the model was trained with)");
+      ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+      kmer_prepare(ks, nullptr);
+      read_fasta(o.pos[1], ks, 1, d); read_fasta(o.pos[2], ks, 0, d);
+    }
+    const int64_t n = (int64_t)d.labels.size();
+    klr_mat *mat = nullptr, *red = nullptr;
+    if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+      die("%s", klr_last_error(ctx));
+    std::vector<int64_t> cols{0};
+    for (double v : index) cols.push_back((int64_t)v + 1);
+    if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
+                               offset.empty() ? nullptr : offset.data(), &red) != KLR_OK)
+      die("%s", klr_last_error(ctx));
+    const double cw[2] = {1.0, 1.0};
+    double out = 0.0;
+    if (klr_loss(ctx, red, theta.data(), cw, strtod(opt(o, "lambda", "NaN").c_str(), nullptr), &out) != KLR_OK) die("%s", klr_last_error(ctx));
+    printf("%15e\n", out);                                              // saveLoss, kmerLr_loss.go:48
+    klr_mat_destroy(red); klr_mat_destroy(mat);
+  } else {
+    die("unknown command `%s' (this build provides learn and loss)", cmd.c_str());
+  }
+  klr_ctx_destroy(ctx);
+  return 0;
+}

@@ -119,7 +119,7 @@ struct CdArgs {
   int g_in_lds;
 };
 
-// One workgroup.  LDS: theta[d], q[d], diag[d], xyv[d] (+ G[d*d] when it fits).
+// One workgroup.  LDS: theta[d], q[d], diag[d], xyv[d] (+ G[d*d] when it fits); up to d = 4900.
 __global__ __launch_bounds__(CD_THREADS) void k_cd_sweeps(CdArgs a) {
   extern __shared__ double lds[];
   const int d = a.d, tid = threadIdx.x;

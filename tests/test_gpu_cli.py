@@ -1,0 +1,97 @@
+"""GPU: the `kmerlr` command line (learn / loss) against the reference's README transcript and, for the
+bundled FASTA files (BASELINE configs[1]: k=4, --lambda-auto=10), against the oracle-served driver on
+the same counts."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import oracle_driver as OD
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "kmerlr_amd", "_lib", "kmerlr")
+
+
+def run(args, cwd):
+    r = subprocess.run([CLI] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def test_scores_learn_transcript_and_loss(tmp_path):
+    fg, bg = os.path.join(GOLDEN, "scoresLr_test_fg.table"), os.path.join(GOLDEN, "scoresLr_test_bg.table")
+    r = run(["-v", "--type=scoresLr", "learn", "--lambda-auto=2", "--save-trace", "--save-path", fg, bg, "test"], tmp_path)
+    lines = r.stderr.splitlines()
+    # README.md:35-44
+    assert lines[0] == "Reading scores from `%s'... done" % fg
+    assert "Estimating classifier with 2 non-zero coefficients..." in lines
+    assert "Estimating parameters with lambda=2.496875e+00..." in lines
+    assert "Estimated classifier has 2 non-zero coefficients, selecting 0 new features..." in lines
+    assert "Exporting trace to `test.trace'... done" in lines
+    assert "Exporting model to `test.json'... done" in lines
+    m = json.load(open(tmp_path / "test.json"))
+    assert m["Parameters"]["Index"] == [1, 6]                       # scoresLr_test.go:53-58
+    theta = m["Distributions"][0]["Parameters"]
+    np.testing.assert_allclose(theta, [0.842178566751775, -0.05466291047449, -0.03026279836545], rtol=2e-2)
+    out = run(["--type=scoresLr", "loss", "--lambda=4.647556", "test.json", fg, bg], tmp_path).stdout
+    assert len(out) == 16 and out.endswith("\n")                     # "%15e\n", kmerLr_loss.go:48
+    _, xf = O.read_scores_table(fg); _, xb = O.read_scores_table(bg)
+    x = O.Csr.from_dense(np.concatenate([xf, xb])); labels = np.array([1] * 8 + [0] * 8, dtype=np.uint8)
+    ref = O.loss(O.select_columns(x, [0, 2, 7]), labels, theta, lam=4.647556)
+    assert abs(float(out) - ref) < 1e-6 * ref
+
+
+def count_kmers(path, k):
+    seqs, cur = [], None
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur is not None:
+                seqs.append(cur)
+            cur = ""
+        elif cur is not None:
+            cur += line
+    if cur is not None:
+        seqs.append(cur)
+    code = {"a": 0, "c": 1, "g": 2, "t": 3}
+    rows = []
+    for s in seqs:
+        c = np.zeros(4 ** k)
+        s = s.lower()
+        for p in range(len(s) - k + 1):
+            w = s[p:p + k]
+            if all(ch in code for ch in w):
+                v = 0
+                for ch in w:
+                    v = v * 4 + code[ch]
+                c[v] += 1
+        rows.append(c)
+    return np.array(rows)
+
+
+def test_kmers_learn_config1_matches_oracle_driver(tmp_path):
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
+    run(["-v", "learn", "--lambda-auto=10", "--save-path", "4", "4", fg, bg, "km"], tmp_path)
+    m = json.load(open(tmp_path / "km.json"))
+    assert m["Name"] == "kmerLr" and len(m["Parameters"]["Index"]) == 10
+    cf, cb = count_kmers(fg, 4), count_kmers(bg, 4)
+    assert cf.shape == (11, 256) and cb.shape == (11, 256)
+    dense = np.concatenate([cf, cb])
+    # sparse rows like convert_counts (kmerLr_data.go:197-235): zero counts are not stored
+    rowptr, col, val = [0], [], []
+    for r in dense:
+        nzc = np.nonzero(r)[0]
+        col += [0] + list(nzc + 1); val += [1.0] + list(r[nzc]); rowptr.append(len(col))
+    x = O.Csr(22, 257, rowptr, col, val); labels = np.array([1] * 11 + [0] * 11, dtype=np.uint8)
+    h = OD.matrix(x, labels)
+    c = OD.estimator().estimate(h, [10])[0]
+    OD.free_matrix(h)
+    assert m["Parameters"]["Index"] == list(c["cols"][1:] - 1)       # identical selected k-mers
+    np.testing.assert_allclose(m["Distributions"][0]["Parameters"], c["theta"], rtol=1e-6, atol=1e-10)
+    assert m["Parameters"]["Names"][0] == "acgt"[(c["cols"][1] - 1) // 64] + "acgt"[(c["cols"][1] - 1) // 16 % 4] + \
+        "acgt"[(c["cols"][1] - 1) // 4 % 4] + "acgt"[(c["cols"][1] - 1) % 4]
