@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-baseline-rows", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cd-sweeps", type=int, default=200, help="reduced-problem CD sweeps timed for cd_sweeps_per_s")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="set up the process group and the library's RCCL communicator even for one rank (plumbing check)")
     return ap.parse_args()
 
 
@@ -57,15 +59,18 @@ def main():
                              % (args.gpus, args.gpus))
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = world > 1 or args.force_comm
+    if comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n_local, m, draws, N = args.rows_per_gpu, args.features, args.draws, args.lambda_auto
     n_total = n_local * world
     S = 2 * N
 
     ctx = K.Context(local_rank)
-    if world > 1:
+    if comm:
         # RCCL communicator owned by the library: one all-reduce per sweep on the library's stream
         ids = [K.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -98,8 +103,9 @@ def main():
         step()
     ctx.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if comm:
         dist.barrier()
+        torch.cuda.synchronize()
     ctx.prof_enable(True)
     ctx.prof_read(reset=True)
     t0 = time.perf_counter()
@@ -107,8 +113,9 @@ def main():
         out = step()
     ctx.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if comm:
         dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     launches, kern_ms = ctx.prof_read(reset=True)
     ctx.prof_enable(False)
@@ -180,10 +187,12 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "ingest_upload": round(t_up, 2)},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if comm:
         dist.barrier()
-        dist.destroy_process_group()
+    full.close(); red.close()
     ctx.close()
+    if comm:
+        dist.destroy_process_group()
 
 
 def cpu_baseline_leg(args, theta, cols, cw):

@@ -135,7 +135,7 @@ extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* us
 }
 
 int klr_allreduce(klr_ctx* ctx, void* dev, i64 count, int dtype) {
-  if (!ctx->ar_fn || ctx->nranks <= 1) return KLR_OK;
+  if (!ctx->ar_fn) return KLR_OK;      // a hook installed for a single rank still runs (RCCL: in-place no-op)
   int rc = ctx->ar_fn(ctx->ar_user, dev, count, dtype, (void*)ctx->stream);
   if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "all-reduce hook failed (%d) on %lld elements", rc, (long long)count);
   return KLR_OK;

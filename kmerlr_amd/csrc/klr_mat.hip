@@ -354,7 +354,7 @@ extern "C" int klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2])
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, mat != nullptr && cw != nullptr);
   double cnts[2] = {(double)(mat->n - mat->n1_local), (double)mat->n1_local};
-  if (ctx->ar_fn && ctx->nranks > 1) {
+  if (ctx->ar_fn) {
     double* d;
     KLR_TRY(ws_get(ctx, WS_G, 2 * sizeof(double), (void**)&d));
     KLR_TRY(h2d(ctx, d, cnts, sizeof(cnts)));

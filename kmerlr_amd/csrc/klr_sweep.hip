@@ -464,7 +464,7 @@ int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double
   klr_mat* mm = const_cast<klr_mat*>(mat);
   if (mm->col_abs_max_global < 0.0) {
     double a = mat->col_abs_max;
-    if (ctx->ar_fn && ctx->nranks > 1) {
+    if (ctx->ar_fn) {
       double* t;
       KLR_TRY(ws_get(ctx, WS_BLK, 64, (void**)&t));
       KLR_TRY(h2d(ctx, t, &a, sizeof(double)));
