@@ -138,9 +138,9 @@ def main():
     lay = full.layout()
     if lay["tiled"]:
         # single pass over the 2-D tiled packed COO stream: 4 B per stored entry ((count:8|col:12|row:12),
-        # padding included); per (tile, workgroup) piece one 32 KiB tile of int64 s read and one 32 KiB
-        # vector of int64 column sums written
-        alg_bytes = 4.0 * lay["padded_entries"] + lay["nseg"] * 2.0 * 4096 * 8
+        # padding included), one 32 KiB vector of int64 column sums written per (tile, workgroup) piece,
+        # s read once (the per-piece s tiles are L2 hits and not counted)
+        alg_bytes = 4.0 * lay["padded_entries"] + lay["nseg"] * 4096.0 * 8 + 8.0 * n_local
         kname = "k_sweep_coo"
     else:
         # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column

@@ -277,7 +277,9 @@ static void xt_s_group(int g, dim3 grid, hipStream_t st, const klr_mat* m, const
 // kernel at ~20 % of HBM peak (profiles/r01_plain_csc.md).  Here both vectors the sweep touches at
 // random live in LDS: the matrix is cut into 4096 x 4096 tiles, a workgroup holds the tile's 4096
 // s values and 4096 column accumulators (32 KiB each), and the ONLY HBM stream is the packed entry
-// array, 4 bytes per stored nonzero, read with 16-byte loads, four per lane in flight.
+// array, 4 bytes per stored nonzero, read with non-temporal 16-byte loads.  Occupancy, not unrolling, hides
+// the HBM latency: 1024-thread workgroups, two per CU (32 waves/CU), one load per lane per iteration
+// measured 10 % faster than 512 threads x 4 loads and 30 % faster than x 8 (tools/ab_sweep.py).
 //
 // Accumulation is exact: s is converted to int64 fixed point (scale 2^E chosen from max|s| and the
 // largest column sum so that no column sum can overflow), products are integer, and the column
@@ -285,55 +287,118 @@ static void xt_s_group(int g, dim3 grid, hipStream_t st, const klr_mat* m, const
 // depend on lane scheduling, on how the stream is cut into pieces, or on the number of GPUs (the
 // cross-GPU all-reduce is int64 too): the gradient is bitwise reproducible and partition invariant.
 // ---------------------------------------------------------------------------------------------
-#define COO_THREADS 512
-#define COO_UNROLL 4
-
 __device__ __forceinline__ void coo_consume(const u32 w, const i64* __restrict__ sS, unsigned long long* __restrict__ sG) {
   const u32 row = w & (TILE_DIM - 1), col = (w >> TILE_BITS) & (TILE_DIM - 1), v = w >> 24;
   const unsigned long long prod = (unsigned long long)sS[row] * (unsigned long long)v;   // mod 2^64 == two's complement
   atomicAdd(&sG[col], prod);
 }
+// timing-only ablations (tools/ab_sweep.py): results are wrong by construction
+template <int ABL>
+__device__ __forceinline__ void coo_consume_abl(const u32 w, const i64* __restrict__ sS, unsigned long long* __restrict__ sG,
+                                                unsigned long long& sink) {
+  const u32 row = w & (TILE_DIM - 1), col = (w >> TILE_BITS) & (TILE_DIM - 1), v = w >> 24;
+  if (ABL == 1) { sink += (unsigned long long)sS[row] * (unsigned long long)v + col; }            // no atomics
+  else { atomicAdd(&sG[col], (unsigned long long)(v + row)); }                                    // no s gather
+}
 
-__global__ __launch_bounds__(COO_THREADS) void k_sweep_coo(const uint4* __restrict__ ent4, const uint4* __restrict__ piece,
-                                                           const u32* __restrict__ wgpiece, u32 nct, i64 n,
-                                                           const i64* __restrict__ S, i64* __restrict__ part) {
+template <int THREADS, int UNROLL, bool NT, int ABL = 0>
+__global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__ ent4, const uint4* __restrict__ piece,
+                                                       const u32* __restrict__ wgpiece, u32 nct, i64 n,
+                                                       const i64* __restrict__ S, i64* __restrict__ part) {
   extern __shared__ unsigned long long coo_lds[];
   i64* sS = (i64*)coo_lds;
   unsigned long long* sG = coo_lds + TILE_DIM;
   const u32 tid = threadIdx.x;
   const u32 p0 = wgpiece[blockIdx.x], p1 = wgpiece[blockIdx.x + 1];
   u32 cur_rt = 0xFFFFFFFFu;
+  unsigned long long sink = 0ull;
   for (u32 p = p0; p < p1; p++) {
     const uint4 d = piece[p];
     const u32 rt = d.x / nct, q0 = d.y, q1 = d.z;
     __syncthreads();                                   // previous piece written out
     if (rt != cur_rt) {
       const i64 r0 = (i64)rt * TILE_DIM;
-      for (u32 i = tid; i < TILE_DIM; i += COO_THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
+      for (u32 i = tid; i < TILE_DIM; i += THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
       cur_rt = rt;
     }
-    for (u32 i = tid; i < TILE_DIM; i += COO_THREADS) sG[i] = 0ull;
+    for (u32 i = tid; i < TILE_DIM; i += THREADS) sG[i] = 0ull;
     __syncthreads();
-    for (u32 q = q0 + tid; q < q1; q += COO_THREADS * COO_UNROLL) {
-      uint4 e[COO_UNROLL];
+    for (u32 q = q0 + tid; q < q1; q += THREADS * UNROLL) {
+      uint4 e[UNROLL];
 #pragma unroll
-      for (int u = 0; u < COO_UNROLL; u++) {
-        const u32 qq = q + u * COO_THREADS;
-        e[u] = qq < q1 ? ent4[qq] : make_uint4(0u, 0u, 0u, 0u);
+      for (int u = 0; u < UNROLL; u++) {
+        const u32 qq = q + u * THREADS;
+        if (qq < q1) {
+          if (NT) {
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ent4) + qq);
+            e[u] = make_uint4(t.x, t.y, t.z, t.w);
+          } else e[u] = ent4[qq];
+        } else e[u] = make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
-      for (int u = 0; u < COO_UNROLL; u++) {
-        coo_consume(e[u].x, sS, sG);
-        coo_consume(e[u].y, sS, sG);
-        coo_consume(e[u].z, sS, sG);
-        coo_consume(e[u].w, sS, sG);
+      for (int u = 0; u < UNROLL; u++) {
+        if (ABL == 0) {
+          coo_consume(e[u].x, sS, sG);
+          coo_consume(e[u].y, sS, sG);
+          coo_consume(e[u].z, sS, sG);
+          coo_consume(e[u].w, sS, sG);
+        } else {
+          coo_consume_abl<ABL>(e[u].x, sS, sG, sink);
+          coo_consume_abl<ABL>(e[u].y, sS, sG, sink);
+          coo_consume_abl<ABL>(e[u].z, sS, sG, sink);
+          coo_consume_abl<ABL>(e[u].w, sS, sG, sink);
+        }
       }
     }
+    if (ABL == 1) sG[tid] += sink;
     __syncthreads();
     i64* out = part + (i64)p * TILE_DIM;
-    for (u32 i = tid; i < TILE_DIM; i += COO_THREADS) out[i] = (i64)sG[i];
+    for (u32 i = tid; i < TILE_DIM; i += THREADS) {
+      if (NT) __builtin_nontemporal_store((i64)sG[i], out + i);
+      else out[i] = (i64)sG[i];
+    }
   }
 }
+
+template <int THREADS, int UNROLL, bool NT, int ABL = 0>
+static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part) {
+  const size_t lds_bytes = (size_t)TILE_DIM * 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL>), dim3(mat->nwg), dim3(THREADS), lds_bytes, ctx->stream, (const uint4*)mat->t_ent,
+                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->nct, mat->n, S, part);
+  return KLR_OK;
+}
+
+// variant switch for in-process A/B timing (tools/ab_sweep.py); 0 = the shipped configuration
+static int g_coo_variant = -1;
+static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part) {
+  if (g_coo_variant < 0) { const char* e = getenv("KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
+  switch (g_coo_variant) {
+    case 1:  return launch_sweep_coo<512, 4, true>(ctx, mat, S, part);
+    case 2:  return launch_sweep_coo<512, 8, false>(ctx, mat, S, part);
+    case 3:  return launch_sweep_coo<512, 8, true>(ctx, mat, S, part);
+    case 4:  return launch_sweep_coo<1024, 4, false>(ctx, mat, S, part);
+    case 5:  return launch_sweep_coo<1024, 4, true>(ctx, mat, S, part);
+    case 6:  return launch_sweep_coo<1024, 2, false>(ctx, mat, S, part);
+    case 7:  return launch_sweep_coo<256, 8, false>(ctx, mat, S, part);
+    case 8:  return launch_sweep_coo<512, 4, true, 1>(ctx, mat, S, part);     // ablation: no atomics
+    case 9:  return launch_sweep_coo<512, 4, true, 2>(ctx, mat, S, part);     // ablation: no s gather
+    case 10: return launch_sweep_coo<512, 2, true>(ctx, mat, S, part);
+    case 11: return launch_sweep_coo<1024, 2, true>(ctx, mat, S, part);
+    case 12: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part);
+    case 13: return launch_sweep_coo<512, 1, true>(ctx, mat, S, part);
+    case 14: return launch_sweep_coo<1024, 1, false>(ctx, mat, S, part);
+    case 15: return launch_sweep_coo<768, 1, true>(ctx, mat, S, part);
+    case 16: return launch_sweep_coo<512, 4, false>(ctx, mat, S, part);
+    default: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part);      // shipped: 32 waves/CU, nt loads
+  }
+}
+extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
 
 // ibuf layout (int64): [0, dim) column sums (slot 0 unused) | dim: bias hi | dim+1: bias lo |
 //                      dim+2: loss limb0 | dim+3: loss limb1 | dim+4: non-finite loss terms
@@ -493,20 +558,13 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
   KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
   KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * TILE_DIM * 8, (void**)&part));
-  const size_t lds = (size_t)TILE_DIM * 16;
-  static bool attr = false;
-  if (!attr) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof_on) {
     KLR_HIP(ctx, hipEventCreate(&e0));
     KLR_HIP(ctx, hipEventCreate(&e1));
     KLR_HIP(ctx, hipEventRecord(e0, st));
   }
-  hipLaunchKernelGGL(k_sweep_coo, dim3(mat->nwg), dim3(COO_THREADS), lds, st, (const uint4*)mat->t_ent,
-                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->nct, n, S, part);
+  KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part));
   if (ctx->prof_on) {
     KLR_HIP(ctx, hipEventRecord(e1, st));
     ctx->prof_ev.emplace_back(e0, e1);

@@ -1,0 +1,35 @@
+"""In-process interleaved A/B timing of the sweep-kernel variants (dev tool; GPU only).
+usage: python tools/ab_sweep.py [rounds]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kmerlr_amd as K  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 5, 6, 7]
+n, m, draws, N = 100000, 65536, 993, 100
+ctx = K.Context(0)
+rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
+full = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
+cw = full.class_weights()
+L = K.lib()
+L.klr_debug_set_coo_variant.argtypes = [C.c_int]
+res = {v: [] for v in variants}
+ctx.prof_enable(True)
+for r in range(rounds + 1):
+    for v in variants:
+        L.klr_debug_set_coo_variant(v)
+        ctx.prof_read(reset=True)
+        for _ in range(5):
+            K.sweep_select(ctx, full, None, None, np.zeros(1), cw, N)
+        nl, ms = ctx.prof_read(reset=True)
+        if r > 0:
+            res[v].append(ms / nl * 1e3)
+names = {14: "1024x1", 15: "768x1 nt", 8: "no-atomic", 9: "no-gather", 10: "512x2 nt", 11: "1024x2 nt", 12: "1024x1 nt", 13: "512x1 nt", 0: "512x4", 1: "512x4 nt", 2: "512x8", 3: "512x8 nt", 4: "1024x4", 5: "1024x4 nt", 6: "1024x2", 7: "256x8"}
+for v in variants:
+    a = np.array(res[v])
+    print("variant %d %-10s median %7.2f us  min %7.2f us" % (v, names.get(v, "?"), np.median(a), a.min()))
