@@ -90,14 +90,15 @@ struct klr_mat {
   //      tile (rt, ct) = rows [rt*4096, +4096) x columns [ct*4096, +4096); entries row-major inside a
   //      tile; entry = (count:8 << 24) | (col-in-tile:12 << 12) | row-in-tile:12   (4 B per stored nonzero;
   //      counts > 255 are split, the bias column is not stored)
-  bool tiled = false;
+  bool tiled = false, rt_major = false;
   u32  nrt = 0, nct = 0, nwg = 0, npiece = 0;
   i64  total4 = 0;               // quads (4 entries) incl. per-tile padding
   i64  stored_entries = 0;       // entries before padding
   double col_abs_max = 0.0;      // max over non-bias columns of sum_i |x_ij| (local rows)
   double col_abs_max_global = -1.0;   // bound over all ranks (lazily all-reduced)
   u32* t_ent = nullptr;          // total4*4 packed entries
-  u32* t_piece = nullptr;        // npiece * 4: {tile id, quad begin, quad end, unused}
+  u32* t_piece = nullptr;        // npiece * 4: {column tile, quad begin, quad end, first tile index}
+  u32* t_tileq = nullptr;        // ntile+1 quad offsets of the tiles (column-tile major: tile = ct*nrt + rt)
   u32* t_wgpiece = nullptr;      // nwg+1: pieces of workgroup w
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile

@@ -25,7 +25,7 @@ void mat_free(klr_mat* m) {
   (void)hipDeviceSynchronize();
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
                 m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->t_ent, m->t_piece, m->t_wgpiece,
-                m->t_ctptr, m->t_ctlist};
+                m->t_ctptr, m->t_ctlist, m->t_tileq};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete m;
 }
@@ -94,13 +94,15 @@ int mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat) {
 // 2-D tiled packed COO stream for the full-width sweep.  Built when every value is a non-negative
 // integer (k-mer counts) and the matrix is large enough for the sweep to be bandwidth bound;
 // otherwise the plain CSC kernel is used.
-//   tile (rt, ct): rows [rt*4096, +4096) x columns [ct*4096, +4096), tile id = rt*nct + ct
+//   tile (rt, ct): rows [rt*4096, +4096) x columns [ct*4096, +4096); tiles are stored COLUMN-TILE major
+//            (tile id = ct*nrt + rt) so a workgroup walks down one column tile, reloading only the s tile,
+//            and writes its 4096 column sums once per column tile it touches
 //   entry  = (count:8 << 24) | (col & 4095) << 12 | (row & 4095); counts > 255 are split into several
 //            entries (the sweep is additive); column 0 (bias, all ones) is not stored
 //   order  = row-major inside a tile (so consecutive entries share the row -> LDS broadcast reads of s
 //            and distinct columns -> few same-address LDS atomics); every tile padded to 4 entries
-//   pieces = the entry stream cut into nwg equal parts (one per workgroup), each part cut at tile
-//            boundaries; a piece produces one 4096-wide int64 partial column-sum vector
+//   pieces = the entry stream cut into nwg equal parts (one per workgroup), each part cut where the
+//            column tile changes; a piece produces one 4096-wide int64 partial column-sum vector
 // =================================================================================================
 static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* col, const double* val) {
   const i64 n = m->n, dim = m->dim;
@@ -108,6 +110,16 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   const i64 nrt = ceil_div(n, (i64)TILE_DIM), nct = ceil_div(dim, (i64)TILE_DIM);
   const i64 ntile = nrt * nct;
   if (ntile >= (i64)1 << 31) return KLR_OK;
+  // Tile order.  Row-tile major: a workgroup crossing a tile boundary keeps its s tile and starts a new
+  // 4096-wide output vector (one 32 KiB write per tile).  Column-tile major: it keeps the output vector and
+  // reloads the s tile (32 KiB from L2, no HBM traffic).  Dense tiles (>= 32k entries, e.g. 100k x 65k k-mer
+  // counts) amortise the writes and run fastest row-tile major; sparse tiles (1M columns) are dominated by the
+  // per-tile writes and run column-tile major (measured: profiles/README.md).  KLR_TILE_ORDER=rt|ct overrides.
+  const char* ord = getenv("KLR_TILE_ORDER");
+  bool rt_major = (double)m->nnz / (double)ntile >= 32768.0;
+  if (ord && ord[0] == 'r') rt_major = true;
+  if (ord && ord[0] == 'c') rt_major = false;
+  auto tix = [&](i64 rt, i64 ct) -> i64 { return rt_major ? rt * nct + ct : ct * nrt + rt; };
   int T = (int)std::min<i64>(std::max<unsigned>(1u, std::min(8u, std::thread::hardware_concurrency())), nrt);
   std::vector<int> bad(T, 0);
   std::vector<u64> tlen((size_t)ntile, 0);           // entries per tile (after splitting)
@@ -116,7 +128,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
       for (i64 rt = t; rt < nrt; rt += T) {
-        u64* l = tlen.data() + (size_t)rt * nct;
+        u64* l = tlen.data();
         const i64 r0 = rt * TILE_DIM, r1 = std::min<i64>(n, r0 + TILE_DIM);
         for (i64 a = rowptr[r0]; a < rowptr[r1]; a++) {
           const double v = val[a];
@@ -124,7 +136,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
           const i64 c = col[a];
           if (c == 0) continue;
           const u32 iv = (u32)v;
-          l[c >> TILE_BITS] += (iv + 254u) / 255u;       // 0 -> no entry
+          l[(size_t)tix(rt, c >> TILE_BITS)] += (iv + 254u) / 255u;       // 0 -> no entry
           colsum[t][(size_t)c] += v;
         }
       }
@@ -147,7 +159,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
       std::vector<u64> cur((size_t)nct);
       for (i64 rt = t; rt < nrt; rt += T) {
-        for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)(rt * nct + ct)] * 4;
+        for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)tix(rt, ct)] * 4;
         const i64 r0 = rt * TILE_DIM, r1 = std::min<i64>(n, r0 + TILE_DIM);
         for (i64 i = r0; i < r1; i++)
           for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
@@ -162,9 +174,9 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
     });
     for (auto& x : th) x.join();
   }
-  // pieces: equal parts of the quad stream, cut at tile boundaries
+  // pieces: equal parts of the quad stream, cut where the column tile changes
   const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
-  std::vector<u32> piece; piece.reserve((size_t)(nwg + ntile) * 4);
+  std::vector<u32> piece; piece.reserve((size_t)(nwg + nct) * 4);
   std::vector<u32> wgp((size_t)nwg + 1);
   {
     i64 tile = 0;
@@ -174,8 +186,12 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
       u64 q = q0;
       while (q < q1) {
         while (toff4[(size_t)tile + 1] <= q) tile++;
-        const u64 e = std::min<u64>(q1, toff4[(size_t)tile + 1]);
-        piece.push_back((u32)tile); piece.push_back((u32)q); piece.push_back((u32)e); piece.push_back(0u);
+        const i64 ct = rt_major ? tile % nct : tile / nrt;
+        // a piece ends where the column tile changes: the next tile (row-tile major) or the end of the
+        // column strip (column-tile major)
+        const u64 ct_end = rt_major ? toff4[(size_t)tile + 1] : toff4[(size_t)((ct + 1) * nrt)];
+        const u64 e = std::min<u64>(q1, ct_end);
+        piece.push_back((u32)ct); piece.push_back((u32)q); piece.push_back((u32)e); piece.push_back((u32)tile);
         q = e;
       }
     }
@@ -183,23 +199,30 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   }
   const u32 npiece = (u32)(piece.size() / 4);
   std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(npiece);
-  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)(piece[(size_t)p * 4] % nct) + 1]++;
+  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
   for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
   {
     std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
-    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)(piece[(size_t)p * 4] % nct)]++] = p;
+    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
   }
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)total4 * 16));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)npiece * 16));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, ((size_t)nwg + 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_tileq, ((size_t)ntile + 2) * 4));
+  {
+    std::vector<u32> tq((size_t)ntile + 2);
+    for (i64 t = 0; t <= ntile; t++) tq[(size_t)t] = (u32)toff4[(size_t)t];
+    tq[(size_t)ntile + 1] = (u32)total4;                 // sentinel: the kernel reads tileq[t+1] before it stops
+    KLR_HIP(ctx, hipMemcpy(m->t_tileq, tq.data(), ((size_t)ntile + 2) * 4, hipMemcpyHostToDevice));
+  }
   KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * 16, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, wgp.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
-  m->tiled = true; m->nrt = (u32)nrt; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
+  m->rt_major = rt_major; m->tiled = true; m->nrt = (u32)nrt; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
   m->total4 = total4; m->stored_entries = (i64)stored; m->col_abs_max = amax;
   return KLR_OK;
 }

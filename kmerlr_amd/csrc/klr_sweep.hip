@@ -303,51 +303,66 @@ __device__ __forceinline__ void coo_consume_abl(const u32 w, const i64* __restri
 
 template <int THREADS, int UNROLL, bool NT, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__ ent4, const uint4* __restrict__ piece,
-                                                       const u32* __restrict__ wgpiece, u32 nct, i64 n,
-                                                       const i64* __restrict__ S, i64* __restrict__ part) {
+                                                       const u32* __restrict__ wgpiece, const u32* __restrict__ tileq,
+                                                       u32 nrt, u32 nct_or0, i64 n, const i64* __restrict__ S,
+                                                       i64* __restrict__ part) {
   extern __shared__ unsigned long long coo_lds[];
   i64* sS = (i64*)coo_lds;
   unsigned long long* sG = coo_lds + TILE_DIM;
   const u32 tid = threadIdx.x;
   const u32 p0 = wgpiece[blockIdx.x], p1 = wgpiece[blockIdx.x + 1];
-  u32 cur_rt = 0xFFFFFFFFu;
   unsigned long long sink = 0ull;
+  u32 cur_rt = 0xFFFFFFFFu;
   for (u32 p = p0; p < p1; p++) {
-    const uint4 d = piece[p];
-    const u32 rt = d.x / nct, q0 = d.y, q1 = d.z;
-    __syncthreads();                                   // previous piece written out
-    if (rt != cur_rt) {
-      const i64 r0 = (i64)rt * TILE_DIM;
-      for (u32 i = tid; i < TILE_DIM; i += THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
-      cur_rt = rt;
-    }
+    const uint4 d = piece[p];                           // {column tile, quad begin, quad end, first tile}
+    const u32 pq0 = d.y, pq1 = d.z;
+    __syncthreads();                                    // previous piece written out
     for (u32 i = tid; i < TILE_DIM; i += THREADS) sG[i] = 0ull;
-    __syncthreads();
-    for (u32 q = q0 + tid; q < q1; q += THREADS * UNROLL) {
-      uint4 e[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-        const u32 qq = q + u * THREADS;
-        if (qq < q1) {
-          if (NT) {
-            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ent4) + qq);
-            e[u] = make_uint4(t.x, t.y, t.z, t.w);
-          } else e[u] = ent4[qq];
-        } else e[u] = make_uint4(0u, 0u, 0u, 0u);
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-        if (ABL == 0) {
-          coo_consume(e[u].x, sS, sG);
-          coo_consume(e[u].y, sS, sG);
-          coo_consume(e[u].z, sS, sG);
-          coo_consume(e[u].w, sS, sG);
+    // walk down the column tile: one s tile per row tile
+    for (u32 t = d.w; ; t++) {
+      const u32 tq0 = tileq[t], tq1 = tileq[t + 1];
+      if (tq0 >= pq1) break;
+      const u32 q0 = max(pq0, tq0), q1 = min(pq1, tq1);
+      if (q0 >= q1) continue;                           // empty tile
+      const u32 rt = nct_or0 ? t / nct_or0 : t % nrt;   // row-tile major / column-tile major
+      if (rt != cur_rt) {
+        const i64 r0 = (i64)rt * TILE_DIM;
+        __syncthreads();                                // the previous s tile is no longer read
+        if (r0 + TILE_DIM <= n) {                       // full tile: 16-byte loads
+          const longlong2* src = reinterpret_cast<const longlong2*>(S + r0);
+          for (u32 i = tid; i < TILE_DIM / 2; i += THREADS) reinterpret_cast<longlong2*>(sS)[i] = src[i];
         } else {
-          coo_consume_abl<ABL>(e[u].x, sS, sG, sink);
-          coo_consume_abl<ABL>(e[u].y, sS, sG, sink);
-          coo_consume_abl<ABL>(e[u].z, sS, sG, sink);
-          coo_consume_abl<ABL>(e[u].w, sS, sG, sink);
+          for (u32 i = tid; i < TILE_DIM; i += THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
+        }
+        cur_rt = rt;
+      }
+      __syncthreads();                                  // s tile (and the zeroed accumulators) visible
+      for (u32 q = q0 + tid; q < q1; q += THREADS * UNROLL) {
+        uint4 e[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+          const u32 qq = q + u * THREADS;
+          if (qq < q1) {
+            if (NT) {
+              typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+              const u32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ent4) + qq);
+              e[u] = make_uint4(tt.x, tt.y, tt.z, tt.w);
+            } else e[u] = ent4[qq];
+          } else e[u] = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+          if (ABL == 0) {
+            coo_consume(e[u].x, sS, sG);
+            coo_consume(e[u].y, sS, sG);
+            coo_consume(e[u].z, sS, sG);
+            coo_consume(e[u].w, sS, sG);
+          } else {
+            coo_consume_abl<ABL>(e[u].x, sS, sG, sink);
+            coo_consume_abl<ABL>(e[u].y, sS, sG, sink);
+            coo_consume_abl<ABL>(e[u].z, sS, sG, sink);
+            coo_consume_abl<ABL>(e[u].w, sS, sG, sink);
+          }
         }
       }
     }
@@ -370,7 +385,7 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
     attr_done = true;
   }
   hipLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL>), dim3(mat->nwg), dim3(THREADS), lds_bytes, ctx->stream, (const uint4*)mat->t_ent,
-                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->nct, mat->n, S, part);
+                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->t_tileq, mat->nrt, mat->rt_major ? mat->nct : 0u, mat->n, S, part);
   return KLR_OK;
 }
 

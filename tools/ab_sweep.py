@@ -14,22 +14,29 @@ variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0
 n, m, draws, N = 100000, 65536, 993, 100
 ctx = K.Context(0)
 rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
-full = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
+mats = {}
+for order in ("ct", "rt"):
+    os.environ["KLR_TILE_ORDER"] = order
+    mats[order] = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
+    print(order, mats[order].layout())
+full = mats["ct"]
 cw = full.class_weights()
 L = K.lib()
 L.klr_debug_set_coo_variant.argtypes = [C.c_int]
-res = {v: [] for v in variants}
+res = {(o, v): [] for v in variants for o in mats}
 ctx.prof_enable(True)
 for r in range(rounds + 1):
     for v in variants:
-        L.klr_debug_set_coo_variant(v)
-        ctx.prof_read(reset=True)
-        for _ in range(5):
-            K.sweep_select(ctx, full, None, None, np.zeros(1), cw, N)
-        nl, ms = ctx.prof_read(reset=True)
-        if r > 0:
-            res[v].append(ms / nl * 1e3)
+        for o in mats:
+            L.klr_debug_set_coo_variant(v)
+            ctx.prof_read(reset=True)
+            for _ in range(5):
+                K.sweep_select(ctx, mats[o], None, None, np.zeros(1), cw, N)
+            nl, ms = ctx.prof_read(reset=True)
+            if r > 0:
+                res[(o, v)].append(ms / nl * 1e3)
 names = {14: "1024x1", 15: "768x1 nt", 8: "no-atomic", 9: "no-gather", 10: "512x2 nt", 11: "1024x2 nt", 12: "1024x1 nt", 13: "512x1 nt", 0: "512x4", 1: "512x4 nt", 2: "512x8", 3: "512x8 nt", 4: "1024x4", 5: "1024x4 nt", 6: "1024x2", 7: "256x8"}
 for v in variants:
-    a = np.array(res[v])
-    print("variant %d %-10s median %7.2f us  min %7.2f us" % (v, names.get(v, "?"), np.median(a), a.min()))
+    for o in mats:
+        a = np.array(res[(o, v)])
+        print("order %s variant %d %-10s median %7.2f us  min %7.2f us" % (o, v, names.get(v, "?"), np.median(a), a.min()))
