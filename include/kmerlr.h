@@ -84,6 +84,13 @@ int  klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows, int64_t*
  * col/val need klr_mat_shape's nnz entries. */
 int  klr_mat_to_csr(klr_ctx* ctx, const klr_mat* mat, int64_t* rowptr, int64_t* col, double* val);
 
+/* Restrict every sum over samples (gradient, loss, Gram, class counts) to the rows with mask[i] != 0 --
+ * the training / test split of a cross-validation fold or ensemble member (filterCvGroup,
+ * kmerLr_crossvalidation.go:96-120) without re-uploading the matrix.  n_active_total = number of active
+ * rows over all shards (takes the place of len(data) in 1/n and lambda = L1Reg/n).  mask = NULL restores
+ * all rows.  Reduced matrices inherit the mask in force when they are created.  klr_log_pdf ignores it. */
+int  klr_mat_set_active_rows(klr_ctx* ctx, klr_mat* mat, const uint8_t* mask, int64_t n_active_total);
+
 /* compute_class_weights (kmerLr_data.go:178-193) over the (all-reduced) label counts */
 int  klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2]);
 

@@ -40,6 +40,8 @@ typedef struct klr_backend {
                        double*, int64_t*, int*, double*, double*);
   int  (*cd_solve)(klr_ctx*, const klr_mat*, double*, const double[2], double, double, double, double, int,
                    int64_t, klr_iter_rec*, int64_t, int64_t*);
+  int  (*set_active_rows)(klr_ctx*, klr_mat*, const uint8_t*, int64_t);
+  int  (*log_pdf)(klr_ctx*, const klr_mat*, const double*, double*);
 } klr_backend;
 
 /* the HIP table for an existing context */
@@ -92,6 +94,28 @@ int  klr_estimator_trace(const klr_estimator* est, const klr_iter_rec** recs, in
 /* number of leapfrog epochs of the last estimate call and their lambdas (the "Estimating parameters
  * with lambda=..." lines of kmerLr_estimator.go:246) */
 int  klr_estimator_epochs(const klr_estimator* est, const double** lambdas, const int64_t** nonzero, int64_t* n);
+
+/* k-fold cross-validation (crossvalidation / getCvGroups / filterCvGroup, kmerLr_crossvalidation.go:56-211,
+ * learn_cv kmerLr_learn.go:71-87).  Folds are row masks on the resident matrix (no re-upload): fold f trains
+ * a fresh estimator (cfg of `est`) on the rows with group != f, predicts the rows of group f
+ * (Predict = log sigma(x.theta), kmerLr_classifier.go:107-123) and records train / test loss, for every
+ * lambda_auto.  Group of GLOBAL row r: (r mod k) permuted by the documented shuffle (Go's
+ * math/rand stream is not reproducible without Go); seed = -1: no shuffle, as in the reference.
+ *   row0                global id of the first local row (sharded data), n_all = rows of the whole set
+ *   predictions         out, n_lambda_auto x n_local (local rows; each row is tested in exactly one fold)
+ *   groups              out, n_local (fold of every local row), nullable
+ *   loss_train/test     out, n_lambda_auto x k_fold
+ * Per-fold classifiers stay readable through klr_estimator_classifier (index fold*n_lambda_auto + j). */
+int  klr_estimator_crossvalidate(klr_estimator* est, klr_mat* data, int64_t row0, int64_t n_all, int k_fold, int64_t seed,
+                                 const int64_t* lambda_auto, int64_t n_lambda_auto, const double* scale,
+                                 const double* offset, double* predictions, int32_t* groups, double* loss_train,
+                                 double* loss_test);
+/* fold assignment alone: groups[i] for global rows [row0, row0+n_local) */
+void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t row0, int64_t n_local, int32_t* groups);
+/* SaveCrossvalidation / SaveCrossvalidationLoss (kmerLr_crossvalidation.go:122-165): rows in fold order */
+int  klr_save_crossvalidation(const char* filename, const double* predictions, const uint8_t* labels,
+                              const int32_t* groups, int64_t n, int k_fold);
+int  klr_save_crossvalidation_loss(const char* filename, const double* loss_train, const double* loss_test, int k_fold);
 
 /* Trace.Export (kmerLr_estimator_trace.go:49-78) */
 int  klr_estimator_save_trace(const klr_estimator* est, const char* filename);

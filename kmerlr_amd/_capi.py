@@ -39,6 +39,7 @@ SIGNATURES = {
     "klr_mat_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
                               C.POINTER(_int), C.POINTER(_int)]),
     "klr_mat_to_csr": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "klr_mat_set_active_rows": (_int, [_vp, _vp, _vp, _i64]),
     "klr_class_weights": (_int, [_vp, _vp, _vp]),
     "klr_gradient": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "klr_loss": (_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(_dbl)]),
@@ -198,6 +199,20 @@ class Matrix:
         val = np.zeros(max(self.nnz, 1), dtype=np.float64)
         self.ctx.check(lib().klr_mat_to_csr(self.ctx._h, self._h, _p(rowptr), _p(col), _p(val)))
         return rowptr, col[:self.nnz], val[:self.nnz]
+
+    def set_active_rows(self, mask, n_active_total=0):
+        """mask: uint8 per local row (None = all rows); n_active_total: active rows over all shards."""
+        if mask is None:
+            self.ctx.check(lib().klr_mat_set_active_rows(self.ctx._h, self._h, None, 0))
+            self.n_total = self.n  # refreshed below
+        else:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.shape == (self.n,)
+            self.ctx.check(lib().klr_mat_set_active_rows(self.ctx._h, self._h, _p(mask),
+                                                         n_active_total or int(mask.sum())))
+        n, dim, nnz, nt = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self.ctx.check(lib().klr_mat_shape(self._h, C.byref(n), C.byref(dim), C.byref(nnz), C.byref(nt)))
+        self.n_total = nt.value
 
     def class_weights(self):
         cw = np.zeros(2)

@@ -11,7 +11,8 @@ from . import _capi
 
 class Backend(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ctx", "last_error", "mat_shape", "mat_destroy", "class_weights", "gradient",
-                                          "loss", "select_columns", "sweep_select", "cd_solve")]
+                                          "loss", "select_columns", "sweep_select", "cd_solve", "set_active_rows",
+                                          "log_pdf")]
 
 
 class Config(C.Structure):
@@ -47,6 +48,13 @@ def bind_driver(L):
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, C.c_char_p]
+    L.klr_estimator_crossvalidate.restype = C.c_int
+    L.klr_estimator_crossvalidate.argtypes = [vp, vp, i64, i64, C.c_int, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.klr_cv_groups.argtypes = [i64, C.c_int, i64, i64, i64, vp]
+    L.klr_save_crossvalidation.restype = C.c_int
+    L.klr_save_crossvalidation.argtypes = [C.c_char_p, vp, vp, vp, i64, C.c_int]
+    L.klr_save_crossvalidation_loss.restype = C.c_int
+    L.klr_save_crossvalidation_loss.argtypes = [C.c_char_p, vp, vp, C.c_int]
     L.klr_estimator_save_model.restype = C.c_int
     L.klr_estimator_save_model.argtypes = [vp, i64, C.c_char_p, C.c_char_p, vp]
     return L
@@ -103,6 +111,21 @@ class Estimator:
                                                   None if scale is None else scale.ctypes.data,
                                                   None if offset is None else offset.ctypes.data))
         return self.classifiers()
+
+    def crossvalidate(self, mat_handle, n_local, k_fold, lambda_auto, seed=1, row0=0, n_all=0, scale=None, offset=None):
+        """Returns dict(predictions[nla, n_local], groups[n_local], loss_train[nla, k], loss_test[nla, k])."""
+        la = np.ascontiguousarray(list(lambda_auto), dtype=np.int64)
+        nla = len(la)
+        n_all = n_all or n_local
+        pred = np.zeros((nla, n_local)); groups = np.zeros(n_local, dtype=np.int32)
+        lt = np.zeros((nla, k_fold)); ls = np.zeros((nla, k_fold))
+        scale = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+        offset = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
+        self._check(self.L.klr_estimator_crossvalidate(
+            self._h, mat_handle, row0, n_all, k_fold, seed, la.ctypes.data, nla,
+            None if scale is None else scale.ctypes.data, None if offset is None else offset.ctypes.data,
+            pred.ctypes.data, groups.ctypes.data, lt.ctypes.data, ls.ctypes.data))
+        return dict(predictions=pred, groups=groups, loss_train=lt, loss_test=ls, classifiers=self.classifiers())
 
     def classifiers(self):
         out = []

@@ -271,5 +271,7 @@ extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
   out->select_columns = klr_mat_select_columns;
   out->sweep_select = klr_sweep_select;
   out->cd_solve = klr_cd_solve;
+  out->set_active_rows = klr_mat_set_active_rows;
+  out->log_pdf = klr_log_pdf;
   return KLR_OK;
 }

@@ -313,6 +313,111 @@ extern "C" int klr_estimator_epochs(const klr_estimator* e, const double** lambd
   return KLR_OK;
 }
 
+// ---- cross-validation ---------------------------------------------------------------------------------
+static inline uint64_t sm64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// getCvGroups (kmerLr_crossvalidation.go:56-94) without a validation set: groups = i mod fold, then the
+// shuffle of :42-52 (swap a random remaining element to the end) with Go's r.Intn(n) replaced by
+// splitmix64(seed * GOLD + draw) mod n.
+extern "C" void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t row0, int64_t n_local, int32_t* groups) {
+  std::vector<int32_t> g((size_t)std::max<int64_t>(n_all, 1));
+  for (int64_t i = 0; i < n_all; i++) g[(size_t)i] = k_fold <= 1 ? -1 : (int32_t)(i % k_fold);
+  if (seed != -1 && k_fold > 1) {
+    uint64_t draw = 0;
+    for (int64_t n = n_all; n > 0; n--) {
+      const int64_t r = (int64_t)(sm64((uint64_t)seed * 0x9E3779B97F4A7C15ull + draw++) % (uint64_t)n);
+      std::swap(g[(size_t)(n - 1)], g[(size_t)r]);
+    }
+  }
+  for (int64_t i = 0; i < n_local; i++) groups[i] = g[(size_t)(row0 + i)];
+}
+
+extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int64_t row0, int64_t n_all, int k_fold,
+                                           int64_t seed, const int64_t* lambda_auto, int64_t nla, const double* scale,
+                                           const double* offset, double* predictions, int32_t* groups_out,
+                                           double* loss_train, double* loss_test) {
+  if (!e) return KLR_EINVAL;
+  if (!data || k_fold < 2 || !lambda_auto || nla < 1 || !predictions || !loss_train || !loss_test)
+    return fail(e, KLR_EINVAL, "crossvalidate: invalid argument");
+  if (!e->be.set_active_rows || !e->be.log_pdf) return fail(e, KLR_EINVAL, "backend lacks set_active_rows / log_pdf");
+  int64_t n = 0, dim = 0;
+  if (e->be.mat_shape(data, &n, &dim, nullptr, nullptr) != KLR_OK) return fail(e, KLR_EINVAL, "bad data matrix");
+  if (n_all < k_fold) return fail(e, KLR_EINVAL, "not enough training samples (%lld) for %d-fold cross-validation", (long long)n_all, k_fold);
+  std::vector<int32_t> all((size_t)n_all);
+  klr_cv_groups(n_all, k_fold, seed, 0, n_all, all.data());
+  std::vector<int64_t> fold_size((size_t)k_fold, 0);
+  for (int32_t g : all) fold_size[(size_t)g]++;
+  const int32_t* grp = all.data() + row0;
+  if (groups_out) for (int64_t i = 0; i < n; i++) groups_out[i] = grp[i];
+  std::vector<uint8_t> mask((size_t)std::max<int64_t>(n, 1));
+  std::vector<double> lp((size_t)std::max<int64_t>(n, 1));
+  int rc = KLR_OK;
+  e->out.clear();
+  std::vector<Classifier> all_cls;
+  for (int f = 0; f < k_fold && rc == KLR_OK; f++) {
+    // training rows of fold f (filterCvGroup :96-120)
+    for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] != f;
+    if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_all - fold_size[(size_t)f]) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+    // a fresh estimator per fold (learn_parameters, kmerLr_learn.go:37-38)
+    klr_estimator* fe = nullptr;
+    if (klr_estimator_create(&e->be, &e->cfg, &fe) != KLR_OK) { rc = fail(e, KLR_EINVAL, "cannot create fold estimator"); break; }
+    if (e->cfg.verbose >= 1 && fe) fe->cfg.verbose = e->cfg.verbose;
+    rc = klr_estimator_estimate(fe, data, lambda_auto, nla, scale, offset);
+    if (rc != KLR_OK) { e->err = fe->err; klr_estimator_destroy(fe); break; }
+    for (auto& r : fe->trace) e->trace.push_back(r);
+    for (int64_t j = 0; j < nla && rc == KLR_OK; j++) {
+      const Classifier& c = fe->out[(size_t)j];
+      klr_mat* red = nullptr;
+      if (e->be.select_columns(e->be.ctx, data, c.cols.data(), (int64_t)c.cols.size(), c.scale.empty() ? nullptr : c.scale.data(),
+                               c.offset.empty() ? nullptr : c.offset.data(), &red) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "select_columns"); break; }
+      const double cw1[2] = {1.0, 1.0};
+      // loss_train on the training rows (classifier.Loss, kmerLr_estimator_ensemble.go:143-145; ClassWeights [1,1])
+      if (e->be.loss(e->be.ctx, red, c.theta.data(), cw1, NAN, &loss_train[j * k_fold + f]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "loss");
+      // predictions of the test rows
+      if (rc == KLR_OK && e->be.log_pdf(e->be.ctx, red, c.theta.data(), lp.data()) != KLR_OK) rc = be_fail(e, KLR_EHIP, "log_pdf");
+      if (rc == KLR_OK) for (int64_t i = 0; i < n; i++) if (grp[i] == f) predictions[j * n + i] = lp[(size_t)i];
+      // loss_test on the test rows
+      if (rc == KLR_OK) {
+        for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] == f;
+        if (e->be.set_active_rows(e->be.ctx, red, mask.data(), fold_size[(size_t)f]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "set_active_rows");
+        else if (e->be.loss(e->be.ctx, red, c.theta.data(), cw1, NAN, &loss_test[j * k_fold + f]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "loss");
+      }
+      e->be.mat_destroy(red);
+      all_cls.push_back(c);
+    }
+    klr_estimator_destroy(fe);
+  }
+  e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
+  if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j
+  return rc;
+}
+
+extern "C" int klr_save_crossvalidation(const char* filename, const double* predictions, const uint8_t* labels,
+                                        const int32_t* groups, int64_t n, int k_fold) {
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  fprintf(f, "%15s\t%6s\n", "prediction", "labels");                                  // crossvalidation.go:133
+  for (int g = 0; g < k_fold; g++)                                                        // folds joined in order :196-207
+    for (int64_t i = 0; i < n; i++)
+      if (groups[i] == g) fprintf(f, "%15e\t%6d\n", predictions[i], labels[i] ? 1 : 0);
+  fclose(f);
+  return KLR_OK;
+}
+
+extern "C" int klr_save_crossvalidation_loss(const char* filename, const double* loss_train, const double* loss_test, int k_fold) {
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  fprintf(f, "%15s\t%15s\n", "train", "test");                                         // :158
+  for (int g = 0; g < k_fold; g++) fprintf(f, "%15e\t%15e\n", loss_train[g], loss_test[g]);
+  fclose(f);
+  return KLR_OK;
+}
+
 // format_duration, kmerLr_estimator_trace.go:29-36
 static std::string format_duration(double seconds) {
   const double hours_total = seconds / 3600.0;

@@ -86,6 +86,10 @@ struct klr_mat {
   i64* colchunk = nullptr;       // dim+1: chunks of column j are [colchunk[j], colchunk[j+1])
   int  group = 64;               // lanes per chunk
   uint8_t* labels = nullptr;     // n
+  uint8_t* active = nullptr;     // n row mask (nullable): rows that take part in sums over samples
+  i64  n_total_all = 0;          // n_total without a mask
+  i64  n_active_local = 0;       // active local rows (valid when active != nullptr)
+  std::vector<uint8_t> h_labels; // host copy (class counts under a mask)
   // ---- 2-D tiled packed COO stream for the full-width sweep (klr_sweep.hip, DESIGN.md "data layout"):
   //      tile (rt, ct) = rows [rt*4096, +4096) x columns [ct*4096, +4096); entries row-major inside a
   //      tile; entry = (count:8 << 24) | (col-in-tile:12 << 12) | row-in-tile:12   (4 B per stored nonzero;

@@ -24,7 +24,7 @@ void mat_free(klr_mat* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
-                m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->t_ent, m->t_piece, m->t_wgpiece,
+                m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->active, m->t_ent, m->t_piece, m->t_wgpiece,
                 m->t_ctptr, m->t_ctlist, m->t_tileq};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete m;
@@ -279,6 +279,7 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
   }
   klr_mat* m = new klr_mat();
   m->ctx = ctx; m->device = ctx->device; m->n = n; m->dim = dim; m->nnz = nnz; m->n_total = n_total;
+  m->n_total_all = n_total; m->h_labels.assign(labels, labels + n);
   m->val_f64 = false;
   for (int t = 0; t < T; t++) { if (notf32[t]) m->val_f64 = true; m->n1_local += n1[t]; }
   m->avg_row = n ? (double)nnz / (double)n : 0.0;
@@ -372,11 +373,35 @@ extern "C" int klr_mat_to_csr(klr_ctx* ctx, const klr_mat* mat, int64_t* rowptr,
   return KLR_OK;
 }
 
+extern "C" int klr_mat_set_active_rows(klr_ctx* ctx, klr_mat* mat, const uint8_t* mask, int64_t n_active_total) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!mask) {
+    if (mat->active) { (void)hipFree(mat->active); mat->active = nullptr; }
+    mat->n_total = mat->n_total_all;
+    mat->n1_local = 0;
+    for (uint8_t l : mat->h_labels) if (l) mat->n1_local++;
+    mat->n_active_local = mat->n;
+    return KLR_OK;
+  }
+  KLR_ARG(ctx, n_active_total > 0);
+  if (!mat->active) KLR_TRY(dev_alloc(ctx, (void**)&mat->active, (size_t)std::max<i64>(mat->n, 1)));
+  KLR_HIP(ctx, hipMemcpy(mat->active, mask, (size_t)mat->n, hipMemcpyHostToDevice));
+  i64 na = 0, n1 = 0;
+  for (i64 i = 0; i < mat->n; i++) if (mask[i]) { na++; if (mat->h_labels[(size_t)i]) n1++; }
+  mat->n_active_local = na; mat->n1_local = n1;
+  mat->n_total = n_active_total;
+  return KLR_OK;
+}
+
 // compute_class_weights, kmerLr_data.go:178-193, over all shards
 extern "C" int klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2]) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, mat != nullptr && cw != nullptr);
-  double cnts[2] = {(double)(mat->n - mat->n1_local), (double)mat->n1_local};
+  const i64 nloc = mat->active ? mat->n_active_local : mat->n;
+  double cnts[2] = {(double)(nloc - mat->n1_local), (double)mat->n1_local};
   if (ctx->ar_fn) {
     double* d;
     KLR_TRY(ws_get(ctx, WS_G, 2 * sizeof(double), (void**)&d));
@@ -614,7 +639,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
   const i64 n = full->n;
   klr_mat* r = new klr_mat();
   r->ctx = ctx; r->device = ctx->device; r->n = n; r->dim = c1; r->n_total = full->n_total; r->val_f64 = true;
-  r->n1_local = full->n1_local;
+  r->n1_local = full->n1_local; r->n_total_all = full->n_total_all; r->h_labels = full->h_labels;
   r->h_colptr.assign((size_t)c1 + 1, 0);
   r->h_collen.assign((size_t)c1, 0);
   r->h_colnz.assign((size_t)c1, 0);
@@ -660,6 +685,10 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
     if (e == hipSuccess) e = hipMemcpyAsync(d_srclen, src_len.data(), (size_t)c1 * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dstlen, r->h_collen.data(), (size_t)c1 * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n) e = hipMemcpyAsync(r->labels, full->labels, (size_t)n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && n && full->active) {
+      e = hipMalloc((void**)&r->active, (size_t)n);
+      if (e == hipSuccess) e = hipMemcpyAsync(r->active, full->active, (size_t)n, hipMemcpyDeviceToDevice, st);
+    }
     if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns copy failed: %s", hipGetErrorString(e)); break; }
     const double* scp = scale ? d_scale : nullptr;
     if (dense) {

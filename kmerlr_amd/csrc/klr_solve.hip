@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64) void k_cd_wave(CdArgs a) {
 template <bool LDS>
 __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                     const double* __restrict__ val, const uint8_t* __restrict__ labels,
+                                                    const uint8_t* __restrict__ active,
                                                     i64 n, int d, const double* __restrict__ hist, const int* __restrict__ ndone,
                                                     double cw0, double cw1, double* __restrict__ blk) {
   extern __shared__ double lm_lds[];            // KSPEC * d iterates, layout [column][k]
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowp
   double term[KSPEC];
 #pragma unroll
   for (int k = 0; k < KSPEC; k++) term[k] = 0.0;
-  if (i < n) {
+  if (i < n && (!active || active[i])) {
     const i64 b = rowptr[i], e = rowptr[i + 1];
     const int y = labels[i] != 0;
     double r[KSPEC];
@@ -477,10 +478,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (eval_loss) {
         if ((size_t)KSPEC * d * 8 <= 48 * 1024)
           hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nb), dim3(256), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
-                             (const double*)red->val, red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
+                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
         else
           hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nb), dim3(256), 0, st, red->rowptr, red->col,
-                             (const double*)red->val, red->labels, n, d, hist, ndone, cw[0], cw[1], lossb);
+                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
         hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
         KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
         KLR_HIP(ctx, hipMemcpyAsync(hloss.data(), losses, KSPEC * 8, hipMemcpyDeviceToHost, st));

@@ -33,7 +33,7 @@ __device__ __forceinline__ double group_sum(double v) {
 // row pass: G lanes per row
 // ---------------------------------------------------------------------------------------------
 struct RowPassArgs {
-  const i64* rowptr; const u32* col; const void* val; const uint8_t* labels;
+  const i64* rowptr; const u32* col; const void* val; const uint8_t* labels; const uint8_t* active;
   const double* theta; i64 n; double inv_n; double cw0, cw1;
   double* out0; double* out1; double* blk;   // blk: per-block loss partials
   double theta0_only; int const_mode;
@@ -41,6 +41,14 @@ struct RowPassArgs {
 };
 
 __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i, double r, double& loss_term) {
+  if (a.active && !a.active[i] && mode != ROW_LOGPDF) {
+    // row outside the current training / test split: it contributes nothing to any sum over samples
+    loss_term = 0.0;
+    if (mode == ROW_SWEEP) { a.out0[i] = 0.0; if (a.out1) a.out1[i] = 0.0; }
+    else if (mode == ROW_SWEEP_FIX) a.S[i] = 0;
+    else if (mode == ROW_IRLS) { a.out0[i] = 0.0; a.out1[i] = 0.0; }
+    return;
+  }
   const int y = a.labels[i] != 0;
   const double lp = -d_log_add0(-r);                 // log sigma(r), LogPdf (:147-149)
   if (mode == ROW_LOGPDF) { a.out0[i] = lp; loss_term = 0.0; return; }
@@ -172,7 +180,7 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
   double* blk;
   KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(double), (void**)&blk));
   RowPassArgs a;
-  a.rowptr = mat->rowptr; a.col = mat->col; a.val = mat->val; a.labels = mat->labels;
+  a.rowptr = mat->rowptr; a.col = mat->col; a.val = mat->val; a.labels = mat->labels; a.active = mat->active;
   a.theta = theta_dev; a.n = n; a.inv_n = 1.0 / (double)mat->n_total; a.cw0 = cw[0]; a.cw1 = cw[1];
   a.out0 = out0; a.out1 = out1; a.blk = blk; a.theta0_only = theta0; a.const_mode = const_mode ? 1 : 0;
   a.fix_scale = fix_scale; a.S = S; a.acc = acc;

@@ -13,7 +13,11 @@
 
 struct klr_ctx { char err[256]; };
 struct klr_mat {
-  klo_csr x; int64_t* rowptr; int64_t* col; double* val; uint8_t* labels; int64_t n_total;
+  klo_csr x;                 /* the rows that take part in sums over samples (all rows, or the active subset) */
+  int64_t* rowptr; int64_t* col; double* val; uint8_t* labels; int64_t n_total;
+  /* all rows (owner arrays) */
+  klo_csr all; int64_t* a_rowptr; int64_t* a_col; double* a_val; uint8_t* a_labels; int64_t n_total_all;
+  uint8_t* mask;
 };
 
 static const char* ob_last_error(const klr_ctx* c) { return c ? c->err : ""; }
@@ -28,18 +32,58 @@ klr_mat* klo_backend_mat(int64_t n, int64_t dim, const int64_t* rowptr, const in
   m->labels = (uint8_t*)malloc((size_t)(n > 0 ? n : 1)); memcpy(m->labels, labels, (size_t)n);
   m->x.n = n; m->x.dim = dim; m->x.rowptr = m->rowptr; m->x.col = m->col; m->x.val = m->val;
   m->n_total = n_total ? n_total : n;
+  m->all = m->x; m->a_rowptr = m->rowptr; m->a_col = m->col; m->a_val = m->val; m->a_labels = m->labels;
+  m->n_total_all = m->n_total; m->mask = NULL;
   return m;
+}
+
+static void drop_view(klr_mat* m) {
+  if (m->rowptr != m->a_rowptr) { free(m->rowptr); free(m->col); free(m->val); free(m->labels); }
+  m->rowptr = m->a_rowptr; m->col = m->a_col; m->val = m->a_val; m->labels = m->a_labels;
+  m->x = m->all; m->n_total = m->n_total_all;
+  free(m->mask); m->mask = NULL;
 }
 
 static void ob_mat_destroy(klr_mat* m) {
   if (!m) return;
-  free(m->rowptr); free(m->col); free(m->val); free(m->labels); free(m);
+  drop_view(m);
+  free(m->a_rowptr); free(m->a_col); free(m->a_val); free(m->a_labels); free(m);
+}
+
+/* klr_mat_set_active_rows: the active rows as a filtered copy (what filterCvGroup builds upstream) */
+static int ob_set_active_rows(klr_ctx* c, klr_mat* m, const uint8_t* mask, int64_t n_active_total) {
+  (void)c;
+  drop_view(m);
+  if (!mask) return 0;
+  const int64_t n = m->all.n;
+  int64_t na = 0, nnz = 0;
+  for (int64_t i = 0; i < n; i++) if (mask[i]) { na++; nnz += m->a_rowptr[i + 1] - m->a_rowptr[i]; }
+  m->rowptr = (int64_t*)malloc((size_t)(na + 1) * 8);
+  m->col = (int64_t*)malloc((size_t)(nnz > 0 ? nnz : 1) * 8);
+  m->val = (double*)malloc((size_t)(nnz > 0 ? nnz : 1) * 8);
+  m->labels = (uint8_t*)malloc((size_t)(na > 0 ? na : 1));
+  m->mask = (uint8_t*)malloc((size_t)(n > 0 ? n : 1)); memcpy(m->mask, mask, (size_t)n);
+  int64_t r = 0, o = 0;
+  m->rowptr[0] = 0;
+  for (int64_t i = 0; i < n; i++) if (mask[i]) {
+    for (int64_t a = m->a_rowptr[i]; a < m->a_rowptr[i + 1]; a++) { m->col[o] = m->a_col[a]; m->val[o] = m->a_val[a]; o++; }
+    m->labels[r] = m->a_labels[i]; r++; m->rowptr[r] = o;
+  }
+  m->x.n = na; m->x.dim = m->all.dim; m->x.rowptr = m->rowptr; m->x.col = m->col; m->x.val = m->val;
+  m->n_total = n_active_total;
+  return 0;
+}
+
+static int ob_log_pdf(klr_ctx* c, const klr_mat* m, const double* theta, double* out) {
+  (void)c;
+  for (int64_t i = 0; i < m->all.n; i++) out[i] = klo_class_log_pdf(&m->all, i, theta, NULL, NULL, 1);
+  return 0;
 }
 
 static int ob_mat_shape(const klr_mat* m, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total) {
-  if (n) *n = m->x.n;
-  if (dim) *dim = m->x.dim;
-  if (nnz) *nnz = m->x.rowptr[m->x.n];
+  if (n) *n = m->all.n;
+  if (dim) *dim = m->all.dim;
+  if (nnz) *nnz = m->all.rowptr[m->all.n];
   if (n_total) *n_total = m->n_total;
   return 0;
 }
@@ -64,13 +108,14 @@ static int ob_loss(klr_ctx* c, const klr_mat* m, const double* theta, const doub
 
 static int ob_select_columns(klr_ctx* c, const klr_mat* m, const int64_t* cols, int64_t c1, const double* scale,
                              const double* offset, klr_mat** out) {
-  (void)c;
   int64_t *rp, *ci; double* cv;
-  klo_select_columns(&m->x, cols, c1, scale, offset, &rp, &ci, &cv);
+  klo_select_columns(&m->all, cols, c1, scale, offset, &rp, &ci, &cv);
   klr_mat* r = (klr_mat*)calloc(1, sizeof(klr_mat));
   r->rowptr = rp; r->col = ci; r->val = cv;
-  r->labels = (uint8_t*)malloc((size_t)(m->x.n > 0 ? m->x.n : 1)); memcpy(r->labels, m->labels, (size_t)m->x.n);
-  r->x.n = m->x.n; r->x.dim = c1; r->x.rowptr = rp; r->x.col = ci; r->x.val = cv; r->n_total = m->n_total;
+  r->labels = (uint8_t*)malloc((size_t)(m->all.n > 0 ? m->all.n : 1)); memcpy(r->labels, m->a_labels, (size_t)m->all.n);
+  r->x.n = m->all.n; r->x.dim = c1; r->x.rowptr = rp; r->x.col = ci; r->x.val = cv; r->n_total = m->n_total_all;
+  r->all = r->x; r->a_rowptr = rp; r->a_col = ci; r->a_val = cv; r->a_labels = r->labels; r->n_total_all = m->n_total_all;
+  if (m->mask) ob_set_active_rows(c, r, m->mask, m->n_total);        /* reduced matrices inherit the split */
   *out = r;
   return 0;
 }
@@ -118,6 +163,8 @@ void klo_backend_table(klr_backend* out) {
   out->select_columns = ob_select_columns;
   out->sweep_select = ob_sweep_select;
   out->cd_solve = ob_cd_solve;
+  out->set_active_rows = ob_set_active_rows;
+  out->log_pdf = ob_log_pdf;
 }
 
 void klo_backend_mat_destroy(klr_mat* m) { ob_mat_destroy(m); }

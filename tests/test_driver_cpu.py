@@ -114,3 +114,54 @@ def test_transform_scale_leapfrog(scores_mat):
     top = np.argsort(-np.abs(g[1:]))[:2] + 1
     assert sorted(c["cols"][1:]) == sorted(top)
     np.testing.assert_allclose(c["scale"], scale[c["cols"]])
+
+
+def test_crossvalidation_matches_explicit_subsets(tmp_path):
+    """k-fold CV through row masks == training on the filtered rows (filterCvGroup), predictions and losses
+    computed directly; CV table writers."""
+    x, labels = O.synth_csr(21, 0, 240, 240, 128, 60, 8)
+    h = OD.matrix(x, labels)
+    est = OD.estimator(balance=1)
+    k = 3
+    r = est.crossvalidate(h, x.n, k, [3, 6], seed=7)
+    groups = r["groups"]
+    assert sorted(np.bincount(groups)) == [80, 80, 80] and len(r["classifiers"]) == k * 2
+    # the shuffle is a permutation of i mod k and depends on the seed; seed -1 keeps i mod k
+    g2 = np.zeros(x.n, dtype=np.int32); OD.lib().klr_cv_groups(x.n, k, -1, 0, x.n, g2.ctypes.data)
+    assert list(g2[:6]) == [0, 1, 2, 0, 1, 2] and not np.array_equal(groups, g2)
+    d = x.to_dense()
+    for f in range(k):
+        tr = np.nonzero(groups != f)[0]; te = np.nonzero(groups == f)[0]
+        xt = O.Csr.from_dense(d[tr][:, 1:]) if False else None
+        # explicit subset in the sparse layout
+        rp = [0]; col = []; val = []
+        for i in tr:
+            s, e = x.rowptr[i], x.rowptr[i + 1]
+            col += list(x.col[s:e]); val += list(x.val[s:e]); rp.append(len(col))
+        xs = O.Csr(len(tr), x.dim, rp, col, val)
+        hs = OD.matrix(xs, labels[tr])
+        cs = OD.estimator(balance=1).estimate(hs, [3, 6])
+        OD.free_matrix(hs)
+        for j in range(2):
+            c = r["classifiers"][f * 2 + j]
+            np.testing.assert_array_equal(c["cols"], cs[j]["cols"])
+            np.testing.assert_allclose(c["theta"], cs[j]["theta"], rtol=1e-9, atol=1e-13)
+            theta_full = np.zeros(x.dim); theta_full[c["cols"]] = c["theta"]
+            pred = np.array([O.class_log_pdf(x, i, theta_full, 1) for i in te])
+            np.testing.assert_allclose(r["predictions"][j, te], pred, rtol=1e-12)
+            lt = -np.mean([O.class_log_pdf(x, i, theta_full, labels[i]) for i in tr])
+            ls = -np.mean([O.class_log_pdf(x, i, theta_full, labels[i]) for i in te])
+            assert abs(r["loss_train"][j, f] - lt) < 1e-12 and abs(r["loss_test"][j, f] - ls) < 1e-12
+    OD.free_matrix(h)
+    L = OD.lib()
+    fn = str(tmp_path / "cv.table")
+    p0 = np.ascontiguousarray(r["predictions"][0])
+    assert L.klr_save_crossvalidation(fn.encode(), p0.ctypes.data, labels.ctypes.data, groups.ctypes.data, x.n, k) == 0
+    lines = open(fn).read().splitlines()
+    assert lines[0] == "%15s\t%6s" % ("prediction", "labels") and len(lines) == 1 + x.n
+    first_fold0 = np.nonzero(groups == 0)[0][0]
+    assert lines[1] == "%15e\t%6d" % (p0[first_fold0], labels[first_fold0])
+    fn2 = str(tmp_path / "cv_loss.table")
+    lt, ls = np.ascontiguousarray(r["loss_train"][0]), np.ascontiguousarray(r["loss_test"][0])
+    assert L.klr_save_crossvalidation_loss(fn2.encode(), lt.ctypes.data, ls.ctypes.data, k) == 0
+    assert open(fn2).read().splitlines()[1] == "%15e\t%15e" % (lt[0], ls[0])

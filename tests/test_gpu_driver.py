@@ -106,3 +106,53 @@ def test_allreduce_hook_f64_and_int64(ctx):
         np.testing.assert_allclose(t2, t1, rtol=1e-6, atol=1e-12)
         m1.close(); m2.close(); c2.close(); base.close()
     assert 0 in seen and 1 in seen
+
+
+def test_active_row_masks_on_gpu(ctx):
+    """klr_mat_set_active_rows: masked sums equal the oracle on the filtered rows (tiled and plain layouts)."""
+    for shape in ((6000, 6000, 4096, 250, 16), (500, 500, 300, 60, 8)):
+        x, labels = O.synth_csr(31, 0, *shape)
+        rng = np.random.default_rng(4)
+        mask = (rng.uniform(size=x.n) < 0.7).astype(np.uint8)
+        tr = np.nonzero(mask)[0]
+        rp = np.concatenate([[0], np.cumsum((x.rowptr[1:] - x.rowptr[:-1])[tr])])
+        idx = np.concatenate([np.arange(x.rowptr[i], x.rowptr[i + 1]) for i in tr])
+        xs = O.Csr(len(tr), x.dim, rp, x.col[idx], x.val[idx])
+        m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+        m.set_active_rows(mask)
+        assert m.n_total == len(tr)
+        cw = O.class_weights(labels[tr])
+        np.testing.assert_array_equal(m.class_weights(), cw)
+        theta = np.zeros(x.dim); theta[0] = 0.2; theta[[3, 40, 200]] = [0.1, -0.2, 0.05]
+        g = K.gradient_dense(ctx, m, theta, cw=cw); go = O.gradient(xs, labels[tr], theta, cw=cw)
+        assert np.max(np.abs(g - go)) <= 1e-11 * np.max(np.abs(go))
+        assert abs(K.loss(ctx, m, theta, cw=cw) - O.loss(xs, labels[tr], theta, cw=cw)) < 1e-12
+        r = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, 8)
+        b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+        ok, lam, c, b2 = O.select(O.gradient(xs, labels[tr], np.zeros(x.dim), cw=cw)[1:], b, 0, 8)
+        np.testing.assert_array_equal(r["b"], b2)
+        cols = np.nonzero(b2)[0]
+        red = m.select_columns(cols)                                   # inherits the mask
+        th, _ = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=r["lam"] * len(tr))
+        tho, _ = O.cd_solve(O.select_columns(xs, cols), labels[tr], np.zeros(len(cols)), cw=cw, l1reg=lam * len(tr))
+        np.testing.assert_allclose(th, tho, rtol=1e-6, atol=1e-12)
+        m.set_active_rows(None)
+        assert m.n_total == x.n
+        assert np.max(np.abs(K.gradient_dense(ctx, m, theta) - O.gradient(x, labels, theta))) <= 1e-11
+        m.close()
+
+
+def test_crossvalidation_on_gpu_matches_oracle_driver(ctx):
+    x, labels = O.synth_csr(41, 0, 3000, 3000, 2048, 200, 20)
+    m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    rg = K.hip_estimator(ctx, balance=1).crossvalidate(m._h, x.n, 5, [4, 10], seed=1)
+    h = OD.matrix(x, labels)
+    ro = OD.estimator(balance=1).crossvalidate(h, x.n, 5, [4, 10], seed=1)
+    OD.free_matrix(h)
+    np.testing.assert_array_equal(rg["groups"], ro["groups"])
+    for a, b in zip(rg["classifiers"], ro["classifiers"]):
+        np.testing.assert_array_equal(a["cols"], b["cols"])
+        np.testing.assert_allclose(a["theta"], b["theta"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(rg["predictions"], ro["predictions"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(rg["loss_train"], ro["loss_train"], rtol=1e-8)
+    np.testing.assert_allclose(rg["loss_test"], ro["loss_test"], rtol=1e-8)
