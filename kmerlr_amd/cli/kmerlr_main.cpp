@@ -35,6 +35,7 @@ struct DataSet {                       // ScoresDataSet / KmerDataSet: fg rows f
 }
 
 static int g_verbose = 0;
+static std::string g_seed = "1";
 static void say(int level, const char* fmt, ...) {
   if (g_verbose < level) return;
   va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
@@ -230,7 +231,8 @@ int main(int argc, char** argv) {
     else if (a.rfind("--device=", 0) == 0) device = atoi(a.c_str() + 9);
     else if (a == "-v") g_verbose = std::max(g_verbose, 1);
     else if (a == "-vv") g_verbose = 2;
-    else if (a.rfind("--threads", 0) == 0 || a.rfind("--seed", 0) == 0) continue;      // accepted, unused
+    else if (a.rfind("--threads", 0) == 0) continue;                                     // accepted, unused
+    else if (a.rfind("--seed=", 0) == 0) g_seed = a.substr(7);
     else break;
   }
   if (ci >= argc) {
@@ -267,8 +269,11 @@ int main(int argc, char** argv) {
     cfg.save_trace = flag(o, "save-trace");
     cfg.save_path = flag(o, "save-path");
     cfg.verbose = g_verbose;
-    if (atoi(opt(o, "k-fold-cv", "1").c_str()) != 1 || atoi(opt(o, "ensemble-size", "1").c_str()) != 1)
-      die("--k-fold-cv / --ensemble-size are not part of this build (DESIGN.md, out of scope)");
+    const int kfold = atoi(opt(o, "k-fold-cv", "1").c_str());
+    const long long seed = atoll(opt(o, "seed", g_seed.c_str()).c_str());
+    if (kfold < 1) die("invalid --k-fold-cv");
+    if (atoi(opt(o, "ensemble-size", "1").c_str()) != 1)
+      die("--ensemble-size is not part of this build (DESIGN.md, out of scope)");
     if (flag(o, "co-occurrence")) die("--co-occurrence is not part of this build (DESIGN.md, out of scope)");
 
     DataSet d;
@@ -299,6 +304,40 @@ int main(int argc, char** argv) {
       die("%s", klr_last_error(ctx));
     klr_estimator* est = nullptr;
     if (klr_estimator_create(&be, &cfg, &est) != KLR_OK) die("cannot create estimator");
+    std::vector<const char*> names;
+    for (auto& s : d.names) names.push_back(s.c_str());
+    if (kfold > 1) {
+      // learn_cv (kmerLr_learn.go:71-87): k folds, per-fold models, joined prediction / loss tables
+      if (!std::isnan(cfg.lambda)) die("--k-fold-cv needs --lambda-auto in this build");
+      const int64_t nla = (int64_t)la.size();
+      std::vector<double> pred((size_t)(nla * n)), ltr((size_t)(nla * kfold)), lte((size_t)(nla * kfold));
+      std::vector<int32_t> groups((size_t)n);
+      if (klr_estimator_crossvalidate(est, mat, 0, n, kfold, seed, la.data(), nla, scale.empty() ? nullptr : scale.data(),
+                                      offset.empty() ? nullptr : offset.data(), pred.data(), groups.data(), ltr.data(), lte.data()) != KLR_OK)
+        die("%s", klr_estimator_error(est));
+      char fn[4096];
+      for (int f = 0; f < kfold; f++) for (int64_t j = 0; j < nla; j++) {                  // learn_parameters :42-66
+        if (nla == 1) snprintf(fn, sizeof(fn), "%s_cv%d.json", base.c_str(), f + 1);
+        else snprintf(fn, sizeof(fn), "%s_cv%d_%lld.json", base.c_str(), f + 1, (long long)la[(size_t)j]);
+        say(1, "Exporting model to `%s'... ", fn);
+        if (klr_estimator_save_model(est, f * nla + j, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data()) != KLR_OK) die("failed");
+        say(1, "done\n");
+      }
+      for (int64_t j = 0; j < nla; j++) {                                                    // learn_cv :78-86
+        if (nla == 1) snprintf(fn, sizeof(fn), "%s.table", base.c_str()); else snprintf(fn, sizeof(fn), "%s_%lld.table", base.c_str(), (long long)la[(size_t)j]);
+        say(1, "Exporting cross-validation results to `%s'... ", fn);
+        if (klr_save_crossvalidation(fn, pred.data() + j * n, d.labels.data(), groups.data(), n, kfold) != KLR_OK) die("failed");
+        say(1, "done\n");
+        if (nla == 1) snprintf(fn, sizeof(fn), "%s_loss.table", base.c_str()); else snprintf(fn, sizeof(fn), "%s_%lld_loss.table", base.c_str(), (long long)la[(size_t)j]);
+        say(1, "Exporting cross-validation loss to `%s'... ", fn);
+        if (klr_save_crossvalidation_loss(fn, ltr.data() + j * kfold, lte.data() + j * kfold, kfold) != KLR_OK) die("failed");
+        say(1, "done\n");
+      }
+      klr_estimator_destroy(est);
+      klr_mat_destroy(mat);
+      klr_ctx_destroy(ctx);
+      return 0;
+    }
     if (klr_estimator_estimate(est, mat, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
                                offset.empty() ? nullptr : offset.data()) != KLR_OK)
       die("%s", klr_estimator_error(est));
@@ -314,8 +353,6 @@ int main(int argc, char** argv) {
       if (klr_estimator_save_path(est, fn.c_str()) != KLR_OK) die("failed");
       say(1, "done\n");
     }
-    std::vector<const char*> names;
-    for (auto& s : d.names) names.push_back(s.c_str());
     const int64_t nc = klr_estimator_n_classifiers(est);
     for (int64_t i = 0; i < nc; i++) {                                    // kmerLr_learn.go:60-66
       char fn[4096];

@@ -95,3 +95,20 @@ def test_kmers_learn_config1_matches_oracle_driver(tmp_path):
     np.testing.assert_allclose(m["Distributions"][0]["Parameters"], c["theta"], rtol=1e-6, atol=1e-10)
     assert m["Parameters"]["Names"][0] == "acgt"[(c["cols"][1] - 1) // 64] + "acgt"[(c["cols"][1] - 1) // 16 % 4] + \
         "acgt"[(c["cols"][1] - 1) // 4 % 4] + "acgt"[(c["cols"][1] - 1) % 4]
+
+
+def test_scores_learn_kfold_cv(tmp_path):
+    # README.md:93-166: 5-fold CV on the bundled tables (fold shuffling is Go math/rand upstream: not pinned)
+    fg, bg = os.path.join(GOLDEN, "scoresLr_test_fg.table"), os.path.join(GOLDEN, "scoresLr_test_bg.table")
+    r = run(["-v", "--type=scoresLr", "learn", "--epsilon-loss=1e-4", "--lambda-auto=2,5", "--k-fold-cv=4", fg, bg, "test"], tmp_path)
+    assert "Exporting cross-validation results to `test_2.table'... done" in r.stderr
+    for f in range(1, 5):
+        for la in (2, 5):
+            m = json.load(open(tmp_path / ("test_cv%d_%d.json" % (f, la))))
+            assert len(m["Parameters"]["Index"]) == la
+    t = open(tmp_path / "test_5.table").read().splitlines()
+    assert t[0] == "%15s\t%6s" % ("prediction", "labels") and len(t) == 17
+    assert sorted(int(l.split("\t")[1]) for l in t[1:]) == [0] * 8 + [1] * 8
+    assert all(float(l.split("\t")[0]) <= 0.0 for l in t[1:])            # log-probabilities
+    lt = open(tmp_path / "test_5_loss.table").read().splitlines()
+    assert lt[0] == "%15s\t%15s" % ("train", "test") and len(lt) == 5
