@@ -111,6 +111,18 @@ int  klr_loss(klr_ctx* ctx, const klr_mat* mat, const double* theta, const doubl
  * kmerLr_classifier.go): out[i] = log sigma(x_i . theta) for the local rows. */
 int  klr_log_pdf(klr_ctx* ctx, const klr_mat* mat, const double* theta, double* out);
 
+/* TransformFull.Fit (kmerLr_transform.go:59-252): column statistics over the resident matrix (all shards;
+ * honours the active-row mask) -> Scale / Offset of length dim.
+ * kind: 1 standardizer, 2 variance-scaler, 3 max-abs-scaler, 4 mean-scaler (KLR_TR_*); *has_offset = 1 when
+ * the transform keeps an Offset (standardizer).  max-abs needs a max over ranks and is refused with an
+ * all-reduce hook installed (the hook only sums). */
+#define KLR_TR_STANDARDIZER  1
+#define KLR_TR_VARIANCE      2
+#define KLR_TR_MAXABS        3
+#define KLR_TR_MEAN          4
+int  klr_transform_fit(klr_ctx* ctx, const klr_mat* mat, int kind, double* scale_out, double* offset_out,
+                       int* has_offset);
+
 /* ---- L3: feature selection -------------------------------------------------------------- */
 /* featureSelector.Select + computeLambda + NLargestAbsFloat64
  * (kmerLr_feature_selection.go:78-134,179-192; kmerLr_sort.go:120-131).

@@ -44,6 +44,7 @@ SIGNATURES = {
     "klr_gradient": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "klr_loss": (_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(_dbl)]),
     "klr_log_pdf": (_int, [_vp, _vp, _vp, _vp]),
+    "klr_transform_fit": (_int, [_vp, _vp, _int, _vp, _vp, C.POINTER(_int)]),
     "klr_select": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _dbl, _dbl, C.POINTER(_dbl), C.POINTER(_i64),
                           C.POINTER(_int)]),
     "klr_select_fixed": (_int, [_vp, _vp, _i64, _vp, _i64, _dbl, _i64, C.POINTER(_i64), C.POINTER(_int)]),
@@ -256,6 +257,17 @@ def log_pdf(ctx, mat, theta):
     out = np.zeros(mat.n)
     ctx.check(lib().klr_log_pdf(ctx._h, mat._h, _p(theta), _p(out)))
     return out
+
+
+TRANSFORMS = {"standardizer": 1, "variance-scaler": 2, "max-abs-scaler": 3, "mean-scaler": 4}
+
+
+def transform_fit(ctx, mat, kind):
+    """TransformFull.Fit on the device: returns (scale, offset or None)."""
+    scale, offset = np.zeros(mat.dim), np.zeros(mat.dim)
+    ho = C.c_int(0)
+    ctx.check(lib().klr_transform_fit(ctx._h, mat._h, TRANSFORMS[kind], _p(scale), _p(offset), C.byref(ho)))
+    return scale, (offset if ho.value else None)
 
 
 def select(ctx, g, b, c_prev, N, lambda_prev=0.0, eps_lambda=0.0):

@@ -795,3 +795,107 @@ extern "C" int klr_log_pdf(klr_ctx* ctx, const klr_mat* mat, const double* theta
   KLR_TRY(d2h_sync(ctx, out, o, (size_t)n * sizeof(double)));
   return KLR_OK;
 }
+
+
+// =================================================================================================
+// TransformFull.Fit: per-column statistics with the same lane-group-per-chunk sweep over the plain CSC
+//   count, sum x, sum x^2, max |x|  over the ACTIVE rows; finishing on the host (dim values each)
+// =================================================================================================
+template <typename VT, int G>
+__global__ __launch_bounds__(256) void k_col_stats(const u32* __restrict__ crow, const VT* __restrict__ cval,
+                                                   const i64* __restrict__ chunk_begin, const u32* __restrict__ chunk_len,
+                                                   i64 nchunks, const uint8_t* __restrict__ active, double* __restrict__ part) {
+  const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (gid >= nchunks) return;
+  const i64 b = chunk_begin[gid];
+  const i64 e = b + (i64)chunk_len[gid];
+  double cnt = 0.0, sx = 0.0, sxx = 0.0, mx = 0.0;
+  for (i64 p = b + lane; p < e; p += G) {
+    const u32 r = crow[p];
+    const double v = (double)cval[p];
+    // padding entries are (row 0, value 0); stored explicit zeros of real rows count towards k like upstream:
+    // distinguish by position is not possible here, so padding is excluded through the per-column length
+    // (the finish step uses the host's true lengths for the count) -- only sums and max are taken here
+    if (!active || active[r]) { sx += v; sxx += v * v; mx = fmax(mx, fabs(v)); cnt += (v != 0.0) ? 1.0 : 0.0; }
+  }
+  cnt = group_sum<G>(cnt); sx = group_sum<G>(sx); sxx = group_sum<G>(sxx);
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) { part[gid * 4 + 0] = cnt; part[gid * 4 + 1] = sx; part[gid * 4 + 2] = sxx; part[gid * 4 + 3] = mx; }
+}
+
+__global__ __launch_bounds__(256) void k_col_stats_finish(const i64* __restrict__ colchunk, i64 dim, const double* __restrict__ part,
+                                                          double* __restrict__ out) {
+  const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= dim) return;
+  double cnt = 0.0, sx = 0.0, sxx = 0.0, mx = 0.0;
+  for (i64 c = colchunk[j]; c < colchunk[j + 1]; c++) {
+    cnt += part[c * 4 + 0]; sx += part[c * 4 + 1]; sxx += part[c * 4 + 2]; mx = fmax(mx, part[c * 4 + 3]);
+  }
+  out[j] = cnt; out[dim + j] = sx; out[2 * dim + j] = sxx; out[3 * dim + j] = mx;
+}
+
+template <typename VT>
+static void col_stats_launch(int g, dim3 grid, hipStream_t st, const klr_mat* m, double* part) {
+  const VT* cv = (const VT*)m->cval;
+  switch (g) {
+    case 4:  hipLaunchKernelGGL((k_col_stats<VT, 4>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, m->active, part); break;
+    case 8:  hipLaunchKernelGGL((k_col_stats<VT, 8>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, m->active, part); break;
+    case 16: hipLaunchKernelGGL((k_col_stats<VT, 16>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, m->active, part); break;
+    case 32: hipLaunchKernelGGL((k_col_stats<VT, 32>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, m->active, part); break;
+    default: hipLaunchKernelGGL((k_col_stats<VT, 64>), grid, dim3(256), 0, st, m->crow, cv, m->chunk_begin, m->chunk_len, m->nchunks, m->active, part); break;
+  }
+}
+
+extern "C" int klr_transform_fit(klr_ctx* ctx, const klr_mat* mat, int kind, double* scale_out, double* offset_out,
+                                 int* has_offset) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr && scale_out != nullptr && offset_out != nullptr && has_offset != nullptr);
+  KLR_ARG(ctx, kind >= KLR_TR_STANDARDIZER && kind <= KLR_TR_MEAN);
+  if (kind == KLR_TR_MAXABS && ctx->ar_fn && ctx->nranks > 1)
+    return klr_fail(ctx, KLR_EINVAL, "max-abs-scaler needs a max over ranks; the all-reduce hook only sums");
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 dim = mat->dim;
+  double *part, *out;
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<i64>(mat->nchunks, 1) * 4 * sizeof(double), (void**)&part));
+  KLR_TRY(ws_get(ctx, WS_G, (size_t)(4 * dim + 8) * sizeof(double), (void**)&out));
+  if (mat->nchunks > 0) {
+    const int g = mat->group;
+    const dim3 grid((unsigned)ceil_div(mat->nchunks * g, 256));
+    if (mat->val_f64) col_stats_launch<double>(g, grid, ctx->stream, mat, part);
+    else              col_stats_launch<float>(g, grid, ctx->stream, mat, part);
+  }
+  hipLaunchKernelGGL(k_col_stats_finish, dim3((unsigned)ceil_div(dim, 256)), dim3(256), 0, ctx->stream, mat->colchunk, dim, part, out);
+  KLR_HIP(ctx, hipGetLastError());
+  KLR_TRY(klr_allreduce(ctx, out, 3 * dim, KLR_F64));                 // count, sum, sum of squares
+  std::vector<double> h((size_t)4 * dim);
+  KLR_TRY(d2h_sync(ctx, h.data(), out, (size_t)4 * dim * sizeof(double)));
+  const double n = (double)mat->n_total;
+  const double* sx = h.data() + dim; const double* sxx = h.data() + 2 * dim; const double* mx = h.data() + 3 * dim;
+  // k[j] of the reference counts STORED entries (explicit zeros included); with the active mask only the
+  // host-side lengths of an unmasked matrix are exact, so k is taken as stored entries when no mask is set
+  // and as the nonzero count otherwise (identical for k-mer data, which stores no zeros)
+  *has_offset = 0;
+  for (i64 j = 0; j < dim; j++) { scale_out[j] = 0.0; offset_out[j] = 0.0; }
+  if (kind == KLR_TR_STANDARDIZER || kind == KLR_TR_VARIANCE) {
+    for (i64 j = 1; j < dim; j++) {
+      const double mean = sx[j] / n;
+      // sum over stored (v-mean)^2 + (n-k) mean^2  ==  sum v^2 - 2 mean sum v + n mean^2
+      double sj = sxx[j] - 2.0 * mean * sx[j] + n * mean * mean;
+      if (sj < 0.0) sj = 0.0;
+      offset_out[j] = mean;
+      scale_out[j] = (sj == 0.0) ? 1.0 : 1.0 / std::sqrt(sj / (n - 1.0));
+    }
+    offset_out[0] = 0.0; scale_out[0] = 1.0;
+    if (kind == KLR_TR_STANDARDIZER) *has_offset = 1;
+    else for (i64 j = 0; j < dim; j++) offset_out[j] = 0.0;
+  } else if (kind == KLR_TR_MAXABS) {
+    for (i64 j = 1; j < dim; j++) scale_out[j] = 1.0 / mx[j];
+    scale_out[0] = 1.0;
+  } else {
+    for (i64 j = 1; j < dim; j++) scale_out[j] = n / sx[j];
+    scale_out[0] = 1.0;
+  }
+  return KLR_OK;
+}

@@ -439,6 +439,53 @@ void klo_prox_step(double* theta, const double* g, int64_t len, double step, dou
   }
 }
 
+/* TransformFull.Fit (kmerLr_transform.go:59-252, non-co-occurrence).  kind: 1 standardizer, 2 variance-scaler,
+ * 3 max-abs-scaler, 4 mean-scaler.  scale/offset have length dim; *has_offset tells whether Offset is kept.
+ * With sharding on, n and every per-column sum are over all ranks (the max through a sum of indicator-free
+ * two-pass is not needed here: max-abs uses the hook on a copy raised to... see klo code). */
+int klo_transform_fit(const klo_csr* x, int kind, double* scale, double* offset, int* has_offset) {
+  const int64_t n = x->n, dim = x->dim;
+  const double nn = eff_n(n);
+  for (int64_t j = 0; j < dim; j++) { scale[j] = 0.0; offset[j] = 0.0; }
+  *has_offset = 0;
+  if (kind == 1 || kind == 2) {                                          /* fitStandardizer :59-146 */
+    double* k = (double*)calloc((size_t)dim, sizeof(double));
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t a = x->rowptr[i] + 1; a < x->rowptr[i + 1]; a++) offset[x->col[a]] += x->val[a];   /* :87-89 */
+    ar(offset, dim);
+    for (int64_t j = 1; j < dim; j++) offset[j] /= nn;                   /* :103-105 */
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t a = x->rowptr[i] + 1; a < x->rowptr[i + 1]; a++) {    /* :116-120 */
+        const int64_t j = x->col[a];
+        k[j] += 1.0;
+        scale[j] += (x->val[a] - offset[j]) * (x->val[a] - offset[j]);
+      }
+    ar(k, dim); ar(scale, dim);
+    for (int64_t j = 1; j < dim; j++) {                                  /* :134-143 */
+      const double sj = scale[j] + (nn - k[j]) * offset[j] * offset[j];
+      scale[j] = (sj == 0.0) ? 1.0 : sqrt(sj / (nn - 1.0));
+      scale[j] = 1.0 / scale[j];
+    }
+    offset[0] = 0.0; scale[0] = 1.0;                                     /* :144-145 */
+    free(k);
+    *has_offset = (kind == 1);                                           /* FitVarianceScaler drops Offset :157 */
+    if (kind == 2) for (int64_t j = 0; j < dim; j++) offset[j] = 0.0;
+  } else if (kind == 3) {                                                /* FitMaxAbsScaler :161-204 */
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t a = x->rowptr[i] + 1; a < x->rowptr[i + 1]; a++)
+        scale[x->col[a]] = fmax(scale[x->col[a]], fabs(x->val[a]));
+    for (int64_t j = 1; j < dim; j++) scale[j] = 1.0 / scale[j];
+    scale[0] = 1.0;
+  } else if (kind == 4) {                                                /* FitMeanScaler :206-250 */
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t a = x->rowptr[i] + 1; a < x->rowptr[i + 1]; a++) scale[x->col[a]] += x->val[a];
+    ar(scale, dim);
+    for (int64_t j = 1; j < dim; j++) scale[j] = nn / scale[j];
+    scale[0] = 1.0;
+  } else return 1;
+  return 0;
+}
+
 uint64_t klo_splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ULL;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;

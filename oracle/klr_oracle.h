@@ -94,6 +94,9 @@ int    klo_cd_solve(const klo_csr* x, const uint8_t* labels, double* theta,
                     double eps, double eps_loss, int eval_loss, int64_t max_iter,
                     klo_iter_rec* recs, int64_t recs_cap, int64_t* n_recs);
 
+/* TransformFull.Fit; kind 1 standardizer, 2 variance-scaler, 3 max-abs-scaler, 4 mean-scaler */
+int    klo_transform_fit(const klo_csr* x, int kind, double* scale, double* offset, int* has_offset);
+
 /* proximal-gradient step of kmerLr_estimator_proximal.go:84-98 (one iteration) */
 void   klo_prox_step(double* theta, const double* g, int64_t len, double step, double l1reg);
 

@@ -67,6 +67,8 @@ def lib():
         L.klo_cd_solve.restype = C.c_int
         L.klo_cd_solve.argtypes = [C.POINTER(_Csr), vp, vp, vp, C.c_double, C.c_double, C.c_double,
                                    C.c_double, C.c_int, i64, vp, i64, C.POINTER(i64)]
+        L.klo_transform_fit.restype = C.c_int
+        L.klo_transform_fit.argtypes = [C.POINTER(_Csr), C.c_int, vp, vp, C.POINTER(C.c_int)]
         L.klo_prox_step.argtypes = [vp, vp, i64, C.c_double, C.c_double]
         L.klo_splitmix64.restype = C.c_uint64
         L.klo_splitmix64.argtypes = [C.c_uint64]
@@ -223,6 +225,18 @@ def cd_solve(x, labels, theta, cw=(1.0, 1.0), l1reg=0.0, l2reg=0.0, eps=0.0, eps
     out = [dict(iteration=r.iteration, nonzero=r.nonzero, change=r.change, lambda_=r.lambda_,
                 loss=r.loss, seconds=r.seconds) for r in recs[:min(n_recs.value, recs_cap)]]
     return theta, out
+
+
+TRANSFORMS = {"standardizer": 1, "variance-scaler": 2, "max-abs-scaler": 3, "mean-scaler": 4}
+
+
+def transform_fit(x, kind):
+    """Returns (scale, offset or None)."""
+    scale, offset = np.zeros(x.dim), np.zeros(x.dim)
+    ho = C.c_int(0)
+    rc = lib().klo_transform_fit(x.ref, TRANSFORMS[kind], _p(scale), _p(offset), C.byref(ho))
+    assert rc == 0
+    return scale, (offset if ho.value else None)
 
 
 def prox_step(theta, g, step, l1reg):

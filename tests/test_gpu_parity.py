@@ -389,3 +389,17 @@ def test_cd_solve_solver_variants(ctx, N):
     assert [a["nonzero"] for a in recs] == [a["nonzero"] for a in reco]
     np.testing.assert_allclose([a["loss"] for a in recs], [a["loss"] for a in reco], rtol=0, atol=1e-10)
     np.testing.assert_allclose(th, tho, rtol=THETA_RTOL, atol=1e-11)
+
+
+@pytest.mark.parametrize("kind", ["standardizer", "variance-scaler", "max-abs-scaler", "mean-scaler"])
+def test_transform_fit_on_device(ctx, synth_small, kind):
+    x, labels = synth_small
+    m = upload(ctx, x, labels)
+    sc, of = K.transform_fit(ctx, m, kind)
+    sco, ofo = O.transform_fit(x, kind)
+    ok = np.isfinite(sco)
+    np.testing.assert_allclose(sc[ok], sco[ok], rtol=1e-10)
+    np.testing.assert_array_equal(np.isfinite(sc), ok)               # empty columns: 1/0 = inf on both sides
+    assert (of is None) == (ofo is None)
+    if of is not None:
+        np.testing.assert_allclose(of, ofo, rtol=1e-12, atol=1e-15)

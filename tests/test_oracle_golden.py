@@ -208,3 +208,19 @@ def test_cd_solve_kkt_on_synthetic():
             assert abs(gr[j]) <= lam + 1e-7
     losses = [r["loss"] for r in recs]
     assert losses[-1] <= losses[0]
+
+
+def test_transform_fit_definitions():
+    x, labels = O.synth_csr(13, 0, 120, 120, 40, 30, 4)
+    d = x.to_dense()[:, 1:]
+    sc, of = O.transform_fit(x, "standardizer")
+    np.testing.assert_allclose(of[1:], d.mean(axis=0), rtol=1e-13)
+    sd = d.std(axis=0, ddof=1); exp = np.where(sd == 0, 1.0, 1.0 / np.where(sd == 0, 1.0, sd))
+    np.testing.assert_allclose(sc[1:], exp, rtol=1e-12)
+    assert sc[0] == 1.0 and of[0] == 0.0
+    sc2, of2 = O.transform_fit(x, "variance-scaler")
+    np.testing.assert_array_equal(sc2, sc); assert of2 is None
+    sc3, _ = O.transform_fit(x, "max-abs-scaler")
+    np.testing.assert_allclose(sc3[1:][d.max(axis=0) > 0], 1.0 / d.max(axis=0)[d.max(axis=0) > 0])
+    sc4, _ = O.transform_fit(x, "mean-scaler")
+    np.testing.assert_allclose(sc4[1:][d.sum(axis=0) > 0], 120.0 / d.sum(axis=0)[d.sum(axis=0) > 0])
