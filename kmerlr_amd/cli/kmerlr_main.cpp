@@ -152,39 +152,25 @@ static void read_fasta(const std::string& fn, const KmerSpec& s, uint8_t label, 
   }
 }
 
-// ---- TransformFull.Fit (kmerLr_transform.go:59-252), host side ---------------------------------------
-static void fit_transform(const std::string& kind_, const DataSet& d, std::vector<double>& scale, std::vector<double>& offset) {
+// ---- TransformFull.Fit (kmerLr_transform.go:38-57): column statistics on the device (klr_transform_fit) -----
+static void fit_transform(klr_ctx* ctx, const klr_mat* mat, int64_t dim, const std::string& kind_, std::vector<double>& scale,
+                          std::vector<double>& offset) {
   std::string kind = kind_;
   for (auto& c : kind) c = (char)tolower((unsigned char)c);
   scale.clear(); offset.clear();
   if (kind.empty() || kind == "none") return;
-  const int64_t n = (int64_t)d.labels.size(), dim = d.dim;
-  if (kind == "standardizer" || kind == "variance-scaler") {
-    if (kind == "standardizer") say(1, "WARNING: Standardizing data will result in dense data and slow down computations!\n");
-    offset.assign((size_t)dim, 0.0); scale.assign((size_t)dim, 0.0);
-    std::vector<int64_t> k((size_t)dim, 0);
-    for (int64_t i = 0; i < n; i++) for (int64_t a = d.rowptr[(size_t)i] + 1; a < d.rowptr[(size_t)i + 1]; a++) offset[(size_t)d.col[(size_t)a]] += d.val[(size_t)a];
-    for (int64_t j = 1; j < dim; j++) offset[(size_t)j] /= (double)n;
-    for (int64_t i = 0; i < n; i++) for (int64_t a = d.rowptr[(size_t)i] + 1; a < d.rowptr[(size_t)i + 1]; a++) {
-      const int64_t j = d.col[(size_t)a]; k[(size_t)j]++;
-      const double t = d.val[(size_t)a] - offset[(size_t)j]; scale[(size_t)j] += t * t;
-    }
-    for (int64_t j = 1; j < dim; j++) {
-      const double sj = scale[(size_t)j] + (double)(n - k[(size_t)j]) * offset[(size_t)j] * offset[(size_t)j];
-      scale[(size_t)j] = sj == 0.0 ? 1.0 : 1.0 / std::sqrt(sj / (double)(n - 1));
-    }
-    offset[0] = 0.0; scale[0] = 1.0;
-    if (kind == "variance-scaler") offset.clear();
-  } else if (kind == "max-abs-scaler" || kind == "mean-scaler") {
-    scale.assign((size_t)dim, 0.0);
-    for (int64_t i = 0; i < n; i++) for (int64_t a = d.rowptr[(size_t)i] + 1; a < d.rowptr[(size_t)i + 1]; a++) {
-      const int64_t j = d.col[(size_t)a];
-      if (kind == "max-abs-scaler") scale[(size_t)j] = std::max(scale[(size_t)j], std::fabs(d.val[(size_t)a]));
-      else scale[(size_t)j] += d.val[(size_t)a];
-    }
-    for (int64_t j = 1; j < dim; j++) scale[(size_t)j] = (kind == "max-abs-scaler" ? 1.0 : (double)n) / scale[(size_t)j];
-    scale[0] = 1.0;
-  } else die("invalid data transform");
+  int k = 0;
+  if (kind == "standardizer") { k = KLR_TR_STANDARDIZER; say(1, "WARNING: Standardizing data will result in dense data and slow down computations!\n"); }
+  else if (kind == "variance-scaler") k = KLR_TR_VARIANCE;
+  else if (kind == "max-abs-scaler") k = KLR_TR_MAXABS;
+  else if (kind == "mean-scaler") k = KLR_TR_MEAN;
+  else die("invalid data transform");
+  say(1, "Fitting data transform (%s)... ", kind.c_str());
+  scale.assign((size_t)dim, 0.0); offset.assign((size_t)dim, 0.0);
+  int has_offset = 0;
+  if (klr_transform_fit(ctx, mat, k, scale.data(), offset.data(), &has_offset) != KLR_OK) die("failed\n%s", klr_last_error(ctx));
+  if (!has_offset) offset.clear();
+  say(1, "done\n");
 }
 
 // ---- tiny reader for the model JSON written by klr_estimator_save_model ---------------------------------
@@ -236,7 +222,7 @@ int main(int argc, char** argv) {
     else break;
   }
   if (ci >= argc) {
-    printf("usage: kmerlr [--type=kmerLr|scoresLr] [-v] [--device=N] <learn|loss> ...\n");
+    printf("usage: kmerlr [--type=kmerLr|scoresLr] [-v] [--device=N] <learn|loss|predict> ...\n");
     return 0;
   }
   const std::string cmd = argv[ci];
@@ -296,12 +282,11 @@ int main(int argc, char** argv) {
     }
     const int64_t n = (int64_t)d.labels.size();
     if (n == 0) die("Error: no training data given");
-    std::vector<double> scale, offset;
-    fit_transform(opt(o, "data-transform", ""), d, scale, offset);
-
     klr_mat* mat = nullptr;
     if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
       die("%s", klr_last_error(ctx));
+    std::vector<double> scale, offset;
+    fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), scale, offset);
     klr_estimator* est = nullptr;
     if (klr_estimator_create(&be, &cfg, &est) != KLR_OK) die("cannot create estimator");
     std::vector<const char*> names;
@@ -401,8 +386,49 @@ int main(int argc, char** argv) {
     if (klr_loss(ctx, red, theta.data(), cw, strtod(opt(o, "lambda", "NaN").c_str(), nullptr), &out) != KLR_OK) die("%s", klr_last_error(ctx));
     printf("%15e\n", out);                                              // saveLoss, kmerLr_loss.go:48
     klr_mat_destroy(red); klr_mat_destroy(mat);
+  } else if (cmd == "predict") {
+    // predict_ / predict_scores_ (kmerLr_predict.go:125-139, scoresLr_predict.go:28-37): log sigma(x . theta) per row
+    if (o.pos.size() != 2 && o.pos.size() != 3) die("usage: kmerlr predict MODEL.json DATA [RESULT.table]");
+    std::ifstream jf(o.pos[0]);
+    if (!jf) die("cannot open `%s'", o.pos[0].c_str());
+    std::stringstream buf; buf << jf.rdbuf();
+    const std::string js = buf.str();
+    size_t pos = 0;
+    std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
+    size_t dpos = js.find("\"Distributions\"");
+    std::vector<double> theta = json_numbers_after(js, "Parameters", dpos, &pos);
+    std::vector<double> offset = json_numbers_after(js, "Offset", pos, nullptr);
+    std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
+    if (theta.size() != index.size() + 1) die("invalid config file");
+    DataSet d;
+    if (scores) read_scores(o.pos[1], flag(o, "header"), 0, d);
+    else {
+      KmerSpec ks;
+      ks.M = atoi(opt(o, "m", "0").c_str()); ks.N = atoi(opt(o, "n", "0").c_str());
+      if (ks.M < 1) die("kmerlr predict --type=kmerLr needs --m=M --n=N (the k-mer lengths the model was trained with)");
+      ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+      kmer_prepare(ks, nullptr);
+      read_fasta(o.pos[1], ks, 0, d);
+    }
+    const int64_t n = (int64_t)d.labels.size();
+    klr_mat *mat = nullptr, *red = nullptr;
+    if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+      die("%s", klr_last_error(ctx));
+    std::vector<int64_t> cols{0};
+    for (double v : index) cols.push_back((int64_t)v + 1);
+    if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
+                               offset.empty() ? nullptr : offset.data(), &red) != KLR_OK)
+      die("%s", klr_last_error(ctx));
+    std::vector<double> out((size_t)std::max<int64_t>(n, 1));
+    if (klr_log_pdf(ctx, red, theta.data(), out.data()) != KLR_OK) die("%s", klr_last_error(ctx));
+    FILE* f = o.pos.size() == 3 ? fopen(o.pos[2].c_str(), "w") : stdout;
+    if (!f) die("cannot write `%s'", o.pos[2].c_str());
+    fprintf(f, "%15s\n", "prediction");                                  // savePredictions, kmerLr_predict.go:81-84
+    for (int64_t i = 0; i < n; i++) fprintf(f, "%15e\n", out[(size_t)i]);
+    if (f != stdout) fclose(f);
+    klr_mat_destroy(red); klr_mat_destroy(mat);
   } else {
-    die("unknown command `%s' (this build provides learn and loss)", cmd.c_str());
+    die("unknown command `%s' (this build provides learn, loss and predict)", cmd.c_str());
   }
   klr_ctx_destroy(ctx);
   return 0;

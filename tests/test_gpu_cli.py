@@ -112,3 +112,22 @@ def test_scores_learn_kfold_cv(tmp_path):
     assert all(float(l.split("\t")[0]) <= 0.0 for l in t[1:])            # log-probabilities
     lt = open(tmp_path / "test_5_loss.table").read().splitlines()
     assert lt[0] == "%15s\t%15s" % ("train", "test") and len(lt) == 5
+
+
+def test_predict_and_data_transform(tmp_path):
+    # TestKmers6-style constant predictions are covered by G7; here: predict == log sigma(x.theta) of the model,
+    # and --data-transform=variance-scaler goes through the device fit
+    fg, bg = os.path.join(GOLDEN, "scoresLr_test_fg.table"), os.path.join(GOLDEN, "scoresLr_test_bg.table")
+    r = run(["-v", "--type=scoresLr", "learn", "--lambda-auto=3", "--data-transform=variance-scaler", fg, bg, "tv"], tmp_path)
+    assert "Fitting data transform (variance-scaler)... done" in r.stderr
+    m = json.load(open(tmp_path / "tv.json"))
+    theta = np.array(m["Distributions"][0]["Parameters"]); scale = np.array(m["Distributions"][1]["Parameters"]["Scale"])
+    idx = m["Parameters"]["Index"]
+    assert len(scale) == 4 and scale[0] == 1.0
+    out = run(["--type=scoresLr", "predict", "tv.json", fg], tmp_path).stdout.splitlines()
+    assert out[0] == "%15s" % "prediction" and len(out) == 9
+    _, xf = O.read_scores_table(fg); _, xb = O.read_scores_table(bg)
+    sd = np.concatenate([xf, xb]).std(axis=0, ddof=1)
+    np.testing.assert_allclose(scale[1:], 1.0 / sd[idx], rtol=1e-10)
+    r_lin = theta[0] + (xf[:, idx] * scale[1:]) @ theta[1:]
+    np.testing.assert_allclose([float(v) for v in out[1:]], -np.log1p(np.exp(-r_lin)), rtol=1e-6)
