@@ -50,46 +50,61 @@ __global__ __launch_bounds__(256) void k_gram_scale(const double* __restrict__ n
 }
 
 // off-diagonal, non-bias Gram cells from the short reduced rows, upper triangle only:
-//   Gi[min(ja,jb)][max(ja,jb)] += round(w_i v_a v_b 2^E)   (integer atomics: exact, order free)
-__global__ __launch_bounds__(256) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
-                                                      const double* __restrict__ val, const double* __restrict__ w,
-                                                      i64 n, int d, const double* __restrict__ sc,
-                                                      unsigned long long* __restrict__ Gi) {
-  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const i64 b = rowptr[i], e = rowptr[i + 1];
-  const double wi = w[i] * sc[0];
-  for (i64 a = b + 1; a < e; a++) {
-    const double wa = wi * val[a];
-    const i64 ja = col[a];                       // columns ascend inside a row: ja < col[c] for c > a
-    for (i64 c = a + 1; c < e; c++)
-      atomicAdd(&Gi[ja * d + col[c]], (unsigned long long)__double2ll_rn(wa * val[c]));
+//   Gi[ja][jb] += round(w_i v_a v_b 2^E)  for a < b   (integer atomics: exact, order free)
+// 16 lanes per row: every lane holds one stored entry (coalesced load), partners arrive by shuffle, so a row
+// of q entries costs ~q steps instead of q^2/2 dependent load round trips (rows longer than 16 are chunked).
+// LDSACC: the d x d integer Gram is privatised in LDS (d*d*8 <= 128 KiB) and written out as one partial per
+// workgroup (summed by k_gram_reduce); otherwise global integer atomics.
+template <bool LDSACC>
+__global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                       const double* __restrict__ val, const double* __restrict__ w,
+                                                       i64 n, int d, const double* __restrict__ sc,
+                                                       unsigned long long* __restrict__ Gi) {
+  extern __shared__ unsigned long long gl[];
+  const int dd = d * d;
+  if (LDSACC) {
+    for (int t = threadIdx.x; t < dd; t += 1024) gl[t] = 0ull;
+    __syncthreads();
+  }
+  unsigned long long* acc = LDSACC ? gl : Gi;
+  const double s0 = sc[0];
+  const int lane = threadIdx.x & 15;
+  const i64 grp0 = ((i64)blockIdx.x * 1024 + threadIdx.x) >> 4, ngrp = ((i64)gridDim.x * 1024) >> 4;
+  for (i64 i = grp0; i < n; i += ngrp) {
+    const i64 b = rowptr[i] + 1, e = rowptr[i + 1];            // skip the bias entry
+    const double wi = w[i] * s0;
+    for (i64 a0 = b; a0 < e; a0 += 16) {
+      const bool ha = a0 + lane < e;
+      const int ja = ha ? (int)col[a0 + lane] : 0;
+      const double wa = ha ? wi * val[a0 + lane] : 0.0;
+      for (i64 c0 = a0; c0 < e; c0 += 16) {
+        const bool hc = c0 + lane < e;
+        const int jc_own = hc ? (int)col[c0 + lane] : -1;
+        const double vc_own = hc ? val[c0 + lane] : 0.0;
+#pragma unroll 4
+        for (int o = 0; o < 16; o++) {
+          const int src = (lane + o) & 15;
+          const int jc = __shfl(jc_own, src, 16);
+          const double vc = __shfl(vc_own, src, 16);
+          // columns ascend inside a row: the pair is taken once, with ja < jc
+          if (ha && jc > ja) atomicAdd(&acc[ja * d + jc], (unsigned long long)__double2ll_rn(wa * vc));
+        }
+      }
+    }
+  }
+  if (LDSACC) {
+    __syncthreads();
+    unsigned long long* out = Gi + (size_t)(blockIdx.x + 1) * dd;      // per-workgroup partial, coalesced stores
+    for (int t = threadIdx.x; t < dd; t += 1024) out[t] = gl[t];
   }
 }
 
-// same, with the d x d integer Gram privatised in LDS (d*d*8 bytes <= 128 KiB): LDS atomics absorb the
-// hot cells (popular column pairs), one global atomic per nonzero cell and workgroup at the end
-__global__ __launch_bounds__(1024) void k_gram_offdiag_lds(const i64* __restrict__ rowptr, const u32* __restrict__ col,
-                                                           const double* __restrict__ val, const double* __restrict__ w,
-                                                           i64 n, int d, const double* __restrict__ sc,
-                                                           unsigned long long* __restrict__ Gi) {
-  extern __shared__ unsigned long long gl[];
-  const int dd = d * d;
-  for (int t = threadIdx.x; t < dd; t += 1024) gl[t] = 0ull;
-  __syncthreads();
-  const double s0 = sc[0];
-  for (i64 i = (i64)blockIdx.x * 1024 + threadIdx.x; i < n; i += (i64)gridDim.x * 1024) {
-    const i64 b = rowptr[i], e = rowptr[i + 1];
-    const double wi = w[i] * s0;
-    for (i64 a = b + 1; a < e; a++) {
-      const double wa = wi * val[a];
-      const int ja = (int)col[a];
-      for (i64 c = a + 1; c < e; c++)
-        atomicAdd(&gl[ja * d + (int)col[c]], (unsigned long long)__double2ll_rn(wa * val[c]));
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < dd; t += 1024) { const unsigned long long v = gl[t]; if (v) atomicAdd(&Gi[t], v); }
+__global__ __launch_bounds__(256) void k_gram_reduce(unsigned long long* __restrict__ Gi, int dd, int nblk) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= dd) return;
+  unsigned long long v = 0ull;
+  for (int b = 1; b <= nblk; b++) v += Gi[(size_t)b * dd + t];
+  Gi[t] = v;
 }
 
 // G from its parts: row/column 0 and the diagonal from the column sweeps, the rest from the integers
@@ -207,73 +222,95 @@ __device__ __forceinline__ double bcast_lane(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-template <int QPL>
-__global__ __launch_bounds__(64) void k_cd_wave(CdArgs a) {
+// Row i of the Gram matrix: from LDS (address space known at compile time -> ds_read) or from global memory
+template <bool GLDS>
+__device__ __forceinline__ double gram_at(const double* __restrict__ Gg, i64 idx) {
   extern __shared__ double lds[];
-  const int d = a.d, lane = threadIdx.x;
-  double* Gl = lds;
-  const double* G = a.G;
-  if (a.g_in_lds) {
-    for (i64 i = lane; i < (i64)d * d; i += 64) Gl[i] = a.G[i];
-    G = Gl;
-    __syncthreads();
+  return GLDS ? lds[idx] : Gg[idx];
+}
+
+template <int QPL, bool GLDS>
+__global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
+  // 256 threads stage the Gram matrix into LDS (one wave alone would spend ~1 us per dependent load);
+  // wavefront 0 then runs the sweeps.
+  // LDS: [G d*d (GLDS)] | c[d] | theta[d] | inv[d].  Only q_j travels through the dependency chain of a
+  // coordinate step: c_j = xy_j + norm_j theta_j is formed for all j at the start of a sweep (theta_j only
+  // changes at its own step), theta_j / c_j / 1/(norm_j + l2) / row j of G are fetched one step ahead.
+  extern __shared__ double lds[];
+  const int d = a.d, lane = threadIdx.x & 63;
+  const double* __restrict__ Gg = a.G;
+  double* cl = lds + (GLDS ? (size_t)d * d : 0);
+  double* thl = cl + d;
+  double* invl = thl + d;
+  if (GLDS) {
+    const i64 dd = (i64)d * d;
+#pragma unroll 8
+    for (i64 i = threadIdx.x; i < dd; i += 256) lds[i] = a.G[i];
   }
-  double q[QPL], th[QPL], xy[QPL], dg[QPL];
+  __syncthreads();
+  if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
+  double q[QPL], xy[QPL], dg[QPL];
 #pragma unroll
   for (int s = 0; s < QPL; s++) {
     const int i = s * 64 + lane;
-    th[s] = i < d ? a.theta[i] : 0.0;
     xy[s] = i < d ? a.xy[i] : 0.0;
     dg[s] = i < d ? a.G[(i64)i * d + i] : 1.0;
     q[s] = 0.0;
+    if (i < d) { thl[i] = a.theta[i]; invl[i] = 1.0 / (dg[s] + a.l2reg); }      // :69 as a reciprocal (<= 1 ulp)
   }
+  __builtin_amdgcn_wave_barrier();                     // single wave from here on: LDS ops are in order
   // q = G theta (skipping zero coefficients)
   for (int k = 0; k < d; k++) {
-    double tsel = th[0];
-#pragma unroll
-    for (int s = 1; s < QPL; s++) if ((k >> 6) == s) tsel = th[s];
-    const double t = bcast_lane(tsel, k & 63);
+    const double t = thl[k];
     if (t != 0.0) {
 #pragma unroll
-      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) q[s] += G[(i64)k * d + i] * t; }
+      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) q[s] += gram_at<GLDS>(Gg, (i64)k * d + i) * t; }
     }
   }
   int done = 0;
   for (int k = 0; k < a.K; k++) {
+#pragma unroll
+    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) cl[i] = xy[s] + dg[s] * thl[i]; }   // :56
+    __builtin_amdgcn_wave_barrier();
     double max_x = 0.0, max_delta = 0.0;
     int isnan_ = 0;
+    // step 0 operands
+    double grow[QPL];
+#pragma unroll
+    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; grow[s] = i < d ? gram_at<GLDS>(Gg, i) : 0.0; }
+    double cj = cl[0], old = thl[0], inv = invl[0];
     for (int j = 0; j < d; j++) {
-      double grow[QPL];
+      // operands of step j+1 (independent of this step's result, except theta which only step j+1 writes)
+      const int jn = j + 1 < d ? j + 1 : j;
+      double gnext[QPL];
 #pragma unroll
-      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; grow[s] = i < d ? G[(i64)j * d + i] : 0.0; }
-      double qs = q[0], ts = th[0], xs = xy[0], ds = dg[0];
+      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; gnext[s] = i < d ? gram_at<GLDS>(Gg, (i64)jn * d + i) : 0.0; }
+      const double cn = cl[jn], oldn = thl[jn], invn = invl[jn];
+      // ---- the chain: q_j -> t -> delta -> q, branch free (7 dependent f64 operations).  A coordinate whose
+      // value does not move gives delta = 0 and q += 0 * row: exactly the skipped update.
+      double qs = q[0];
 #pragma unroll
-      for (int s = 1; s < QPL; s++) if ((j >> 6) == s) { qs = q[s]; ts = th[s]; xs = xy[s]; ds = dg[s]; }
-      const int l = j & 63;
-      const double qj = bcast_lane(qs, l), old = bcast_lane(ts, l), xj = bcast_lane(xs, l), dj = bcast_lane(ds, l);
-      double t = xj + dj * old - qj;                              // coordinate.go:56-59
-      // a penalised coordinate sitting at zero whose |t| does not exceed l1reg stays at (+-)0: the
-      // threshold gives 0, 0/(norm+l2) = 0, delta 0 -- skip the rest of the step (exactly the same result)
-      if (j > 0 && old == 0.0 && fabs(t) <= a.l1reg && (dj + a.l2reg) != 0.0) continue;
-      if (j > 0) {                                                // :60-67 soft threshold
-        const double m = fmax(fabs(t) - a.l1reg, 0.0);
-        t = (t >= 0.0) ? m : -m;
-      }
-      t /= (dj + a.l2reg);                                        // :69
-      if (t != t) isnan_ = 1;
-      const double dl = t - old;
-      max_x = fmax(max_x, fabs(t));
+      for (int s = 1; s < QPL; s++) if ((j >> 6) == s) qs = q[s];
+      const double qj = bcast_lane(qs, j & 63);
+      const double l1j = j > 0 ? a.l1reg : 0.0;                    // the bias is not penalised (:60)
+      const double t0 = cj - qj;                                   // coordinate.go:56-59
+      const double m = fmax(fabs(t0) - l1j, 0.0);                  // :60-67 soft threshold
+      const double tn = copysign(m, t0) * inv;                     // :69 (reciprocal)
+      const double dl = tn - old;
+#pragma unroll
+      for (int s = 0; s < QPL; s++) q[s] = fma(dl, grow[s], q[s]);
+      // off the chain: bookkeeping
+      if (lane == 0) thl[j] = tn;
+      isnan_ |= (tn != tn) ? 1 : 0;
+      max_x = fmax(max_x, fabs(tn));
       max_delta = fmax(max_delta, fabs(dl));
-      if (dl != 0.0 || t != t) {                                  // wave-uniform
+      cj = cn; old = oldn; inv = invn;
 #pragma unroll
-        for (int s = 0; s < QPL; s++) {
-          if ((j >> 6) == s && lane == l) th[s] = t;
-          q[s] += dl * grow[s];
-        }
-      }
+      for (int s = 0; s < QPL; s++) grow[s] = gnext[s];
     }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.hist[(i64)k * d + i] = th[s]; }
+    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.hist[(i64)k * d + i] = thl[i]; }
     double delta; int stop;
     if (isnan_) { delta = nan(""); stop = 1; }
     else {
@@ -285,7 +322,7 @@ __global__ __launch_bounds__(64) void k_cd_wave(CdArgs a) {
     if (stop) break;
   }
 #pragma unroll
-  for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.theta[i] = th[s]; }
+  for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.theta[i] = thl[i]; }
   if (lane == 0) *a.ndone = done;
 }
 
@@ -395,14 +432,12 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const int g_in_lds = lds_big <= LDS_MAX;
   const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
   // wave variant: theta, diag, xy (+ G) in LDS
-  const size_t lds_wave = g_in_lds ? (size_t)d * d * sizeof(double) : 16;
+  const size_t lds_wave = (size_t)3 * d * sizeof(double) + (g_in_lds ? (size_t)d * d * sizeof(double) : 0);
   static bool attr_set = false;
   if (!attr_set) {
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
 
@@ -412,7 +447,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * 8, (void**)&w));
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&z));
   KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * 8, (void**)&wz));
-  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8, (void**)&G));
+  // LDS-privatised Gram build: one partial per workgroup after the result slot
+  const bool gram_lds = (size_t)d * d * 8 <= 128 * 1024;
+  const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
+  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)(2 + gram_blocks) * d * d * 8, (void**)&G));
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] hist[K*d] delta[K] gsc[2] | ints: stopf[K] ndone
   const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int);
@@ -449,12 +487,14 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
     KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     if (n) {
-      if ((size_t)d * d * 8 <= 128 * 1024) {
-        const unsigned gb = (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n, 1024)));
-        hipLaunchKernelGGL(k_gram_offdiag_lds, dim3(gb), dim3(1024), (size_t)d * d * 8, st, red->rowptr, red->col,
+      if (gram_lds) {
+        hipLaunchKernelGGL(k_gram_offdiag<true>, dim3(gram_blocks), dim3(1024), (size_t)d * d * 8, st, red->rowptr, red->col,
                            (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
+        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, (unsigned long long*)Gi,
+                           d * d, (int)gram_blocks);
       } else {
-        hipLaunchKernelGGL(k_gram_offdiag, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, red->rowptr, red->col,
+        const unsigned gb = (unsigned)std::max<i64>(1, std::min<i64>(4 * ctx->n_cu, ceil_div(n * 16, 1024)));
+        hipLaunchKernelGGL(k_gram_offdiag<false>, dim3(gb), dim3(1024), 0, st, red->rowptr, red->col,
                            (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
       }
     }
@@ -471,9 +511,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
-      if (d <= 128)      hipLaunchKernelGGL(k_cd_wave<2>, dim3(1), dim3(64), lds_wave, st, a);
-      else if (d <= 256) hipLaunchKernelGGL(k_cd_wave<4>, dim3(1), dim3(64), lds_wave, st, a);
-      else if (d <= 512) hipLaunchKernelGGL(k_cd_wave<8>, dim3(1), dim3(64), lds_wave, st, a);
+      if (d <= 128 && g_in_lds) hipLaunchKernelGGL((k_cd_wave<2, true>), dim3(1), dim3(256), lds_wave, st, a);
+      else if (d <= 128) hipLaunchKernelGGL((k_cd_wave<2, false>), dim3(1), dim3(256), lds_wave, st, a);
+      else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false>), dim3(1), dim3(256), lds_wave, st, a);
+      else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false>), dim3(1), dim3(256), lds_wave, st, a);
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
         if ((size_t)KSPEC * d * 8 <= 48 * 1024)
