@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--features", type=int, default=65536)
     ap.add_argument("--draws", type=int, default=993)
     ap.add_argument("--lambda-auto", type=int, default=100)
-    ap.add_argument("--cpu-baseline-rows", type=int, default=4000)
+    ap.add_argument("--cpu-baseline-rows", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cd-sweeps", type=int, default=64, help="reduced-problem CD sweeps timed for cd_sweeps_per_s")
     ap.add_argument("--force-comm", action="store_true",
@@ -96,8 +96,8 @@ def main():
     t_solve = time.time() - t0
     n_sweeps_solve = len(recs)
 
-    def step():
-        return K.sweep_select(ctx, full, red, cols, theta, cw, N, lambda_prev=r0["lam"] * n_total)
+    stepper = K.SweepStep(ctx, full, red, cols, theta, cw, N, lambda_prev=r0["lam"] * n_total)
+    step = stepper.run
 
     for _ in range(args.warmup):
         step()
@@ -110,7 +110,8 @@ def main():
     ctx.prof_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        step()
+    out = stepper.result()
     ctx.synchronize()
     torch.cuda.synchronize()
     if comm:
@@ -181,7 +182,7 @@ def main():
             "metric": "samples_x_features_per_s (full-width coordinate sweep: X.theta/sigmoid/loss + per-feature gradient + select)",
             "value": value, "unit": "samples*features/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "dtype_note": "row pass in f64; the full-width sweep accumulates in exact int64 fixed point", "data": "synthetic",
             "config": {"workload": "synthetic %d seqs/GPU x %d 8-mer columns, %d draws/row, --lambda-auto=%d "
                                    "(BASELINE configs[2])" % (n_local, m, draws, N),
                        "rows_per_gpu": n_local, "rows_total": n_total, "features": m, "nnz_per_gpu": nnz,
@@ -213,7 +214,7 @@ def cpu_baseline_leg(args, theta, cols, cw):
     th = np.zeros(m + 1)
     th[cols] = theta
     reps, t_tot = 0, 0.0
-    while t_tot < 10.0 and reps < 50:
+    while t_tot < 12.0 and reps < 1000:
         t0 = time.perf_counter()
         g = O.gradient(x, labels, th, cw=cw)
         b = np.zeros(m + 1, dtype=np.uint8); b[0] = 1

@@ -303,6 +303,32 @@ def sweep_select(ctx, full, reduced, red_cols, theta_red, cw, N, lambda_prev=0.0
     return dict(ok=bool(ok.value), lam=lam.value, c=c.value, b=b, loss=ls.value, g=g)
 
 
+class SweepStep:
+    """klr_sweep_select with every argument marshalled once: the per-call Python overhead of the generic
+    wrapper (array conversions, a fresh dim-sized mask) is of the order of the GPU work at small shapes."""
+
+    def __init__(self, ctx, full, reduced, red_cols, theta_red, cw, N, lambda_prev=0.0, eps_lambda=0.0):
+        self.ctx, self.full, self.reduced = ctx, full, reduced
+        self.theta = np.ascontiguousarray(theta_red, dtype=np.float64)
+        self.cols = None if red_cols is None else np.ascontiguousarray(red_cols, dtype=np.int64)
+        self.cw = np.ascontiguousarray(cw, dtype=np.float64)
+        self.b = np.zeros(full.dim, dtype=np.uint8)
+        self.lam, self.c, self.ok, self.loss = C.c_double(0.0), C.c_int64(0), C.c_int(0), C.c_double(0.0)
+        self._fn = lib().klr_sweep_select
+        self._args = (ctx._h, full._h, None if reduced is None else reduced._h, _p(self.cols), _p(self.theta),
+                      C.c_int64(len(self.theta)), _p(self.cw), C.c_int64(N), C.c_double(lambda_prev), C.c_double(eps_lambda),
+                      None, None, _p(self.b), C.byref(self.lam), C.byref(self.c), C.byref(self.ok), C.byref(self.loss), None)
+
+    def run(self):
+        rc = self._fn(*self._args)
+        if rc != 0:
+            self.ctx.check(rc)
+        return self.lam.value
+
+    def result(self):
+        return dict(ok=bool(self.ok.value), lam=self.lam.value, c=self.c.value, b=self.b, loss=self.loss.value, g=None)
+
+
 def cd_solve(ctx, red, theta, cw=(1.0, 1.0), l1reg=0.0, l2reg=0.0, eps=0.0, eps_loss=1e-8, eval_loss=True,
              max_iter=0, recs_cap=100000):
     theta = np.array(theta, dtype=np.float64, copy=True)

@@ -199,7 +199,8 @@ int   launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out);
 // selection on a device gradient (g_dev[0..dim), feature j at g_dev[j+1]); finishes Select on host
 int   select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                          double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
-                         int* ok_out, i64* picked_out, bool keys_hist_ready = false);
+                         int* ok_out, i64* picked_out, bool keys_hist_ready = false,
+                         const double* extra_src = nullptr, double* extra_out = nullptr);
 
 // matrix construction helpers
 int   mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat);   // uses h_colptr/h_collen

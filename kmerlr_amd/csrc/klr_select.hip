@@ -295,6 +295,84 @@ __global__ __launch_bounds__(1024) void k_fast_sort(Cand* __restrict__ c, u32 K,
   }
 }
 
+// fused pick-bin + compact + sort for m <= FUSED_MAX_M: one workgroup does the three steps of the fast path
+// back to back (saves two kernel boundaries; the key scan is m/1024 coalesced loads per lane)
+#define FUSED_MAX_M 262144
+__global__ __launch_bounds__(1024) void k_fast_select_small(u32* __restrict__ hist, const u64* __restrict__ keys, i64 m,
+                                                            u32 K, u32 Nth, FastState* st, Cand* __restrict__ out,
+                                                            const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
+  extern __shared__ Cand sc[];
+  __shared__ u32 ssum[1024];
+  __shared__ unsigned long long s_low;
+  __shared__ u32 s_ncand, s_cursor;
+  __shared__ unsigned long long wbest;
+  const int t = threadIdx.x;
+  if (t == 0 && extra_src) *extra_dst = *extra_src;     // a caller scalar (the sweep's loss) rides in the same block
+  // ---- pick the bracketing bin (as k_fast_pickbin)
+  u32 h[8], loc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; hist[t * 8 + i] = 0; }
+  ssum[t] = loc;
+  if (t == 0) { s_cursor = 0; wbest = 0ull; s_ncand = 0; s_low = 0ull; }
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
+    __syncthreads();
+    ssum[t] += v;
+    __syncthreads();
+  }
+  const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
+  if (above < K && ssum[t] >= K) {
+    u32 cum = above;
+    int b = 7;
+    for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
+    s_low = ((u64)(t * 8 + b)) << FAST_SHIFT;
+    s_ncand = cum + h[b];
+  }
+  __syncthreads();
+  const u32 n = s_ncand;
+  const u64 low = s_low;
+  if (n > FAST_CAP) {                                    // too many candidates: the host falls back
+    if (t == 0) { st->lowkey = low; st->ncand = n; st->cursor = 0; st->fallback = 1; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
+    return;
+  }
+  // ---- compact (order irrelevant: sorted next)
+  for (i64 j = t; j < m; j += 1024) {
+    const u64 k = keys[j];
+    if (k >= low) {
+      const u32 pos = atomicAdd(&s_cursor, 1u);
+      if (pos < FAST_CAP) { sc[pos].key = k; sc[pos].idx = (u32)j; sc[pos].pad = 0; }
+    }
+  }
+  __syncthreads();
+  u32 P = 2; while (P < n) P <<= 1;
+  for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
+  __syncthreads();
+  // ---- bitonic sort by (|g| desc, column asc)
+  for (u32 size = 2; size <= P; size <<= 1) {
+    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+      for (u32 q = t; q < P / 2; q += 1024) {
+        const u32 lo = 2 * q - (q & (stride - 1));
+        const u32 hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        Cand a = sc[lo], b = sc[hi];
+        const bool swap = up ? cand_before(b, a) : cand_before(a, b);
+        if (swap) { sc[lo] = b; sc[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (u32 i = t; i < K && i < n; i += 1024) out[i] = sc[i];
+  const u64 vkey = (Nth >= 1 && Nth <= n) ? sc[Nth - 1].key : 0ull;
+  for (u32 i = t; i < n; i += 1024)
+    if (sc[i].key < vkey && (i == 0 || sc[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sc[i].key | (1ull << 63));
+  __syncthreads();
+  if (t == 0) {
+    st->lowkey = low; st->ncand = n; st->cursor = n; st->fallback = 0;
+    st->vkey = vkey; st->wfound = (wbest >> 63) ? 1u : 0u; st->wkey = wbest & ~(1ull << 63);
+  }
+}
+
 static int select_exact_device(klr_ctx* ctx, const double* g_dev, u64* keys, bool keys_ready, i64 m, i64 K, i64 N,
                                std::vector<Cand>& hc, u64* vkey, u64* wkey) {
   hipStream_t st = ctx->stream;
@@ -347,8 +425,9 @@ int sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist) {
 
 int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                        double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
-                       int* ok_out, i64* picked_out, bool keys_hist_ready) {
+                       int* ok_out, i64* picked_out, bool keys_hist_ready, const double* extra_src, double* extra_out) {
   KLR_ARG(ctx, m >= 0 && N >= 0 && b != nullptr);
+  if (extra_out) *extra_out = NAN;
   const i64 K = std::min<i64>(m, 2 * N);             // NLargestAbsFloat64(g_, 2N)
   std::vector<Cand> hc((size_t)std::max<i64>(K, 1));
   u64 vkey = 0, wkey = 0;
@@ -356,30 +435,41 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     hipStream_t st = ctx->stream;
     u64* keys; u32* hist; Cand* cand;
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
-    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(FAST_CAP + K) * sizeof(Cand), (void**)&cand));
-    FastState* fs = (FastState*)((char*)hist - 64);
-    Cand* out = cand + FAST_CAP;
+    // WS_TMP0: [FAST_CAP scratch candidates | 64 B: FastState (40 B) + caller scalar | K sorted candidates]
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(FAST_CAP + K) * sizeof(Cand) + 64, (void**)&cand));
+    char* stage = (char*)(cand + FAST_CAP);
+    FastState* fs = (FastState*)stage;
+    double* extra_dst = (double*)(stage + 48);
+    Cand* out = (Cand*)(stage + 64);
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
     if (!keys_hist_ready) hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
-    hipLaunchKernelGGL(k_fast_pickbin, dim3(1), dim3(1024), 0, st, hist, (u32)K, fs);
-    hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(256), 0, st, keys, m, fs, cand);
     static bool attr = false;
     if (!attr) {
       KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(FAST_CAP * sizeof(Cand))));
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(FAST_CAP * sizeof(Cand))));
       attr = true;
     }
-    hipLaunchKernelGGL(k_fast_sort, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, cand, (u32)K, (u32)N, fs, out);
+    if (m <= FUSED_MAX_M) {
+      hipLaunchKernelGGL(k_fast_select_small, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, keys, m, (u32)K, (u32)N,
+                         fs, out, extra_src, extra_dst);
+    } else {
+      hipLaunchKernelGGL(k_fast_pickbin, dim3(1), dim3(1024), 0, st, hist, (u32)K, fs);
+      hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(256), 0, st, keys, m, fs, cand);
+      hipLaunchKernelGGL(k_fast_sort, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, cand, (u32)K, (u32)N, fs, out);
+      if (extra_src) KLR_HIP(ctx, hipMemcpyAsync(extra_dst, extra_src, sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
     KLR_HIP(ctx, hipGetLastError());
-    // one pinned staging block: [64 B reserved for the caller | FastState | K candidates]
+    // ONE device->host copy: [state | scalar | K candidates] into pinned memory
     char* pin;
-    KLR_TRY(pin_get(ctx, 64 + 64 + (size_t)K * sizeof(Cand), (void**)&pin));
-    KLR_HIP(ctx, hipMemcpyAsync(pin + 64, fs, sizeof(FastState), hipMemcpyDeviceToHost, st));
-    KLR_HIP(ctx, hipMemcpyAsync(pin + 128, out, (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
+    KLR_TRY(pin_get(ctx, 64 + (size_t)K * sizeof(Cand), (void**)&pin));
+    KLR_HIP(ctx, hipMemcpyAsync(pin, stage, 64 + (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
     KLR_HIP(ctx, hipStreamSynchronize(st));
     FastState hs;
-    memcpy(&hs, pin + 64, sizeof(hs));
-    memcpy(hc.data(), pin + 128, (size_t)K * sizeof(Cand));
+    memcpy(&hs, pin, sizeof(hs));
+    if (extra_out) memcpy(extra_out, pin + 48, sizeof(double));
+    memcpy(hc.data(), pin + 64, (size_t)K * sizeof(Cand));
     vkey = hs.vkey; wkey = hs.wkey;
     const bool need_w = !(N > K) && N >= 1;
     if (hs.fallback || (need_w && !hs.wfound)) {
@@ -387,6 +477,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
       KLR_TRY(select_exact_device(ctx, g_dev, keys, true, m, K, N, hc, &vkey, &wkey));
     }
   }
+  if (K == 0 && extra_src && extra_out) KLR_TRY(d2h_sync(ctx, extra_out, extra_src, sizeof(double)));
   // ---- Select :95-119 on the sorted candidates ------------------------------------------------
   i64 c = c_prev;
   int ok = 0;
@@ -471,9 +562,6 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
     KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
   }
-  const i64 Ksel = std::min<i64>(m, 2 * N);
-  char* pin;
-  KLR_TRY(pin_get(ctx, 64 + 64 + (size_t)std::max<i64>(Ksel, 1) * 16, (void**)&pin));
   bool keys_ready = false;
   if (full->tiled) {
     // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
@@ -496,11 +584,11 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   }
   if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (scale || offset) KLR_TRY(apply_transform_dev(ctx, gbuf, dim, scale, offset));
-  KLR_HIP(ctx, hipMemcpyAsync(pin, gbuf + dim, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready));
-  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out / loss copies (select may not have synchronised)
-  double loss_sum;
-  memcpy(&loss_sum, ctx->pin, sizeof(double));
+
+  double loss_sum = NAN;
+  KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready,
+                             gbuf + dim, &loss_sum));
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out copy (select may not have synchronised)
   if (loss_out) *loss_out = full->n_total ? loss_sum / (double)full->n_total : 0.0;
   return KLR_OK;
 }

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
       if (threadIdx.x < 5) {
         i64 t = 0;
         for (int i = 0; i < 128; i++) t += sq[threadIdx.x][i];
-        ibuf[dim + threadIdx.x] += t;
+        ibuf[dim + threadIdx.x] = t;                      // sole writer: no zeroing needed beforehand
       }
     }
     return;
@@ -566,7 +566,6 @@ int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double
   i64 *S, *ibuf;
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
   KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
-  KLR_HIP(ctx, hipMemsetAsync(ibuf + dim, 0, IB_EXTRA * 8, ctx->stream));
   *S_out = S;
   *acc_out = (unsigned long long*)(ibuf + dim);
   return KLR_OK;
@@ -608,6 +607,7 @@ static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const
                      const double* lterm_dev, double* gbuf) {
   double scale; i64* S; unsigned long long* acc;
   KLR_TRY(sweep_fix_begin(ctx, mat, cw, &scale, &S, &acc));
+  KLR_HIP(ctx, hipMemsetAsync(acc, 0, IB_EXTRA * 8, ctx->stream));      // k_fix_s accumulates with atomics
   if (mat->n) hipLaunchKernelGGL(k_fix_s, dim3((unsigned)ceil_div(mat->n, 256)), dim3(256), 0, ctx->stream, s_dev, lterm_dev,
                                  mat->n, scale, S, acc);
   return sweep_fix_finish(ctx, mat, scale, gbuf, nullptr, nullptr, nullptr, 0);
