@@ -72,6 +72,13 @@ int         klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int nra
 int  klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int64_t* rowptr,
                       const int64_t* col, const double* val, const uint8_t* labels,
                       int64_t n_total, klr_mat** out);
+/* The same matrix from FASTA sequences, counted ON THE DEVICE (scan_sequences / convert_counts,
+ * kmerLr_data.go:197-335): seqs = concatenated sequence bytes, seq_off[n+1]; k-mer lengths M..N (<= 12);
+ * revcomp merges a k-mer with its reverse complement; binarize stores 1 for present classes.  Column ids: for
+ * k = M..N in turn, classes in increasing base-4 code order (a=0,c=1,g=2,t=3; case folded; windows holding any
+ * other character are skipped).  CSR, CSC and the tiled stream are all built on the device. */
+int  klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int64_t* seq_off, int64_t n, int M, int N,
+                            int revcomp, int binarize, const uint8_t* labels, int64_t n_total, klr_mat** out);
 void klr_mat_destroy(klr_mat* mat);
 int  klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total);
 /* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the 2-D tiled packed COO stream

@@ -34,6 +34,7 @@ SIGNATURES = {
     "klr_rccl_unique_id": (_int, [_vp]),
     "klr_ctx_init_rccl": (_int, [_vp, _vp, _int, _int]),
     "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
+    "klr_mat_from_sequences": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _i64, _PVP]),
     "klr_mat_destroy": (None, [_vp]),
     "klr_mat_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "klr_mat_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
@@ -173,6 +174,19 @@ class Matrix:
         labels = np.ascontiguousarray(labels, dtype=np.uint8)
         h = C.c_void_p()
         ctx.check(lib().klr_mat_from_csr(ctx._h, n, dim, _p(rowptr), _p(col), _p(val), _p(labels), n_total, C.byref(h)))
+        return Matrix(ctx, h)
+
+    @staticmethod
+    def from_sequences(ctx, seqs, labels, M, N, revcomp=False, binarize=False, n_total=0):
+        """seqs: list of str/bytes; k-mer counting and the whole matrix build run on the device."""
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(b) for b in bs])
+        blob = b"".join(bs) or b"\0"
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(lib().klr_mat_from_sequences(ctx._h, C.c_char_p(blob), _p(off), len(bs), M, N, int(revcomp), int(binarize),
+                                               _p(labels), n_total, C.byref(h)))
         return Matrix(ctx, h)
 
     def close(self):

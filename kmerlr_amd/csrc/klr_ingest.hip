@@ -1,0 +1,416 @@
+// klr_ingest.hip -- FASTA sequences -> resident k-mer count matrix, entirely on the device
+// (scan_sequences / convert_counts, kmerLr_data.go:197-335, and the CSR -> CSC / tile build of
+// klr_mat.hip's host ingest).
+//
+//   windows   one thread per (sequence, k, position): base-4 code of the window (a=0,c=1,g=2,t=3, case folded),
+//             invalid if it holds any other character; class id through a per-k table (identity, or the dense
+//             rank of min(code, revcomp(code)) with --revcomp)
+//   counts    segmented radix sort of each row's class ids (rocPRIM), run-length encoding -> CSR with the
+//             bias entry (0, 1.0) first; --binarize stores 1
+//   CSC       stable radix sort of the entries by column (row order inside a column is kept)
+//   tiles     stable radix sort by tile id (row-major order inside a tile is kept), counts > 255 split
+// Column ids: for k = M..N in turn, classes in increasing code order (same convention as the CLI's host
+// counter; gonetics' own class order cannot be verified offline).  All integer work: the result is
+// bit-identical to the host ingest of the same counts (tests/test_gpu_ingest.py).
+#include <cstring>
+
+#include "klr_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+#define INVALID_ID 0xFFFFFFFFu
+
+// ---- class tables ---------------------------------------------------------------------------------
+__device__ __forceinline__ u32 revcomp_code(u32 c, int k) {
+  u32 r = 0;
+  for (int i = 0; i < k; i++) { r = (r << 2) | (3u - (c & 3u)); c >>= 2; }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_rep_flag(u32 ncode, int k, u32* __restrict__ flag) {
+  const u32 c = blockIdx.x * 256 + threadIdx.x;
+  if (c < ncode) flag[c] = (min(c, revcomp_code(c, k)) == c) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_class_map(u32 ncode, int k, const i64* __restrict__ rank, int revcomp, u32 base,
+                                                   u32* __restrict__ map) {
+  const u32 c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncode) return;
+  const u32 rep = revcomp ? min(c, revcomp_code(c, k)) : c;
+  map[c] = base + (revcomp ? (u32)rank[rep] : c);
+}
+
+// ---- windows ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int base_code(unsigned char ch) {
+  switch (ch | 0x20) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; default: return -1; }
+}
+
+// windows of row i for k = M..N are laid out k-major: [k=M windows | k=M+1 windows | ...]
+__global__ __launch_bounds__(256) void k_row_windows(const i64* __restrict__ seq_off, i64 n, int M, int N, u32* __restrict__ wcount) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const i64 len = seq_off[i + 1] - seq_off[i];
+  u32 w = 0;
+  for (int k = M; k <= N; k++) if (len >= k) w += (u32)(len - k + 1);
+  wcount[i] = w;
+}
+
+__global__ __launch_bounds__(256) void k_emit_ids(const unsigned char* __restrict__ seqs, const i64* __restrict__ seq_off,
+                                                  const i64* __restrict__ woff, i64 n, int M, int N,
+                                                  const u32* __restrict__ maps, const u32* __restrict__ map_off,
+                                                  u32* __restrict__ ids) {
+  // one block per row; threads stride over the row's windows
+  const i64 i = blockIdx.x;
+  const i64 s0 = seq_off[i], len = seq_off[i + 1] - s0;
+  i64 o = woff[i];
+  for (int k = M; k <= N; k++) {
+    if (len < k) continue;
+    const i64 nw = len - k + 1;
+    const u32* map = maps + map_off[k - M];
+    for (i64 p = threadIdx.x; p < nw; p += 256) {
+      u32 code = 0; bool ok = true;
+      for (int q = 0; q < k; q++) {
+        const int b = base_code(seqs[s0 + p + q]);
+        ok = ok && b >= 0;
+        code = (code << 2) | (u32)(b & 3);
+      }
+      ids[o + p] = ok ? map[code] : INVALID_ID;
+    }
+    o += nw;
+  }
+}
+
+// ---- run-length encoding of the sorted ids ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark_heads(const u32* __restrict__ ids, const i64* __restrict__ woff, i64 n,
+                                                    u32* __restrict__ head, u32* __restrict__ rowheads) {
+  // one block per row: head flags + number of distinct valid ids
+  const i64 i = blockIdx.x;
+  const i64 b = woff[i], e = woff[i + 1];
+  u32 cnt = 0;
+  for (i64 p = b + threadIdx.x; p < e; p += 256) {
+    const u32 v = ids[p];
+    const u32 h = (v != INVALID_ID && (p == b || ids[p - 1] != v)) ? 1u : 0u;
+    head[p] = h;
+    cnt += h;
+  }
+  __shared__ u32 sh[4];
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) rowheads[i] = sh[0] + sh[1] + sh[2] + sh[3] + 1u;      // + the bias entry
+}
+
+__global__ __launch_bounds__(256) void k_write_csr(const u32* __restrict__ ids, const u32* __restrict__ head,
+                                                   const i64* __restrict__ woff, const i64* __restrict__ rowptr, i64 n, int binarize,
+                                                   u32* __restrict__ col, float* __restrict__ val, u32* __restrict__ erow) {
+  // one block per row; entries are few per thread: a head at p owns the run [p, next head or first invalid)
+  const i64 i = blockIdx.x;
+  const i64 b = woff[i], e = woff[i + 1];
+  const i64 r0 = rowptr[i];
+  __shared__ u32 base;
+  if (threadIdx.x == 0) { col[r0] = 0u; val[r0] = 1.0f; erow[r0] = (u32)i; base = 1u; }
+  __syncthreads();
+  // process the row in tiles of 256 positions, ranks by ballot prefix
+  for (i64 p0 = b; p0 < e; p0 += 256) {
+    const i64 p = p0 + threadIdx.x;
+    const bool h = p < e && head[p] != 0u;
+    const unsigned long long m = __ballot(h);
+    __shared__ u32 wcnt[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wcnt[w] = (u32)__popcll(m);
+    __syncthreads();
+    u32 off = base;
+    for (int q = 0; q < w; q++) off += wcnt[q];
+    if (h) {
+      const u32 slot = off + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      const u32 v = ids[p];
+      i64 q = p + 1;
+      while (q < e && ids[q] == v) q++;                    // run length (runs are short: k-mer multiplicities)
+      col[r0 + slot] = v + 1u;
+      val[r0 + slot] = binarize ? 1.0f : (float)(q - p);
+      erow[r0 + slot] = (u32)i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+}
+
+// ---- CSC --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_col_hist(const u32* __restrict__ col, const float* __restrict__ val, i64 nnz,
+                                                  u32* __restrict__ collen, unsigned long long* __restrict__ colsum) {
+  const i64 a = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (a >= nnz) return;
+  atomicAdd(&collen[col[a]], 1u);
+  atomicAdd(&colsum[col[a]], (unsigned long long)val[a]);
+}
+
+__global__ __launch_bounds__(256) void k_iota(u32* __restrict__ v, i64 n) {
+  const i64 a = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (a < n) v[a] = (u32)a;
+}
+
+__global__ __launch_bounds__(256) void k_csc_scatter(const u32* __restrict__ sorted_col, const u32* __restrict__ sorted_idx, i64 nnz,
+                                                     const i64* __restrict__ colstart, const i64* __restrict__ colptr_pad,
+                                                     const u32* __restrict__ erow, const float* __restrict__ val,
+                                                     u32* __restrict__ crow, float* __restrict__ cval) {
+  const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnz) return;
+  const u32 c = sorted_col[k];
+  const u32 idx = sorted_idx[k];
+  const i64 pos = colptr_pad[c] + (k - colstart[c]);
+  crow[pos] = erow[idx];
+  cval[pos] = val[idx];
+}
+
+// ---- tiles -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_keys(const u32* __restrict__ col, const float* __restrict__ val, const u32* __restrict__ erow,
+                                                   i64 nnz, u32 nrt, u32 nct, int rt_major, u32 ntile,
+                                                   u32* __restrict__ tkey, u32* __restrict__ ne, u32* __restrict__ tile_ne) {
+  const i64 a = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (a >= nnz) return;
+  const u32 c = col[a];
+  if (c == 0u) { tkey[a] = ntile; ne[a] = 0u; return; }          // bias column is not stored: sorts to the end
+  const u32 rt = erow[a] >> TILE_BITS, ct = c >> TILE_BITS;
+  const u32 t = rt_major ? rt * nct + ct : ct * nrt + rt;
+  const u32 v = (u32)val[a];
+  const u32 k = (v + 254u) / 255u;
+  tkey[a] = t; ne[a] = k;
+  atomicAdd(&tile_ne[t], k);
+}
+
+__global__ __launch_bounds__(256) void k_tile_quads(const u32* __restrict__ tile_ne, u32 ntile, u32* __restrict__ tile_q4) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t < ntile) tile_q4[t] = (tile_ne[t] + 3u) / 4u;
+}
+
+__global__ __launch_bounds__(256) void k_gather_u32(const u32* __restrict__ src, const u32* __restrict__ idx, i64 n, u32* __restrict__ dst) {
+  const i64 a = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (a < n) dst[a] = src[idx[a]];
+}
+
+__global__ __launch_bounds__(256) void k_tile_scatter(const u32* __restrict__ skey, const u32* __restrict__ sidx, i64 nnz, u32 ntile,
+                                                      const i64* __restrict__ ne_prefix /* over sorted order */,
+                                                      const i64* __restrict__ tile_first /* exscan of per-tile ne */,
+                                                      const i64* __restrict__ tile_q /* exscan of quads */,
+                                                      const u32* __restrict__ col, const float* __restrict__ val,
+                                                      const u32* __restrict__ erow, u32* __restrict__ ent) {
+  const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nnz) return;
+  const u32 t = skey[k];
+  if (t >= ntile) return;                                           // bias entries
+  const u32 a = sidx[k];
+  i64 pos = tile_q[t] * 4 + (ne_prefix[k] - tile_first[t]);
+  u32 v = (u32)val[a];
+  const u32 base = ((col[a] & (TILE_DIM - 1)) << TILE_BITS) | (erow[a] & (TILE_DIM - 1));
+  while (v > 0u) { const u32 q = min(v, 255u); ent[pos++] = (q << 24) | base; v -= q; }
+}
+
+// ---- small helpers -----------------------------------------------------------------------------------------
+template <typename T>
+static int dalloc(klr_ctx* ctx, T** p, size_t count) { return dev_alloc(ctx, (void**)p, std::max<size_t>(count, 1) * sizeof(T)); }
+
+struct TmpPool {
+  std::vector<void*> v;
+  ~TmpPool() { for (void* p : v) (void)hipFree(p); }
+  template <typename T> int get(klr_ctx* ctx, T** p, size_t count) {
+    int rc = dalloc(ctx, p, count);
+    if (rc == KLR_OK) v.push_back((void*)*p);
+    return rc;
+  }
+};
+
+static int exscan64(klr_ctx* ctx, const u32* in, i64 n, i64* out) { return launch_exscan_u32(ctx, in, n, out); }
+
+int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& toff4, i64 nrt, i64 nct, bool rt_major);
+
+// CSC + tiles + host metadata from a device CSR (rowptr i64[n+1], col u32, val f32 counts, erow u32 row of entry)
+static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, TmpPool& tmp) {
+  hipStream_t st = ctx->stream;
+  const i64 n = m->n, dim = m->dim, nnz = m->nnz;
+  const float* val = (const float*)m->val;
+  // ---- column lengths / sums -> host metadata
+  u32* collen; unsigned long long* colsum;
+  KLR_TRY(tmp.get(ctx, &collen, (size_t)dim)); KLR_TRY(tmp.get(ctx, &colsum, (size_t)dim));
+  KLR_HIP(ctx, hipMemsetAsync(collen, 0, (size_t)dim * 4, st));
+  KLR_HIP(ctx, hipMemsetAsync(colsum, 0, (size_t)dim * 8, st));
+  if (nnz) hipLaunchKernelGGL(k_col_hist, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, m->col, val, nnz, collen, colsum);
+  m->h_collen.assign((size_t)dim, 0);
+  std::vector<unsigned long long> h_sum((size_t)dim);
+  KLR_HIP(ctx, hipMemcpyAsync(m->h_collen.data(), collen, (size_t)dim * 4, hipMemcpyDeviceToHost, st));
+  KLR_TRY(d2h_sync(ctx, h_sum.data(), colsum, (size_t)dim * 8));
+  m->h_colnz = m->h_collen;                                    // counts are never stored as zero
+  m->h_colptr.assign((size_t)dim + 1, 0);
+  std::vector<i64> h_colstart((size_t)dim + 1, 0);
+  double amax = 0.0;
+  for (i64 j = 0; j < dim; j++) {
+    h_colstart[(size_t)j + 1] = h_colstart[(size_t)j] + m->h_collen[(size_t)j];
+    m->h_colptr[(size_t)j + 1] = m->h_colptr[(size_t)j] + (i64)((m->h_collen[(size_t)j] + 3u) & ~3u);
+    if (j > 0) amax = std::max(amax, (double)h_sum[(size_t)j]);
+  }
+  m->nnz_pad = m->h_colptr[(size_t)dim];
+  m->col_abs_max = amax;
+  // ---- CSC: stable sort of the entries by column
+  u32 *kin, *kout, *vin, *vout;
+  KLR_TRY(tmp.get(ctx, &kout, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &vin, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &vout, (size_t)nnz));
+  kin = m->col;
+  if (nnz) hipLaunchKernelGGL(k_iota, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, vin, nnz);
+  int bits = 1; while (((i64)1 << bits) < dim) bits++;
+  size_t tsz = 0;
+  KLR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tsz, kin, kout, vin, vout, (size_t)nnz, 0, bits, st));
+  void* tstore; KLR_TRY(tmp.get(ctx, (char**)&tstore, tsz));
+  if (nnz) KLR_HIP(ctx, rocprim::radix_sort_pairs(tstore, tsz, kin, kout, vin, vout, (size_t)nnz, 0, bits, st));
+  i64 *d_colstart, *d_colptr;
+  KLR_TRY(tmp.get(ctx, &d_colstart, (size_t)dim + 1)); KLR_TRY(tmp.get(ctx, &d_colptr, (size_t)dim + 1));
+  KLR_HIP(ctx, hipMemcpyAsync(d_colstart, h_colstart.data(), (size_t)(dim + 1) * 8, hipMemcpyHostToDevice, st));
+  KLR_HIP(ctx, hipMemcpyAsync(d_colptr, m->h_colptr.data(), (size_t)(dim + 1) * 8, hipMemcpyHostToDevice, st));
+  KLR_TRY(dalloc(ctx, &m->crow, (size_t)m->nnz_pad));
+  KLR_TRY(dev_alloc(ctx, &m->cval, (size_t)std::max<i64>(m->nnz_pad, 1) * 4));
+  KLR_HIP(ctx, hipMemsetAsync(m->crow, 0, (size_t)std::max<i64>(m->nnz_pad, 1) * 4, st));
+  KLR_HIP(ctx, hipMemsetAsync(m->cval, 0, (size_t)std::max<i64>(m->nnz_pad, 1) * 4, st));
+  if (nnz) hipLaunchKernelGGL(k_csc_scatter, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, kout, vout, nnz, d_colstart, d_colptr,
+                              erow, val, m->crow, (float*)m->cval);
+  KLR_HIP(ctx, hipGetLastError());
+  KLR_HIP(ctx, hipStreamSynchronize(st));
+  KLR_TRY(mat_build_chunks_and_upload(ctx, m));
+  // ---- tiles
+  if (n < 2048 || nnz < (1 << 20)) return KLR_OK;
+  const i64 nrt = ceil_div(n, (i64)TILE_DIM), nct = ceil_div(dim, (i64)TILE_DIM);
+  const i64 ntile = nrt * nct;
+  if (ntile >= ((i64)1 << 31)) return KLR_OK;
+  const char* ord = getenv("KLR_TILE_ORDER");
+  bool rt_major = (double)nnz / (double)ntile >= 32768.0;
+  if (ord && ord[0] == 'r') rt_major = true;
+  if (ord && ord[0] == 'c') rt_major = false;
+  u32 *tkey, *ne, *tile_ne, *tile_q4, *skey, *sne;
+  KLR_TRY(tmp.get(ctx, &tkey, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &ne, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &skey, (size_t)nnz));
+  KLR_TRY(tmp.get(ctx, &sne, (size_t)nnz));
+  KLR_TRY(tmp.get(ctx, &tile_ne, (size_t)ntile + 1)); KLR_TRY(tmp.get(ctx, &tile_q4, (size_t)ntile + 1));
+  KLR_HIP(ctx, hipMemsetAsync(tile_ne, 0, (size_t)(ntile + 1) * 4, st));
+  hipLaunchKernelGGL(k_tile_keys, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, m->col, val, erow, nnz, (u32)nrt, (u32)nct,
+                     rt_major ? 1 : 0, (u32)ntile, tkey, ne, tile_ne);
+  int tbits = 1; while (((i64)1 << tbits) < ntile + 1) tbits++;
+  size_t tsz2 = 0;
+  KLR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tsz2, tkey, skey, vin, vout, (size_t)nnz, 0, tbits, st));
+  void* tstore2; KLR_TRY(tmp.get(ctx, (char**)&tstore2, tsz2));
+  KLR_HIP(ctx, rocprim::radix_sort_pairs(tstore2, tsz2, tkey, skey, vin, vout, (size_t)nnz, 0, tbits, st));   // vin is still iota
+  hipLaunchKernelGGL(k_gather_u32, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, ne, vout, nnz, sne);
+  hipLaunchKernelGGL(k_tile_quads, dim3((unsigned)ceil_div(ntile, 256)), dim3(256), 0, st, tile_ne, (u32)ntile, tile_q4);
+  i64 *ne_prefix, *tile_first, *tile_q;
+  KLR_TRY(tmp.get(ctx, &ne_prefix, (size_t)nnz + 1)); KLR_TRY(tmp.get(ctx, &tile_first, (size_t)ntile + 1));
+  KLR_TRY(tmp.get(ctx, &tile_q, (size_t)ntile + 1));
+  KLR_TRY(exscan64(ctx, sne, nnz, ne_prefix));
+  KLR_TRY(exscan64(ctx, tile_ne, ntile, tile_first));
+  KLR_TRY(exscan64(ctx, tile_q4, ntile, tile_q));
+  std::vector<i64> h_tq((size_t)ntile + 1);
+  KLR_TRY(d2h_sync(ctx, h_tq.data(), tile_q, (size_t)(ntile + 1) * 8));
+  const i64 total4 = h_tq[(size_t)ntile];
+  if (total4 <= 0 || (u64)total4 * 4ull >= 0xFFFFFFF0ull) return KLR_OK;
+  i64 h_stored = 0;
+  KLR_TRY(d2h_sync(ctx, &h_stored, ne_prefix + nnz, 8));
+  KLR_TRY(dalloc(ctx, &m->t_ent, (size_t)total4 * 4));
+  KLR_HIP(ctx, hipMemsetAsync(m->t_ent, 0, (size_t)total4 * 16, st));
+  hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, skey, vout, nnz, (u32)ntile, ne_prefix,
+                     tile_first, tile_q, m->col, val, erow, m->t_ent);
+  KLR_HIP(ctx, hipGetLastError());
+  KLR_HIP(ctx, hipStreamSynchronize(st));
+  std::vector<u64> toff4((size_t)ntile + 1);
+  for (i64 t = 0; t <= ntile; t++) toff4[(size_t)t] = (u64)h_tq[(size_t)t];
+  m->stored_entries = h_stored;
+  return build_pieces_and_upload(ctx, m, toff4, nrt, nct, rt_major);
+}
+
+extern "C" int klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int64_t* seq_off, int64_t n, int M, int N,
+                                      int revcomp, int binarize, const uint8_t* labels, int64_t n_total, klr_mat** out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, out != nullptr);
+  *out = nullptr;
+  KLR_ARG(ctx, seqs != nullptr && seq_off != nullptr && labels != nullptr && n >= 1 && seq_off[0] == 0);
+  KLR_ARG(ctx, M >= 1 && N >= M && N <= 12);
+  if (n_total == 0) n_total = n;
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  TmpPool tmp;
+  const i64 nbytes = seq_off[n];
+  // ---- class tables
+  std::vector<u32> h_mapoff((size_t)(N - M + 1));
+  u64 tot_codes = 0;
+  for (int k = M; k <= N; k++) { h_mapoff[(size_t)(k - M)] = (u32)tot_codes; tot_codes += (u64)1 << (2 * k); }
+  u32 *maps, *d_mapoff, *flag; i64* rank;
+  KLR_TRY(tmp.get(ctx, &maps, (size_t)tot_codes)); KLR_TRY(tmp.get(ctx, &d_mapoff, h_mapoff.size()));
+  const u32 maxcode = (u32)1 << (2 * N);
+  KLR_TRY(tmp.get(ctx, &flag, (size_t)maxcode)); KLR_TRY(tmp.get(ctx, &rank, (size_t)maxcode + 1));
+  KLR_HIP(ctx, hipMemcpyAsync(d_mapoff, h_mapoff.data(), h_mapoff.size() * 4, hipMemcpyHostToDevice, st));
+  u32 m_total = 0;
+  for (int k = M; k <= N; k++) {
+    const u32 nc = (u32)1 << (2 * k);
+    u32 nclass = nc;
+    if (revcomp) {
+      hipLaunchKernelGGL(k_rep_flag, dim3(ceil_div(nc, 256)), dim3(256), 0, st, nc, k, flag);
+      KLR_TRY(exscan64(ctx, flag, nc, rank));
+      i64 h;
+      KLR_TRY(d2h_sync(ctx, &h, rank + nc, 8));
+      nclass = (u32)h;
+    }
+    hipLaunchKernelGGL(k_class_map, dim3(ceil_div(nc, 256)), dim3(256), 0, st, nc, k, rank, revcomp, m_total,
+                       maps + h_mapoff[(size_t)(k - M)]);
+    KLR_HIP(ctx, hipStreamSynchronize(st));        // `rank` is reused by the next k
+    m_total += nclass;
+  }
+  const i64 dim = (i64)m_total + 1;
+  // ---- sequences, windows
+  unsigned char* d_seqs; i64* d_seqoff; u32* wcount; i64* woff;
+  KLR_TRY(tmp.get(ctx, &d_seqs, (size_t)nbytes)); KLR_TRY(tmp.get(ctx, &d_seqoff, (size_t)n + 1));
+  KLR_TRY(tmp.get(ctx, &wcount, (size_t)n)); KLR_TRY(tmp.get(ctx, &woff, (size_t)n + 1));
+  KLR_HIP(ctx, hipMemcpyAsync(d_seqs, seqs, (size_t)nbytes, hipMemcpyHostToDevice, st));
+  KLR_HIP(ctx, hipMemcpyAsync(d_seqoff, seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_row_windows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_seqoff, n, M, N, wcount);
+  KLR_TRY(exscan64(ctx, wcount, n, woff));
+  i64 nwin = 0;
+  KLR_TRY(d2h_sync(ctx, &nwin, woff + n, 8));
+  KLR_ARG(ctx, nwin < (i64)0xFFFFFFF0ll);
+  u32 *ids, *ids_sorted, *head, *rowheads;
+  KLR_TRY(tmp.get(ctx, &ids, (size_t)nwin)); KLR_TRY(tmp.get(ctx, &ids_sorted, (size_t)nwin));
+  KLR_TRY(tmp.get(ctx, &head, (size_t)nwin)); KLR_TRY(tmp.get(ctx, &rowheads, (size_t)n));
+  hipLaunchKernelGGL(k_emit_ids, dim3((unsigned)n), dim3(256), 0, st, d_seqs, d_seqoff, woff, n, M, N, maps, d_mapoff, ids);
+  // ---- per-row sort (segments = rows)
+  {
+    size_t tsz = 0;
+    KLR_HIP(ctx, rocprim::segmented_radix_sort_keys(nullptr, tsz, ids, ids_sorted, (unsigned)nwin, (unsigned)n, woff, woff + 1, 0, 32, st));
+    void* ts; KLR_TRY(tmp.get(ctx, (char**)&ts, tsz));
+    if (nwin) KLR_HIP(ctx, rocprim::segmented_radix_sort_keys(ts, tsz, ids, ids_sorted, (unsigned)nwin, (unsigned)n, woff, woff + 1, 0, 32, st));
+  }
+  hipLaunchKernelGGL(k_mark_heads, dim3((unsigned)n), dim3(256), 0, st, ids_sorted, woff, n, head, rowheads);
+  // ---- CSR
+  klr_mat* m = new klr_mat();
+  m->ctx = ctx; m->device = ctx->device; m->n = n; m->dim = dim; m->n_total = n_total; m->n_total_all = n_total;
+  m->val_f64 = false;
+  m->h_labels.assign(labels, labels + n);
+  for (i64 i = 0; i < n; i++) if (labels[i]) m->n1_local++;
+  int rc = KLR_OK;
+  do {
+    if ((rc = dalloc(ctx, &m->rowptr, (size_t)n + 1))) break;
+    if ((rc = exscan64(ctx, rowheads, n, m->rowptr))) break;
+    i64 nnz = 0;
+    if ((rc = d2h_sync(ctx, &nnz, m->rowptr + n, 8))) break;
+    m->nnz = nnz;
+    m->avg_row = (double)nnz / (double)n;
+    if ((rc = dalloc(ctx, &m->col, (size_t)nnz))) break;
+    if ((rc = dev_alloc(ctx, &m->val, (size_t)std::max<i64>(nnz, 1) * 4))) break;
+    if ((rc = dalloc(ctx, &m->labels, (size_t)n))) break;
+    u32* erow;
+    if ((rc = tmp.get(ctx, &erow, (size_t)nnz))) break;
+    hipLaunchKernelGGL(k_write_csr, dim3((unsigned)n), dim3(256), 0, st, ids_sorted, head, woff, m->rowptr, n, binarize, m->col,
+                       (float*)m->val, erow);
+    if (hipMemcpyAsync(m->labels, labels, (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "label upload failed"); break; }
+    if (hipGetLastError() != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "k-mer counting kernels failed"); break; }
+    rc = finish_from_device_csr(ctx, m, erow, tmp);
+  } while (0);
+  if (rc == KLR_OK && hipStreamSynchronize(st) != hipSuccess) rc = klr_fail(ctx, KLR_EHIP, "device ingest failed");
+  if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(m); ctx->err = keep; return rc; }
+  *out = m;
+  return KLR_OK;
+}

@@ -90,6 +90,62 @@ int mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat) {
   return KLR_OK;
 }
 
+// pieces / per-workgroup ranges / per-column-tile piece lists / tile offsets of a tiled stream whose tile
+// quad offsets are toff4[ntile+1]; uploads them and marks the matrix tiled (shared by the host and the device ingest)
+int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& toff4, i64 nrt, i64 nct, bool rt_major) {
+  const i64 ntile = nrt * nct;
+  const i64 total4 = (i64)toff4[(size_t)ntile];
+  // pieces: equal parts of the quad stream, cut where the column tile changes
+  const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
+  std::vector<u32> piece; piece.reserve((size_t)(nwg + nct) * 4);
+  std::vector<u32> wgp((size_t)nwg + 1);
+  {
+    i64 tile = 0;
+    for (u32 w = 0; w < nwg; w++) {
+      wgp[w] = (u32)(piece.size() / 4);
+      const u64 q0 = (u64)total4 * w / nwg, q1 = (u64)total4 * (w + 1) / nwg;
+      u64 q = q0;
+      while (q < q1) {
+        while (toff4[(size_t)tile + 1] <= q) tile++;
+        const i64 ct = rt_major ? tile % nct : tile / nrt;
+        // a piece ends where the column tile changes: the next tile (row-tile major) or the end of the
+        // column strip (column-tile major)
+        const u64 ct_end = rt_major ? toff4[(size_t)tile + 1] : toff4[(size_t)((ct + 1) * nrt)];
+        const u64 e = std::min<u64>(q1, ct_end);
+        piece.push_back((u32)ct); piece.push_back((u32)q); piece.push_back((u32)e); piece.push_back((u32)tile);
+        q = e;
+      }
+    }
+    wgp[nwg] = (u32)(piece.size() / 4);
+  }
+  const u32 npiece = (u32)(piece.size() / 4);
+  std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(npiece);
+  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
+  for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
+  {
+    std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
+    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
+  }
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)npiece * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, ((size_t)nwg + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_tileq, ((size_t)ntile + 2) * 4));
+  {
+    std::vector<u32> tq((size_t)ntile + 2);
+    for (i64 t = 0; t <= ntile; t++) tq[(size_t)t] = (u32)toff4[(size_t)t];
+    tq[(size_t)ntile + 1] = (u32)total4;                 // sentinel: the kernel reads tileq[t+1] before it stops
+    KLR_HIP(ctx, hipMemcpy(m->t_tileq, tq.data(), ((size_t)ntile + 2) * 4, hipMemcpyHostToDevice));
+  }
+  KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, wgp.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
+  m->rt_major = rt_major; m->tiled = true; m->nrt = (u32)nrt; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
+  m->total4 = total4;
+  return KLR_OK;
+}
+
 // =================================================================================================
 // 2-D tiled packed COO stream for the full-width sweep.  Built when every value is a non-negative
 // integer (k-mer counts) and the matrix is large enough for the sweep to be bandwidth bound;
@@ -174,56 +230,10 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
     });
     for (auto& x : th) x.join();
   }
-  // pieces: equal parts of the quad stream, cut where the column tile changes
-  const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
-  std::vector<u32> piece; piece.reserve((size_t)(nwg + nct) * 4);
-  std::vector<u32> wgp((size_t)nwg + 1);
-  {
-    i64 tile = 0;
-    for (u32 w = 0; w < nwg; w++) {
-      wgp[w] = (u32)(piece.size() / 4);
-      const u64 q0 = (u64)total4 * w / nwg, q1 = (u64)total4 * (w + 1) / nwg;
-      u64 q = q0;
-      while (q < q1) {
-        while (toff4[(size_t)tile + 1] <= q) tile++;
-        const i64 ct = rt_major ? tile % nct : tile / nrt;
-        // a piece ends where the column tile changes: the next tile (row-tile major) or the end of the
-        // column strip (column-tile major)
-        const u64 ct_end = rt_major ? toff4[(size_t)tile + 1] : toff4[(size_t)((ct + 1) * nrt)];
-        const u64 e = std::min<u64>(q1, ct_end);
-        piece.push_back((u32)ct); piece.push_back((u32)q); piece.push_back((u32)e); piece.push_back((u32)tile);
-        q = e;
-      }
-    }
-    wgp[nwg] = (u32)(piece.size() / 4);
-  }
-  const u32 npiece = (u32)(piece.size() / 4);
-  std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(npiece);
-  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
-  for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
-  {
-    std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
-    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
-  }
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)total4 * 16));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)npiece * 16));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, ((size_t)nwg + 1) * 4));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_tileq, ((size_t)ntile + 2) * 4));
-  {
-    std::vector<u32> tq((size_t)ntile + 2);
-    for (i64 t = 0; t <= ntile; t++) tq[(size_t)t] = (u32)toff4[(size_t)t];
-    tq[(size_t)ntile + 1] = (u32)total4;                 // sentinel: the kernel reads tileq[t+1] before it stops
-    KLR_HIP(ctx, hipMemcpy(m->t_tileq, tq.data(), ((size_t)ntile + 2) * 4, hipMemcpyHostToDevice));
-  }
   KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * 16, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, wgp.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
-  m->rt_major = rt_major; m->tiled = true; m->nrt = (u32)nrt; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
-  m->total4 = total4; m->stored_entries = (i64)stored; m->col_abs_max = amax;
+  m->stored_entries = (i64)stored; m->col_abs_max = amax;
+  KLR_TRY(build_pieces_and_upload(ctx, m, toff4, nrt, nct, rt_major));
   return KLR_OK;
 }
 
