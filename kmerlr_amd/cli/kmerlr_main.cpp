@@ -73,7 +73,7 @@ static void read_scores(const std::string& fn, bool header, uint8_t label, DataS
   say(1, "done\n");
 }
 
-// ---- FASTA -> k-mer counts (host; SURVEY 8(f)1: the device version is a later row) --------------------
+// ---- k-mer classes: names on the host; the counting itself runs on the device (klr_mat_from_sequences) ---
 // Column ids: for k = M..N in turn, the base-4 value of the k-mer (a=0,c=1,g=2,t=3), upper/lower case
 // folded, windows containing any other character skipped; --revcomp merges a k-mer with its reverse
 // complement (class id = the smaller of the two codes, classes renumbered densely per k); --binarize
@@ -117,39 +117,36 @@ static void kmer_prepare(KmerSpec& s, std::vector<std::string>* names) {
   }
 }
 
-static void read_fasta(const std::string& fn, const KmerSpec& s, uint8_t label, DataSet& d) {
+struct SeqSet { std::string blob; std::vector<int64_t> off{0}; std::vector<uint8_t> labels; };
+
+// import_fasta (kmerLr_data.go:101-123): sequences only; counting happens on the device
+static void read_fasta(const std::string& fn, uint8_t label, SeqSet& q) {
   say(1, "Reading sequences from `%s'... ", fn.c_str());
   std::ifstream f(fn);
   if (!f) die("failed\ncannot open `%s'", fn.c_str());
-  std::vector<std::string> seqs;
-  std::string line, cur; bool have = false;
+  std::string line; bool have = false;
   while (std::getline(f, line)) {
-    if (!line.empty() && line[0] == '>') { if (have) seqs.push_back(cur); cur.clear(); have = true; continue; }
-    for (char c : line) if (!isspace((unsigned char)c)) cur.push_back(c);
-  }
-  if (have) seqs.push_back(cur);
-  say(1, "done\n");
-  d.dim = s.m + 1;
-  std::map<int64_t, double> cnt;
-  for (const std::string& q : seqs) {
-    cnt.clear();
-    for (int ki = 0; ki < (int)s.cls.size(); ki++) {
-      const int k = s.M + ki;
-      const int64_t mask = ((int64_t)1 << (2 * k)) - 1;
-      int64_t code = 0; int valid = 0;
-      for (size_t p = 0; p < q.size(); p++) {
-        int b;
-        switch (tolower((unsigned char)q[p])) { case 'a': b = 0; break; case 'c': b = 1; break; case 'g': b = 2; break; case 't': b = 3; break; default: b = -1; }
-        if (b < 0) { valid = 0; code = 0; continue; }
-        code = ((code << 2) | b) & mask; valid++;
-        if (valid >= k) cnt[s.base[(size_t)ki] + s.cls[(size_t)ki][(size_t)code]] += 1.0;
-      }
+    if (!line.empty() && line[0] == '>') {
+      if (have) { q.off.push_back((int64_t)q.blob.size()); q.labels.push_back(label); }
+      have = true; continue;
     }
-    d.col.push_back(0); d.val.push_back(1.0);
-    for (auto& kv : cnt) { d.col.push_back(kv.first + 1); d.val.push_back(s.binarize ? 1.0 : kv.second); }
-    d.rowptr.push_back((int64_t)d.col.size());
-    d.labels.push_back(label);
+    if (have) for (char c : line) if (!isspace((unsigned char)c)) q.blob.push_back(c);
   }
+  if (have) { q.off.push_back((int64_t)q.blob.size()); q.labels.push_back(label); }
+  say(1, "done\n");
+}
+
+// scan_sequences + convert_counts on the device (klr_mat_from_sequences)
+static klr_mat* count_kmers(klr_ctx* ctx, const SeqSet& q, const KmerSpec& ks) {
+  if (q.labels.empty()) die("Error: no training data given");
+  say(1, "Counting k-mers on the device... ");
+  klr_mat* mat = nullptr;
+  const std::string& blob = q.blob.empty() ? std::string("N") : q.blob;
+  if (klr_mat_from_sequences(ctx, blob.data(), q.off.data(), (int64_t)q.labels.size(), ks.M, ks.N, ks.revcomp ? 1 : 0,
+                             ks.binarize ? 1 : 0, q.labels.data(), 0, &mat) != KLR_OK)
+    die("failed\n%s", klr_last_error(ctx));
+  say(1, "done\n");
+  return mat;
 }
 
 // ---- TransformFull.Fit (kmerLr_transform.go:38-57): column statistics on the device (klr_transform_fit) -----
@@ -263,6 +260,7 @@ int main(int argc, char** argv) {
     if (flag(o, "co-occurrence")) die("--co-occurrence is not part of this build (DESIGN.md, out of scope)");
 
     DataSet d;
+    SeqSet sq;
     std::string base;
     KmerSpec ks;
     if (scores) {
@@ -276,15 +274,20 @@ int main(int argc, char** argv) {
       if (ks.M < 1 || ks.N < ks.M || ks.N > 12) die("invalid k-mer lengths");
       ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
       kmer_prepare(ks, &d.names);
-      read_fasta(o.pos[2], ks, 1, d);
-      read_fasta(o.pos[3], ks, 0, d);
+      read_fasta(o.pos[2], 1, sq);
+      read_fasta(o.pos[3], 0, sq);
+      d.dim = ks.m + 1; d.labels = sq.labels;
       base = o.pos[4];
     }
     const int64_t n = (int64_t)d.labels.size();
     if (n == 0) die("Error: no training data given");
     klr_mat* mat = nullptr;
-    if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
-      die("%s", klr_last_error(ctx));
+    if (scores) {
+      if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+        die("%s", klr_last_error(ctx));
+    } else {
+      mat = count_kmers(ctx, sq, ks);
+    }
     std::vector<double> scale, offset;
     fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), scale, offset);
     klr_estimator* est = nullptr;
@@ -363,19 +366,19 @@ int main(int argc, char** argv) {
     std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
     if (theta.size() != index.size() + 1) die("invalid config file");
     DataSet d;
-    if (scores) { read_scores(o.pos[1], flag(o, "header"), 1, d); read_scores(o.pos[2], flag(o, "header"), 0, d); }
-    else {
-      KmerSpec ks;
+    klr_mat *mat = nullptr, *red = nullptr;
+    if (scores) {
+      read_scores(o.pos[1], flag(o, "header"), 1, d); read_scores(o.pos[2], flag(o, "header"), 0, d);
+      if (klr_mat_from_csr(ctx, (int64_t)d.labels.size(), d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+        die("%s", klr_last_error(ctx));
+    } else {
+      KmerSpec ks; SeqSet sq;
       ks.M = atoi(opt(o, "m", "0").c_str()); ks.N = atoi(opt(o, "n", "0").c_str());
       if (ks.M < 1) die("kmerlr loss --type=kmerLr needs --m=M --n=N (the k-mer lengths the model was trained with)");
       ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
-      kmer_prepare(ks, nullptr);
-      read_fasta(o.pos[1], ks, 1, d); read_fasta(o.pos[2], ks, 0, d);
+      read_fasta(o.pos[1], 1, sq); read_fasta(o.pos[2], 0, sq);
+      mat = count_kmers(ctx, sq, ks);
     }
-    const int64_t n = (int64_t)d.labels.size();
-    klr_mat *mat = nullptr, *red = nullptr;
-    if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
-      die("%s", klr_last_error(ctx));
     std::vector<int64_t> cols{0};
     for (double v : index) cols.push_back((int64_t)v + 1);
     if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
@@ -401,19 +404,22 @@ int main(int argc, char** argv) {
     std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
     if (theta.size() != index.size() + 1) die("invalid config file");
     DataSet d;
-    if (scores) read_scores(o.pos[1], flag(o, "header"), 0, d);
-    else {
-      KmerSpec ks;
+    klr_mat *mat = nullptr, *red = nullptr;
+    int64_t n = 0;
+    if (scores) {
+      read_scores(o.pos[1], flag(o, "header"), 0, d);
+      n = (int64_t)d.labels.size();
+      if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+        die("%s", klr_last_error(ctx));
+    } else {
+      KmerSpec ks; SeqSet sq;
       ks.M = atoi(opt(o, "m", "0").c_str()); ks.N = atoi(opt(o, "n", "0").c_str());
       if (ks.M < 1) die("kmerlr predict --type=kmerLr needs --m=M --n=N (the k-mer lengths the model was trained with)");
       ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
-      kmer_prepare(ks, nullptr);
-      read_fasta(o.pos[1], ks, 0, d);
+      read_fasta(o.pos[1], 0, sq);
+      n = (int64_t)sq.labels.size();
+      mat = count_kmers(ctx, sq, ks);
     }
-    const int64_t n = (int64_t)d.labels.size();
-    klr_mat *mat = nullptr, *red = nullptr;
-    if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
-      die("%s", klr_last_error(ctx));
     std::vector<int64_t> cols{0};
     for (double v : index) cols.push_back((int64_t)v + 1);
     if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
