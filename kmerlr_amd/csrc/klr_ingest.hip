@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256) void k_csc_scatter(const u32* __restrict__ sor
 
 // ---- tiles -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_keys(const u32* __restrict__ col, const float* __restrict__ val, const u32* __restrict__ erow,
-                                                   i64 nnz, u32 nrt, u32 nct, int rt_major, u32 ntile,
+                                                   i64 nnz, u32 nrt, u32 nct, u32 RT, u32 CT, int rt_major, u32 ntile,
                                                    u32* __restrict__ tkey, u32* __restrict__ ne, u32* __restrict__ tile_ne) {
   const i64 a = (i64)blockIdx.x * 256 + threadIdx.x;
   if (a >= nnz) return;
   const u32 c = col[a];
   if (c == 0u) { tkey[a] = ntile; ne[a] = 0u; return; }          // bias column is not stored: sorts to the end
-  const u32 rt = erow[a] >> TILE_BITS, ct = c >> TILE_BITS;
+  const u32 rt = erow[a] / RT, ct = c / CT;
   const u32 t = rt_major ? rt * nct + ct : ct * nrt + rt;
   const u32 v = (u32)val[a];
   const u32 k = (v + 254u) / 255u;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const u32* __restrict__ sk
                                                       const i64* __restrict__ tile_first /* exscan of per-tile ne */,
                                                       const i64* __restrict__ tile_q /* exscan of quads */,
                                                       const u32* __restrict__ col, const float* __restrict__ val,
-                                                      const u32* __restrict__ erow, u32* __restrict__ ent) {
+                                                      const u32* __restrict__ erow, u32 RT, u32 CT, u32* __restrict__ ent) {
   const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
   if (k >= nnz) return;
   const u32 t = skey[k];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const u32* __restrict__ sk
   const u32 a = sidx[k];
   i64 pos = tile_q[t] * 4 + (ne_prefix[k] - tile_first[t]);
   u32 v = (u32)val[a];
-  const u32 base = ((col[a] & (TILE_DIM - 1)) << TILE_BITS) | (erow[a] & (TILE_DIM - 1));
+  const u32 base = ((col[a] % CT) << TILE_BITS) | (erow[a] % RT);
   while (v > 0u) { const u32 q = min(v, 255u); ent[pos++] = (q << 24) | base; v -= q; }
 }
 
@@ -278,7 +278,8 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   KLR_TRY(mat_build_chunks_and_upload(ctx, m));
   // ---- tiles
   if (n < 2048 || nnz < (1 << 20)) return KLR_OK;
-  const i64 nrt = ceil_div(n, (i64)TILE_DIM), nct = ceil_div(dim, (i64)TILE_DIM);
+  i64 nrt, nct;
+  tile_geometry(n, dim, (u32)std::max(2, 2 * ctx->n_cu), &m->tile_r, &m->tile_c, &nrt, &nct);
   const i64 ntile = nrt * nct;
   if (ntile >= ((i64)1 << 31)) return KLR_OK;
   const char* ord = getenv("KLR_TILE_ORDER");
@@ -291,7 +292,7 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   KLR_TRY(tmp.get(ctx, &tile_ne, (size_t)ntile + 1)); KLR_TRY(tmp.get(ctx, &tile_q4, (size_t)ntile + 1));
   KLR_HIP(ctx, hipMemsetAsync(tile_ne, 0, (size_t)(ntile + 1) * 4, st));
   hipLaunchKernelGGL(k_tile_keys, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, m->col, val, erow, nnz, (u32)nrt, (u32)nct,
-                     rt_major ? 1 : 0, (u32)ntile, tkey, ne, tile_ne);
+                     m->tile_r, m->tile_c, rt_major ? 1 : 0, (u32)ntile, tkey, ne, tile_ne);
   int tbits = 1; while (((i64)1 << tbits) < ntile + 1) tbits++;
   size_t tsz2 = 0;
   KLR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tsz2, tkey, skey, vin, vout, (size_t)nnz, 0, tbits, st));
@@ -314,7 +315,7 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   KLR_TRY(dalloc(ctx, &m->t_ent, (size_t)total4 * 4));
   KLR_HIP(ctx, hipMemsetAsync(m->t_ent, 0, (size_t)total4 * 16, st));
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, skey, vout, nnz, (u32)ntile, ne_prefix,
-                     tile_first, tile_q, m->col, val, erow, m->t_ent);
+                     tile_first, tile_q, m->col, val, erow, m->tile_r, m->tile_c, m->t_ent);
   KLR_HIP(ctx, hipGetLastError());
   KLR_HIP(ctx, hipStreamSynchronize(st));
   std::vector<u64> toff4((size_t)ntile + 1);

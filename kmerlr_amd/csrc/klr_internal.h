@@ -104,6 +104,7 @@ struct klr_mat {
   u32* t_piece = nullptr;        // npiece * 4: {column tile, quad begin, quad end, first tile index}
   u32* t_tileq = nullptr;        // ntile+1 quad offsets of the tiles (column-tile major: tile = ct*nrt + rt)
   u32* t_wgpiece = nullptr;      // nwg+1: pieces of workgroup w
+  u32 tile_r = 4096, tile_c = 4096;   // rows / columns per tile (<= TILE_DIM), chosen at ingest (tile_geometry)
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile
   // ---- host metadata
@@ -213,4 +214,6 @@ static inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
 
 // 2-D tiled packed COO (klr_mat.hip build_tiled, klr_sweep.hip k_sweep_coo)
 static const u32 TILE_BITS = 12;
-static const u32 TILE_DIM = 1u << TILE_BITS;   // 4096 rows x 4096 columns: 32 KiB of s + 32 KiB of g in LDS
+static const u32 TILE_DIM = 1u << TILE_BITS;   // at most 4096 rows x 4096 columns per tile: 32 KiB of s + 32 KiB of g in LDS
+// rows / columns per tile and the tile grid for an n x dim shard swept by nwg workgroups
+void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt, i64* nct);

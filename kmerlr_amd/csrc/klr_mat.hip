@@ -45,7 +45,7 @@ extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows
                                int64_t* padded_entries, int* lanes_per_segment, int* value_bytes) {
   if (!mat) return klr_fail(nullptr, KLR_EINVAL, "mat is NULL");
   if (tiled) *tiled = mat->tiled ? 1 : 0;
-  if (tile_rows) *tile_rows = mat->tiled ? (int64_t)TILE_DIM : mat->n;
+  if (tile_rows) *tile_rows = mat->tiled ? (int64_t)mat->tile_r : mat->n;
   if (nseg) *nseg = mat->tiled ? (int64_t)mat->npiece : mat->nchunks;
   if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * 4 : mat->nnz_pad;
   if (lanes_per_segment) *lanes_per_segment = mat->tiled ? 0 : mat->group;
@@ -99,11 +99,34 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
   const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
   std::vector<u32> piece; piece.reserve((size_t)(nwg + nct) * 4);
   std::vector<u32> wgp((size_t)nwg + 1);
+  // cut points: every workgroup gets an equal share of what is left of the stream, snapped to a tile boundary
+  // where one lies within a few percent of a share (a workgroup that starts and ends on tile boundaries has no
+  // boundary work in mid-stream; with tile_geometry's one-tile-per-workgroup grid every cut snaps)
+  std::vector<u64> cut((size_t)nwg + 1);
+  {
+    const char* sn = getenv("KLR_CUT_SNAP");
+    const double tolf = sn ? atof(sn) : 0.08;
+    i64 t = 0;
+    cut[0] = 0;
+    for (u32 w = 1; w <= nwg; w++) {
+      const u64 prev = cut[w - 1];
+      const u64 share = ((u64)total4 - prev) / (u64)(nwg - w + 1);
+      const u64 ideal = prev + share;
+      const double tol = tolf * (double)share;
+      while (t < ntile && toff4[(size_t)t + 1] <= ideal) t++;
+      u64 c = ideal;
+      const u64 lo = toff4[(size_t)t], hi = t < ntile ? toff4[(size_t)t + 1] : (u64)total4;
+      if (lo > prev && (double)(ideal - lo) <= tol && (ideal - lo) <= (hi - ideal)) c = lo;
+      else if ((double)(hi - ideal) <= tol) c = hi;
+      cut[w] = std::max(c, prev);
+    }
+    cut[nwg] = (u64)total4;
+  }
   {
     i64 tile = 0;
     for (u32 w = 0; w < nwg; w++) {
       wgp[w] = (u32)(piece.size() / 4);
-      const u64 q0 = (u64)total4 * w / nwg, q1 = (u64)total4 * (w + 1) / nwg;
+      const u64 q0 = cut[w], q1 = cut[w + 1];
       u64 q = q0;
       while (q < q1) {
         while (toff4[(size_t)tile + 1] <= q) tile++;
@@ -150,20 +173,40 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
 // 2-D tiled packed COO stream for the full-width sweep.  Built when every value is a non-negative
 // integer (k-mer counts) and the matrix is large enough for the sweep to be bandwidth bound;
 // otherwise the plain CSC kernel is used.
-//   tile (rt, ct): rows [rt*4096, +4096) x columns [ct*4096, +4096); tiles are stored COLUMN-TILE major
+//   tile (rt, ct): rows [rt*RT, +RT) x columns [ct*CT, +CT), RT, CT <= 4096 (tile_geometry); tiles are stored COLUMN-TILE major
 //            (tile id = ct*nrt + rt) so a workgroup walks down one column tile, reloading only the s tile,
 //            and writes its 4096 column sums once per column tile it touches
-//   entry  = (count:8 << 24) | (col & 4095) << 12 | (row & 4095); counts > 255 are split into several
+//   entry  = (count:8 << 24) | (col - ct*CT) << 12 | (row - rt*RT); counts > 255 are split into several
 //            entries (the sweep is additive); column 0 (bias, all ones) is not stored
 //   order  = row-major inside a tile (so consecutive entries share the row -> LDS broadcast reads of s
 //            and distinct columns -> few same-address LDS atomics); every tile padded to 4 entries
 //   pieces = the entry stream cut into nwg equal parts (one per workgroup), each part cut where the
 //            column tile changes; a piece produces one 4096-wide int64 partial column-sum vector
 // =================================================================================================
+// Tile geometry.  A tile is at most 4096 x 4096 (12-bit offsets in an entry, 32 KiB + 32 KiB of LDS).  Columns:
+// the fewest strips that cover dim, equally wide.  Rows: if the matrix is small enough for one tile per
+// workgroup (nrt_min * nct <= nwg), as many equally tall row tiles as give one tile per workgroup -- then a
+// workgroup starts and ends on tile boundaries and streams its whole part without boundary work in between
+// (configs[2]: 30 x 17 tiles of 3334 x 3856 for 512 workgroups); otherwise the tallest tiles.
+void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt_out, i64* nct_out) {
+  i64 nct = std::max<i64>(1, ceil_div(dim, (i64)TILE_DIM));
+  const i64 CT = std::max<i64>(1, ceil_div(dim, nct));
+  nct = ceil_div(dim, CT);
+  const i64 nrt_min = std::max<i64>(1, ceil_div(n, (i64)TILE_DIM));
+  i64 nrt = nrt_min;
+  if (nrt_min * nct <= (i64)nwg) nrt = std::max<i64>(nrt_min, (i64)nwg / nct);
+  i64 RT = ceil_div(std::max<i64>(n, 1), nrt);
+  RT = std::min<i64>((RT + 1) & ~(i64)1, (i64)TILE_DIM);      // even: the s tile is read with 16-byte loads
+  nrt = std::max<i64>(1, ceil_div(n, RT));
+  *tile_r = (u32)RT; *tile_c = (u32)CT; *nrt_out = nrt; *nct_out = nct;
+}
+
 static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* col, const double* val) {
   const i64 n = m->n, dim = m->dim;
   if (n < 2048 || m->nnz < (1 << 20)) return KLR_OK;          // small: plain kernel
-  const i64 nrt = ceil_div(n, (i64)TILE_DIM), nct = ceil_div(dim, (i64)TILE_DIM);
+  i64 nrt, nct;
+  tile_geometry(n, dim, (u32)std::max(2, 2 * ctx->n_cu), &m->tile_r, &m->tile_c, &nrt, &nct);
+  const i64 RT = m->tile_r, CT = m->tile_c;
   const i64 ntile = nrt * nct;
   if (ntile >= (i64)1 << 31) return KLR_OK;
   // Tile order.  Row-tile major: a workgroup crossing a tile boundary keeps its s tile and starts a new
@@ -185,14 +228,14 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
       for (i64 rt = t; rt < nrt; rt += T) {
         u64* l = tlen.data();
-        const i64 r0 = rt * TILE_DIM, r1 = std::min<i64>(n, r0 + TILE_DIM);
+        const i64 r0 = rt * RT, r1 = std::min<i64>(n, r0 + RT);
         for (i64 a = rowptr[r0]; a < rowptr[r1]; a++) {
           const double v = val[a];
           if (!(v >= 0.0 && v <= 16777216.0 && v == (double)(u32)v)) { bad[t] = 1; return; }
           const i64 c = col[a];
           if (c == 0) continue;
           const u32 iv = (u32)v;
-          l[(size_t)tix(rt, c >> TILE_BITS)] += (iv + 254u) / 255u;       // 0 -> no entry
+          l[(size_t)tix(rt, c / CT)] += (iv + 254u) / 255u;               // 0 -> no entry
           colsum[t][(size_t)c] += v;
         }
       }
@@ -216,14 +259,15 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
       std::vector<u64> cur((size_t)nct);
       for (i64 rt = t; rt < nrt; rt += T) {
         for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)tix(rt, ct)] * 4;
-        const i64 r0 = rt * TILE_DIM, r1 = std::min<i64>(n, r0 + TILE_DIM);
+        const i64 r0 = rt * RT, r1 = std::min<i64>(n, r0 + RT);
         for (i64 i = r0; i < r1; i++)
           for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
             const i64 c = col[a];
             if (c == 0) continue;
             u32 iv = (u32)val[a];
-            const u32 base = (((u32)c & (TILE_DIM - 1)) << TILE_BITS) | (u32)(i - r0);
-            u64& cu = cur[(size_t)(c >> TILE_BITS)];
+            const i64 ct = c / CT;
+            const u32 base = ((u32)(c - ct * CT) << TILE_BITS) | (u32)(i - r0);
+            u64& cu = cur[(size_t)ct];
             while (iv > 0) { const u32 q = std::min(iv, 255u); ent[cu++] = (q << 24) | base; iv -= q; }
           }
       }

@@ -305,14 +305,26 @@ template <int ABL>
 __device__ __forceinline__ void coo_consume_abl(const u32 w, const i64* __restrict__ sS, unsigned long long* __restrict__ sG,
                                                 unsigned long long& sink) {
   const u32 row = w & (TILE_DIM - 1), col = (w >> TILE_BITS) & (TILE_DIM - 1), v = w >> 24;
-  if (ABL == 1) { sink += (unsigned long long)sS[row] * (unsigned long long)v + col; }            // no atomics
+  if (ABL == 4) { atomicAdd(&sG[col], (unsigned long long)sS[row]); }                             // no multiply
+  else if (ABL == 3) { sink += w; }                                                                    // stream only
+  else if (ABL == 1) { sink += (unsigned long long)sS[row] * (unsigned long long)v + col; }       // no atomics
   else { atomicAdd(&sG[col], (unsigned long long)(v + row)); }                                    // no s gather
+}
+
+template <bool NT>
+__device__ __forceinline__ uint4 coo_load(const uint4* __restrict__ ent4, u32 q) {
+  if (NT) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ent4) + q);
+    return make_uint4(tt.x, tt.y, tt.z, tt.w);
+  }
+  return ent4[q];
 }
 
 template <int THREADS, int UNROLL, bool NT, int ABL = 0>
 __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__ ent4, const uint4* __restrict__ piece,
                                                        const u32* __restrict__ wgpiece, const u32* __restrict__ tileq,
-                                                       u32 nrt, u32 nct_or0, i64 n, const i64* __restrict__ S,
+                                                       u32 nrt, u32 nct_or0, u32 RT, i64 n, const i64* __restrict__ S,
                                                        i64* __restrict__ part) {
   extern __shared__ unsigned long long coo_lds[];
   i64* sS = (i64*)coo_lds;
@@ -334,13 +346,13 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__
       if (q0 >= q1) continue;                           // empty tile
       const u32 rt = nct_or0 ? t / nct_or0 : t % nrt;   // row-tile major / column-tile major
       if (rt != cur_rt) {
-        const i64 r0 = (i64)rt * TILE_DIM;
+        const i64 r0 = (i64)rt * RT;                    // RT is even: 16-byte aligned
         __syncthreads();                                // the previous s tile is no longer read
-        if (r0 + TILE_DIM <= n) {                       // full tile: 16-byte loads
+        if (r0 + RT <= n) {                             // full tile: 16-byte loads
           const longlong2* src = reinterpret_cast<const longlong2*>(S + r0);
-          for (u32 i = tid; i < TILE_DIM / 2; i += THREADS) reinterpret_cast<longlong2*>(sS)[i] = src[i];
+          for (u32 i = tid; i < RT / 2; i += THREADS) reinterpret_cast<longlong2*>(sS)[i] = src[i];
         } else {
-          for (u32 i = tid; i < TILE_DIM; i += THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
+          for (u32 i = tid; i < RT; i += THREADS) sS[i] = (r0 + i < n) ? S[r0 + i] : 0;
         }
         cur_rt = rt;
       }
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__
         }
       }
     }
-    if (ABL == 1) sG[tid] += sink;
+    if (ABL == 1 || ABL == 3) sG[tid] += sink;
     __syncthreads();
     i64* out = part + (i64)p * TILE_DIM;
     for (u32 i = tid; i < TILE_DIM; i += THREADS) {
@@ -393,7 +405,7 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
     attr_done = true;
   }
   hipLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL>), dim3(mat->nwg), dim3(THREADS), lds_bytes, ctx->stream, (const uint4*)mat->t_ent,
-                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->t_tileq, mat->nrt, mat->rt_major ? mat->nct : 0u, mat->n, S, part);
+                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->t_tileq, mat->nrt, mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->n, S, part);
   return KLR_OK;
 }
 
@@ -418,6 +430,10 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
     case 14: return launch_sweep_coo<1024, 1, false>(ctx, mat, S, part);
     case 15: return launch_sweep_coo<768, 1, true>(ctx, mat, S, part);
     case 16: return launch_sweep_coo<512, 4, false>(ctx, mat, S, part);
+    case 21: return launch_sweep_coo<1024, 1, true, 1>(ctx, mat, S, part);     // ablations of the shipped shape: no atomics
+    case 22: return launch_sweep_coo<1024, 1, true, 2>(ctx, mat, S, part);     //   no s gather
+    case 26: return launch_sweep_coo<1024, 1, true, 3>(ctx, mat, S, part);     //   stream only
+    case 50: return launch_sweep_coo<1024, 1, true, 4>(ctx, mat, S, part);     //   no multiply
     default: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part);      // shipped: 32 waves/CU, nt loads
   }
 }
@@ -430,7 +446,7 @@ extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
 // 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile, LDS combines
 __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
                                                      const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
-                                                     const i64* __restrict__ rowblk, i64 nrowblk) {
+                                                     const i64* __restrict__ rowblk, i64 nrowblk, u32 CT) {
   __shared__ i64 sh[4][256];
   if (blockIdx.x == gridDim.x - 1) {
     // last block: bias halves, loss limbs and the non-finite count from the row pass's block partials
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
   const i64 j = (i64)blockIdx.x * 256 + cx;
   i64 v = 0;
   if (j < dim) {
-    const u32 ct = (u32)(j >> TILE_BITS), c = (u32)(j & (TILE_DIM - 1));
+    const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
     const u32 k1 = ctptr[ct + 1];
     for (u32 k = ctptr[ct] + ly; k < k1; k += 4) v += part[(i64)ctlist[k] * TILE_DIM + c];
   }
@@ -592,7 +608,7 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
     ctx->prof_ev.emplace_back(e0, e1);
   }
   hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256) + 1), dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist,
-                     dim, ibuf, (const i64*)rowblk, nrowblk);
+                     dim, ibuf, (const i64*)rowblk, nrowblk, mat->tile_c);
   KLR_HIP(ctx, hipGetLastError());
   KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
   hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,

@@ -285,7 +285,7 @@ def test_sharded_partials_sum_to_whole(ctx, synth_small):
 # ---------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def synth_tiled():
-    # 3 row tiles (8192 rows each, last one ragged), long bias segments, ~1.6e6 nonzeros
+    # many row tiles (the geometry gives one tile per workgroup here), ragged last tile, ~1.6e6 nonzeros
     x, labels = O.synth_csr(20261004, 0, 20000, 20000, 3000, 80, 24)
     return x, labels
 
@@ -294,7 +294,7 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled):
     x, labels = synth_tiled
     m = upload(ctx, x, labels)
     lay = m.layout()
-    assert lay["tiled"] and lay["tile_rows"] == 4096 and lay["value_bytes"] == 1
+    assert lay["tiled"] and 0 < lay["tile_rows"] <= 4096 and lay["tile_rows"] % 2 == 0 and lay["value_bytes"] == 1
     cw = O.class_weights(labels)
     rng = np.random.default_rng(1)
     for k in (0, 40):

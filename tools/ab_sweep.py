@@ -11,7 +11,7 @@ import kmerlr_amd as K  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 5, 6, 7]
-n, m, draws, N = 100000, 65536, 993, 100
+n, m, draws, N = int(os.environ.get('AB_N', 100000)), int(os.environ.get('AB_M', 65536)), 993, 100
 ctx = K.Context(0)
 rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
 mats = {}
@@ -35,7 +35,7 @@ for r in range(rounds + 1):
             nl, ms = ctx.prof_read(reset=True)
             if r > 0:
                 res[(o, v)].append(ms / nl * 1e3)
-names = {14: "1024x1", 15: "768x1 nt", 8: "no-atomic", 9: "no-gather", 10: "512x2 nt", 11: "1024x2 nt", 12: "1024x1 nt", 13: "512x1 nt", 0: "512x4", 1: "512x4 nt", 2: "512x8", 3: "512x8 nt", 4: "1024x4", 5: "1024x4 nt", 6: "1024x2", 7: "256x8"}
+names = {0: "shipped", 1: "512x4 nt", 2: "512x8", 3: "512x8 nt", 4: "1024x4", 5: "1024x4 nt", 6: "1024x2", 7: "256x8", 8: "512 noatom", 9: "512 nogath", 10: "512x2 nt", 11: "1024x2 nt", 12: "1024x1 nt", 13: "512x1 nt", 14: "1024x1", 15: "768x1 nt", 16: "512x4", 21: "noatom", 22: "nogather", 26: "stream", 50: "nomul"}
 for v in variants:
     for o in mats:
         a = np.array(res[(o, v)])
