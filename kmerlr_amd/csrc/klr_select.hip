@@ -183,11 +183,11 @@ static inline double key_to_double(u64 k) { double d; memcpy(&d, &k, 8); return 
 
 // ---------------------------------------------------------------------------------------------------
 // fast path: ONE coarse histogram over the top 13 key bits (exponent + 2 mantissa bits) brackets the
-// K-th largest |g|; everything at or above the bracketing bin (usually K + a few hundred keys) is
-// compacted and sorted by one workgroup.  4 launches instead of 25.  Falls back to the exact 8-pass
-// radix select when the bracket holds more than FAST_CAP keys (e.g. K reaches into the zeros).
+// K-th largest |g|; a second-level histogram (next 12 bits) inside the bracketing bin trims the candidates to
+// K + a few, which one workgroup sorts in LDS.  One launch (k_fast_select) instead of 25.  Falls back to the
+// exact 8-pass radix select when more than FAST_CAP candidates remain (e.g. K reaches into the zeros).
 // ---------------------------------------------------------------------------------------------------
-#define FAST_CAP 8192
+#define FAST_CAP 4096
 
 struct FastState {
   u64 lowkey;        // keys >= lowkey are candidates
@@ -212,108 +212,36 @@ __global__ __launch_bounds__(256) void k_fast_keys_hist(const double* __restrict
   for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
 
-__global__ __launch_bounds__(1024) void k_fast_pickbin(u32* __restrict__ hist, u32 K, FastState* st) {
-  // suffix sums over 8192 bins: thread t owns bins [8t, 8t+8)
+// control block + histograms of the fast path (all zero between calls: the last workgroup of k_fast_select
+// re-zeroes what it used)
+#define FINE_BINS 4096
+#define FINE_SHIFT 38
+#define GCAND_CAP 32768
+struct FastCtl { u32 ticket, cursor, pad[14]; };
+
+// Fast path in ONE launch.  Every workgroup: (1) brackets the K-th largest key in the coarse histogram
+// (top 13 key bits), (2) compacts its slice of the keys at or above the bracketing bin into a global candidate
+// list and counts the keys inside the bracketing bin in a second-level histogram (next 12 bits), (3) takes a
+// ticket.  The last workgroup: (4) trims the candidates with the second-level histogram to K + a few,
+// (5) sorts them in LDS by (|g| desc, column asc) -- rank sort up to 1024, bitonic above --, (6) writes the top K,
+// v = the N-th key and w = the largest key below v, and re-zeroes the histograms.
+__global__ __launch_bounds__(1024) void k_fast_select(u32* __restrict__ hist, u32* __restrict__ fine, FastCtl* __restrict__ ctl,
+                                                      const u64* __restrict__ keys, i64 m, u32 K, u32 Nth,
+                                                      Cand* __restrict__ gcand, FastState* st, Cand* __restrict__ out,
+                                                      const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
+  extern __shared__ Cand sc[];                    // FAST_CAP candidates
   __shared__ u32 ssum[1024];
+  __shared__ u32 fh[FINE_BINS];
+  __shared__ unsigned long long s_low, wbest;
+  __shared__ u32 s_n, s_above, s_last, s_cursor, s_fbin, s_nt;
   const int t = threadIdx.x;
+  // ---- (1) bracketing bin: thread t owns bins [8t, 8t+8); inclusive suffix scan over the thread sums
   u32 h[8], loc = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; hist[t * 8 + i] = 0; }
+  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; }
   ssum[t] = loc;
-  __syncthreads();
-  // inclusive suffix scan: ssum[t] = sum_{u >= t}
-  for (int o = 1; o < 1024; o <<= 1) {
-    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
-    __syncthreads();
-    ssum[t] += v;
-    __syncthreads();
-  }
-  const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;      // keys in bins of higher threads
-  if (above < K && ssum[t] >= K) {
-    // the K-th largest lies in one of this thread's 8 bins
-    u32 cum = above;
-    int b = 7;
-    for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
-    const u32 nc = cum + h[b];
-    st->lowkey = ((u64)(t * 8 + b)) << FAST_SHIFT;
-    st->ncand = nc;
-    st->cursor = 0;
-    st->fallback = nc > FAST_CAP ? 1u : 0u;
-    st->wfound = 0; st->vkey = 0; st->wkey = 0;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_fast_compact(const u64* __restrict__ keys, i64 m, FastState* st, Cand* __restrict__ cand) {
-  if (st->fallback) return;
-  const u64 low = st->lowkey;
-  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < m; j += (i64)gridDim.x * 256) {
-    const u64 k = keys[j];
-    if (k >= low) {
-      const u32 pos = atomicAdd(&st->cursor, 1u);
-      if (pos < FAST_CAP) { cand[pos].key = k; cand[pos].idx = (u32)j; cand[pos].pad = 0; }
-    }
-  }
-}
-
-// one workgroup: bitonic sort (LDS) of the <= FAST_CAP candidates by (|g| desc, column asc); v and w
-__global__ __launch_bounds__(1024) void k_fast_sort(Cand* __restrict__ c, u32 K, u32 Nth, FastState* st, Cand* __restrict__ out) {
-  extern __shared__ Cand sc[];
-  if (st->fallback) return;
-  const u32 n = st->ncand;
-  u32 P = 2; while (P < n) P <<= 1;
-  for (u32 i = threadIdx.x; i < P; i += 1024) {
-    if (i < n) sc[i] = c[i];
-    else { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
-  }
-  __syncthreads();
-  for (u32 size = 2; size <= P; size <<= 1) {
-    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-      for (u32 t = threadIdx.x; t < P / 2; t += 1024) {
-        const u32 lo = 2 * t - (t & (stride - 1));
-        const u32 hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        Cand a = sc[lo], b = sc[hi];
-        const bool swap = up ? cand_before(b, a) : cand_before(a, b);
-        if (swap) { sc[lo] = b; sc[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  for (u32 i = threadIdx.x; i < K && i < n; i += 1024) out[i] = sc[i];
-  __shared__ unsigned long long wbest;
-  if (threadIdx.x == 0) wbest = 0ull;
-  __syncthreads();
-  const u64 vkey = (Nth >= 1 && Nth <= n) ? sc[Nth - 1].key : 0ull;
-  // largest candidate key strictly below v (sorted: first position whose key < v)
-  for (u32 i = threadIdx.x; i < n; i += 1024)
-    if (sc[i].key < vkey && (i == 0 || sc[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sc[i].key | (1ull << 63));
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    st->vkey = vkey;
-    st->wfound = (wbest >> 63) ? 1u : 0u;
-    st->wkey = wbest & ~(1ull << 63);
-  }
-}
-
-// fused pick-bin + compact + sort for m <= FUSED_MAX_M: one workgroup does the three steps of the fast path
-// back to back (saves two kernel boundaries; the key scan is m/1024 coalesced loads per lane)
-#define FUSED_MAX_M 262144
-__global__ __launch_bounds__(1024) void k_fast_select_small(u32* __restrict__ hist, const u64* __restrict__ keys, i64 m,
-                                                            u32 K, u32 Nth, FastState* st, Cand* __restrict__ out,
-                                                            const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
-  extern __shared__ Cand sc[];
-  __shared__ u32 ssum[1024];
-  __shared__ unsigned long long s_low;
-  __shared__ u32 s_ncand, s_cursor;
-  __shared__ unsigned long long wbest;
-  const int t = threadIdx.x;
-  if (t == 0 && extra_src) *extra_dst = *extra_src;     // a caller scalar (the sweep's loss) rides in the same block
-  // ---- pick the bracketing bin (as k_fast_pickbin)
-  u32 h[8], loc = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; hist[t * 8 + i] = 0; }
-  ssum[t] = loc;
-  if (t == 0) { s_cursor = 0; wbest = 0ull; s_ncand = 0; s_low = 0ull; }
+  for (int i = t; i < FINE_BINS; i += 1024) fh[i] = 0u;
+  if (t == 0) { s_low = 0ull; s_n = 0; s_above = 0; s_cursor = 0; wbest = 0ull; }
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {
     const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
@@ -321,54 +249,126 @@ __global__ __launch_bounds__(1024) void k_fast_select_small(u32* __restrict__ hi
     ssum[t] += v;
     __syncthreads();
   }
-  const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
-  if (above < K && ssum[t] >= K) {
-    u32 cum = above;
-    int b = 7;
-    for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
-    s_low = ((u64)(t * 8 + b)) << FAST_SHIFT;
-    s_ncand = cum + h[b];
+  {
+    const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
+    if (above < K && ssum[t] >= K) {
+      u32 cum = above;
+      int b = 7;
+      for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
+      s_low = ((u64)(t * 8 + b)) << FAST_SHIFT;
+      s_above = cum;                               // keys in bins above the bracketing bin (< K)
+      s_n = cum + h[b];                            // keys at or above it (>= K)
+    }
   }
   __syncthreads();
-  const u32 n = s_ncand;
+  const u32 n = s_n;
   const u64 low = s_low;
-  if (n > FAST_CAP) {                                    // too many candidates: the host falls back
-    if (t == 0) { st->lowkey = low; st->ncand = n; st->cursor = 0; st->fallback = 1; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
+  const bool too_many = n > GCAND_CAP || n == 0;
+  // ---- (2) compact this workgroup's slice
+  if (!too_many) {
+    const i64 per = (m + gridDim.x - 1) / gridDim.x;
+    const i64 j0 = per * blockIdx.x, j1 = min(m, j0 + per);
+    for (i64 j = j0 + t; j < j1; j += 1024) {
+      const u64 k = keys[j];
+      if (k >= low) {
+        const u32 pos = atomicAdd(&ctl->cursor, 1u);
+        gcand[pos].key = k; gcand[pos].idx = (u32)j; gcand[pos].pad = 0;
+        if ((k >> FAST_SHIFT) == (low >> FAST_SHIFT)) atomicAdd(&fh[(u32)(k >> FINE_SHIFT) & (FINE_BINS - 1)], 1u);
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < FINE_BINS; i += 1024) if (fh[i]) atomicAdd(&fine[i], fh[i]);
+  }
+  // ---- (3) ticket
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_last = (atomicAdd(&ctl->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (t == 0 && extra_src) *extra_dst = *extra_src;     // a caller scalar (the sweep's loss) rides in the same block
+  // ---- (4) second-level threshold: the largest fine bin f with above + #(fine bins >= f) >= K
+  u32 fv[4], floc = 0;
+  if (!too_many) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { fv[i] = fine[t * 4 + i]; floc += fv[i]; }
+  }
+  ssum[t] = floc;
+  if (t == 0) { s_fbin = 0; s_nt = n; }
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
+    __syncthreads();
+    ssum[t] += v;
+    __syncthreads();
+  }
+  if (!too_many) {
+    const u32 need = K - s_above;                  // >= 1 keys wanted from the bracketing bin
+    const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
+    if (above < need && ssum[t] >= need) {
+      u32 cum = above;
+      int b = 3;
+      for (; b > 0; b--) { if (cum + fv[b] >= need) break; cum += fv[b]; }
+      s_fbin = (u32)(t * 4 + b);
+      s_nt = s_above + cum + fv[b];
+    }
+  }
+  __syncthreads();
+  const u32 nt = s_nt;
+  const u64 lowfine = low | ((u64)s_fbin << FINE_SHIFT);
+  // re-zero what this call used (every other workgroup is done with it)
+#pragma unroll
+  for (int i = 0; i < 8; i++) hist[t * 8 + i] = 0u;
+#pragma unroll
+  for (int i = 0; i < 4; i++) fine[t * 4 + i] = 0u;
+  if (t == 0) { ctl->ticket = 0u; ctl->cursor = 0u; }
+  if (too_many || nt > FAST_CAP) {                 // the host falls back to the exact radix select
+    if (t == 0) { st->lowkey = low; st->ncand = too_many ? n : nt; st->cursor = 0; st->fallback = 1; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
     return;
   }
-  // ---- compact (order irrelevant: sorted next)
-  for (i64 j = t; j < m; j += 1024) {
-    const u64 k = keys[j];
-    if (k >= low) {
-      const u32 pos = atomicAdd(&s_cursor, 1u);
-      if (pos < FAST_CAP) { sc[pos].key = k; sc[pos].idx = (u32)j; sc[pos].pad = 0; }
-    }
+  // ---- (5) trimmed candidates into LDS, sort
+  for (u32 i = t; i < n; i += 1024) {
+    const Cand c = gcand[i];
+    if (c.key >= lowfine) { const u32 pos = atomicAdd(&s_cursor, 1u); sc[pos] = c; }
   }
   __syncthreads();
-  u32 P = 2; while (P < n) P <<= 1;
-  for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
-  __syncthreads();
-  // ---- bitonic sort by (|g| desc, column asc)
-  for (u32 size = 2; size <= P; size <<= 1) {
-    for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-      for (u32 q = t; q < P / 2; q += 1024) {
-        const u32 lo = 2 * q - (q & (stride - 1));
-        const u32 hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        Cand a = sc[lo], b = sc[hi];
-        const bool swap = up ? cand_before(b, a) : cand_before(a, b);
-        if (swap) { sc[lo] = b; sc[hi] = a; }
+  Cand* sorted = sc;
+  if (nt <= 1024) {
+    // rank sort: (key, column) pairs are distinct, so the ranks are a permutation
+    Cand my; u32 rank = 0;
+    if ((u32)t < nt) {
+      my = sc[t];
+      for (u32 j = 0; j < nt; j++) rank += cand_before(sc[j], my) ? 1u : 0u;
+    }
+    sorted = sc + 1024;
+    if ((u32)t < nt) sorted[rank] = my;
+    __syncthreads();
+  } else {
+    u32 P = 2; while (P < nt) P <<= 1;
+    for (u32 i = nt + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
+    __syncthreads();
+    for (u32 size = 2; size <= P; size <<= 1) {
+      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+        for (u32 q = t; q < P / 2; q += 1024) {
+          const u32 lo = 2 * q - (q & (stride - 1));
+          const u32 hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          Cand a = sc[lo], b = sc[hi];
+          const bool swap = up ? cand_before(b, a) : cand_before(a, b);
+          if (swap) { sc[lo] = b; sc[hi] = a; }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
-  for (u32 i = t; i < K && i < n; i += 1024) out[i] = sc[i];
-  const u64 vkey = (Nth >= 1 && Nth <= n) ? sc[Nth - 1].key : 0ull;
-  for (u32 i = t; i < n; i += 1024)
-    if (sc[i].key < vkey && (i == 0 || sc[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sc[i].key | (1ull << 63));
+  // ---- (6) outputs
+  for (u32 i = t; i < K && i < nt; i += 1024) out[i] = sorted[i];
+  const u64 vkey = (Nth >= 1 && Nth <= nt) ? sorted[Nth - 1].key : 0ull;
+  for (u32 i = t; i < nt; i += 1024)
+    if (sorted[i].key < vkey && (i == 0 || sorted[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sorted[i].key | (1ull << 63));
   __syncthreads();
   if (t == 0) {
-    st->lowkey = low; st->ncand = n; st->cursor = n; st->fallback = 0;
+    st->lowkey = lowfine; st->ncand = nt; st->cursor = nt; st->fallback = 0;
     st->vkey = vkey; st->wfound = (wbest >> 63) ? 1u : 0u; st->wkey = wbest & ~(1ull << 63);
   }
 }
@@ -413,10 +413,11 @@ static int select_exact_device(klr_ctx* ctx, const double* g_dev, u64* keys, boo
 int sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist) {
   char* fm;
   KLR_TRY(ws_get(ctx, WS_SEL_KEYS, (size_t)std::max<i64>(m, 1) * sizeof(u64), (void**)keys));
-  const size_t fm_bytes = 64 + FAST_BINS * sizeof(u32);
+  // [FastCtl 64 B | coarse histogram | second-level histogram]
+  const size_t fm_bytes = sizeof(FastCtl) + (FAST_BINS + FINE_BINS) * sizeof(u32);
   KLR_TRY(ws_get(ctx, WS_MASK, fm_bytes, (void**)&fm));
-  *hist = (u32*)(fm + 64);
-  if (ctx->sel_hist_zeroed != (void*)*hist) {          // the pick kernel re-zeroes the bins after use
+  *hist = (u32*)(fm + sizeof(FastCtl));
+  if (ctx->sel_hist_zeroed != (void*)*hist) {          // k_fast_select re-zeroes what it used
     KLR_HIP(ctx, hipMemsetAsync(fm, 0, fm_bytes, ctx->stream));
     ctx->sel_hist_zeroed = (void*)*hist;
   }
@@ -435,30 +436,27 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     hipStream_t st = ctx->stream;
     u64* keys; u32* hist; Cand* cand;
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
-    // WS_TMP0: [FAST_CAP scratch candidates | 64 B: FastState (40 B) + caller scalar | K sorted candidates]
-    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(FAST_CAP + K) * sizeof(Cand) + 64, (void**)&cand));
-    char* stage = (char*)(cand + FAST_CAP);
+    // WS_TMP0: [GCAND_CAP compacted candidates | 64 B: FastState (40 B) + caller scalar | K sorted candidates]
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + K) * sizeof(Cand) + 64, (void**)&cand));
+    char* stage = (char*)(cand + GCAND_CAP);
     FastState* fs = (FastState*)stage;
     double* extra_dst = (double*)(stage + 48);
     Cand* out = (Cand*)(stage + 64);
-    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
-    if (!keys_hist_ready) hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
+    if (!keys_hist_ready) {
+      const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
+      hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
+    }
     static bool attr = false;
     if (!attr) {
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_sort, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(FAST_CAP * sizeof(Cand))));
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(FAST_CAP * sizeof(Cand))));
       attr = true;
     }
-    if (m <= FUSED_MAX_M) {
-      hipLaunchKernelGGL(k_fast_select_small, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, keys, m, (u32)K, (u32)N,
-                         fs, out, extra_src, extra_dst);
-    } else {
-      hipLaunchKernelGGL(k_fast_pickbin, dim3(1), dim3(1024), 0, st, hist, (u32)K, fs);
-      hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(256), 0, st, keys, m, fs, cand);
-      hipLaunchKernelGGL(k_fast_sort, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, cand, (u32)K, (u32)N, fs, out);
-      if (extra_src) KLR_HIP(ctx, hipMemcpyAsync(extra_dst, extra_src, sizeof(double), hipMemcpyDeviceToDevice, st));
+    {
+      FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+      const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 128));
+      hipLaunchKernelGGL(k_fast_select, dim3(grid), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, keys, m,
+                         (u32)K, (u32)N, cand, fs, out, extra_src, extra_dst);
     }
     KLR_HIP(ctx, hipGetLastError());
     // ONE device->host copy: [state | scalar | K candidates] into pinned memory
