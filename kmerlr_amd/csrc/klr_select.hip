@@ -373,6 +373,142 @@ __global__ __launch_bounds__(1024) void k_fast_select(u32* __restrict__ hist, u3
   }
 }
 
+// The same selection by ONE workgroup, for m <= ONE_WG_MAX_M: no tickets and no device-scope fences (a fence
+// writes back and invalidates the XCD's L2, which costs more than the rest of the kernel at this size).  One pass
+// over the keys compacts everything at or above the bracketing bin into LDS; the second-level histogram, the trim
+// and the rank sort all work on that LDS list.
+#define ONE_WG_MAX_M 262144
+__global__ __launch_bounds__(1024) void k_fast_select_one(u32* __restrict__ hist, const u64* __restrict__ keys, i64 m, u32 K, u32 Nth,
+                                                          FastState* st, Cand* __restrict__ out,
+                                                          const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
+  extern __shared__ Cand sc[];                    // [FAST_CAP compacted | 1024 trimmed | 1024 sorted]
+  __shared__ u32 ssum[1024];
+  __shared__ u32 fh[FINE_BINS];
+  __shared__ unsigned long long s_low, wbest;
+  __shared__ u32 s_n, s_above, s_cursor, s_cur2, s_fbin, s_nt;
+  const int t = threadIdx.x;
+  if (t == 0 && extra_src) *extra_dst = *extra_src;
+  u32 h[8], loc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; hist[t * 8 + i] = 0u; }
+  ssum[t] = loc;
+  for (int i = t; i < FINE_BINS; i += 1024) fh[i] = 0u;
+  if (t == 0) { s_low = 0ull; s_n = 0; s_above = 0; s_cursor = 0; s_cur2 = 0; wbest = 0ull; }
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
+    __syncthreads();
+    ssum[t] += v;
+    __syncthreads();
+  }
+  {
+    const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
+    if (above < K && ssum[t] >= K) {
+      u32 cum = above;
+      int b = 7;
+      for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
+      s_low = ((u64)(t * 8 + b)) << FAST_SHIFT;
+      s_above = cum;
+      s_n = cum + h[b];
+    }
+  }
+  __syncthreads();
+  const u32 n = s_n;
+  const u64 low = s_low;
+  if (n > FAST_CAP || n == 0) {
+    if (t == 0) { st->lowkey = low; st->ncand = n; st->cursor = 0; st->fallback = 1; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
+    return;
+  }
+  // one pass over the keys, 4 independent loads per trip
+  for (i64 j = t; j < m; j += 4096) {
+    u64 k[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) k[u] = (j + u * 1024 < m) ? keys[j + u * 1024] : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k[u] >= low && j + u * 1024 < m) {
+        const u32 pos = atomicAdd(&s_cursor, 1u);
+        sc[pos].key = k[u]; sc[pos].idx = (u32)(j + u * 1024); sc[pos].pad = 0;
+        if ((k[u] >> FAST_SHIFT) == (low >> FAST_SHIFT)) atomicAdd(&fh[(u32)(k[u] >> FINE_SHIFT) & (FINE_BINS - 1)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // second-level threshold
+  u32 fv[4], floc = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { fv[i] = fh[t * 4 + i]; floc += fv[i]; }
+  ssum[t] = floc;
+  if (t == 0) { s_fbin = 0; s_nt = n; }
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
+    __syncthreads();
+    ssum[t] += v;
+    __syncthreads();
+  }
+  {
+    const u32 need = K - s_above;
+    const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
+    if (above < need && ssum[t] >= need) {
+      u32 cum = above;
+      int b = 3;
+      for (; b > 0; b--) { if (cum + fv[b] >= need) break; cum += fv[b]; }
+      s_fbin = (u32)(t * 4 + b);
+      s_nt = s_above + cum + fv[b];
+    }
+  }
+  __syncthreads();
+  u32 nt = s_nt;
+  const u64 lowfine = low | ((u64)s_fbin << FINE_SHIFT);
+  Cand* sorted;
+  if (nt <= 1024) {
+    Cand* trimmed = sc + FAST_CAP;
+    sorted = sc + FAST_CAP + 1024;
+    for (u32 i = t; i < n; i += 1024) {
+      const Cand c = sc[i];
+      if (c.key >= lowfine) { const u32 pos = atomicAdd(&s_cur2, 1u); trimmed[pos] = c; }
+    }
+    __syncthreads();
+    // rank sort: (key, column) pairs are distinct, so the ranks are a permutation
+    if ((u32)t < nt) {
+      const Cand my = trimmed[t];
+      u32 rank = 0;
+      for (u32 j = 0; j < nt; j++) rank += cand_before(trimmed[j], my) ? 1u : 0u;
+      sorted[rank] = my;
+    }
+    __syncthreads();
+  } else {
+    nt = n;                                          // bitonic over everything that was compacted
+    sorted = sc;
+    u32 P = 2; while (P < n) P <<= 1;
+    for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
+    __syncthreads();
+    for (u32 size = 2; size <= P; size <<= 1) {
+      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+        for (u32 q = t; q < P / 2; q += 1024) {
+          const u32 lo = 2 * q - (q & (stride - 1));
+          const u32 hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          Cand a = sc[lo], b = sc[hi];
+          const bool swap = up ? cand_before(b, a) : cand_before(a, b);
+          if (swap) { sc[lo] = b; sc[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (u32 i = t; i < K && i < nt; i += 1024) out[i] = sorted[i];
+  const u64 vkey = (Nth >= 1 && Nth <= nt) ? sorted[Nth - 1].key : 0ull;
+  for (u32 i = t; i < nt; i += 1024)
+    if (sorted[i].key < vkey && (i == 0 || sorted[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sorted[i].key | (1ull << 63));
+  __syncthreads();
+  if (t == 0) {
+    st->lowkey = lowfine; st->ncand = nt; st->cursor = nt; st->fallback = 0;
+    st->vkey = vkey; st->wfound = (wbest >> 63) ? 1u : 0u; st->wkey = wbest & ~(1ull << 63);
+  }
+}
+
 static int select_exact_device(klr_ctx* ctx, const double* g_dev, u64* keys, bool keys_ready, i64 m, i64 K, i64 N,
                                std::vector<Cand>& hc, u64* vkey, u64* wkey) {
   hipStream_t st = ctx->stream;
@@ -450,9 +586,14 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     if (!attr) {
       KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(FAST_CAP * sizeof(Cand))));
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select_one, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((FAST_CAP + 2048) * sizeof(Cand))));
       attr = true;
     }
-    {
+    if (m <= ONE_WG_MAX_M) {
+      hipLaunchKernelGGL(k_fast_select_one, dim3(1), dim3(1024), (FAST_CAP + 2048) * sizeof(Cand), st, hist, keys, m, (u32)K, (u32)N,
+                         fs, out, extra_src, extra_dst);
+    } else {
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
       const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 128));
       hipLaunchKernelGGL(k_fast_select, dim3(grid), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, keys, m,

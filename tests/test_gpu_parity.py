@@ -155,6 +155,30 @@ def test_select_bit_exact(ctx, N):
     np.testing.assert_array_equal(b2, bo)
 
 
+@pytest.mark.parametrize("m,N,kind", [(300000, 100, "normal"), (1048576, 500, "normal"), (400000, 50, "clustered"),
+                                      (65536, 100, "clustered"), (500000, 2500, "lognormal")])
+def test_select_large_m_bit_exact(ctx, m, N, kind):
+    # m > 262144 takes the multi-workgroup selection kernel; "clustered" puts thousands of keys into the
+    # bracketing coarse bin (second-level trim / bitonic / exact fallback paths)
+    rng = np.random.default_rng(m + N)
+    if kind == "normal":
+        g = rng.normal(size=m)
+    elif kind == "lognormal":
+        g = rng.lognormal(sigma=4.0, size=m) * rng.choice([-1.0, 1.0], size=m)
+    else:
+        g = 1.0 + 1e-6 * rng.random(size=m)                   # all within one quarter-octave
+        g[rng.choice(m, size=m // 2, replace=False)] *= -1.0
+    g[rng.choice(m, size=m // 10, replace=False)] = 0.0
+    b = np.zeros(m + 1, dtype=np.uint8); b[0] = 1
+    pre = rng.choice(m, size=10, replace=False)
+    b[pre + 1] = 1
+    ok, lam, c, b2 = K.select(ctx, g, b, len(pre), N, lambda_prev=0.3, eps_lambda=0.0)
+    oko, lamo, co, bo = O.select(g, b, len(pre), N, lambda_prev=0.3, eps_lambda=0.0)
+    assert (ok, c) == (oko, co)
+    assert lam == lamo
+    np.testing.assert_array_equal(b2, bo)
+
+
 def test_select_ties_across_threshold_and_all_zero(ctx):
     # the 2N-th largest sits inside a block of ties: lowest column ids must be taken
     g = np.zeros(1000); g[200:260] = 1.0; g[5] = 2.0
