@@ -184,7 +184,7 @@ static inline double key_to_double(u64 k) { double d; memcpy(&d, &k, 8); return 
 // ---------------------------------------------------------------------------------------------------
 // fast path: ONE coarse histogram over the top 13 key bits (exponent + 2 mantissa bits) brackets the
 // K-th largest |g|; a second-level histogram (next 12 bits) inside the bracketing bin trims the candidates to
-// K + a few, which one workgroup sorts in LDS.  One launch (k_fast_select) instead of 25.  Falls back to the
+// K + a few, which one workgroup sorts in LDS.  Two launches (k_fast_compact, k_fast_finish) instead of 25.  Falls back to the
 // exact 8-pass radix select when more than FAST_CAP candidates remain (e.g. K reaches into the zeros).
 // ---------------------------------------------------------------------------------------------------
 #define FAST_CAP 4096
@@ -212,43 +212,60 @@ __global__ __launch_bounds__(256) void k_fast_keys_hist(const double* __restrict
   for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
 
-// control block + histograms of the fast path (all zero between calls: the last workgroup of k_fast_select
-// re-zeroes what it used)
+// inclusive suffix sum over the 1024 lanes of a workgroup (sum of v over lanes >= t): wave shuffles, one LDS
+// hop for the 16 wave totals, two barriers
+__device__ __forceinline__ u32 block_suffix_sum_1024(u32 v, u32* wtot /* 16 */) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  u32 x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 y = __shfl_down(x, o, 64);
+    if (lane + o < 64) x += y;
+  }
+  if (lane == 0) wtot[w] = x;                      // lane 0 holds the wave's total
+  __syncthreads();
+  u32 add = 0;
+  for (int u = w + 1; u < 16; u++) add += wtot[u];
+  __syncthreads();                                 // wtot may be reused by the caller
+  return x + add;
+}
+
+// control block + histograms of the fast path (all zero between calls: k_fast_finish re-zeroes what was used)
 #define FINE_BINS 4096
 #define FINE_SHIFT 38
 #define GCAND_CAP 32768
-struct FastCtl { u32 ticket, cursor, pad[14]; };
+struct FastCtl { u32 cursor, n, above, pad0; u64 low; u32 pad[10]; };
 
-// Fast path in ONE launch.  Every workgroup: (1) brackets the K-th largest key in the coarse histogram
-// (top 13 key bits), (2) compacts its slice of the keys at or above the bracketing bin into a global candidate
-// list and counts the keys inside the bracketing bin in a second-level histogram (next 12 bits), (3) takes a
-// ticket.  The last workgroup: (4) trims the candidates with the second-level histogram to K + a few,
-// (5) sorts them in LDS by (|g| desc, column asc) -- rank sort up to 1024, bitonic above --, (6) writes the top K,
-// v = the N-th key and w = the largest key below v, and re-zeroes the histograms.
-__global__ __launch_bounds__(1024) void k_fast_select(u32* __restrict__ hist, u32* __restrict__ fine, FastCtl* __restrict__ ctl,
-                                                      const u64* __restrict__ keys, i64 m, u32 K, u32 Nth,
-                                                      Cand* __restrict__ gcand, FastState* st, Cand* __restrict__ out,
-                                                      const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
-  extern __shared__ Cand sc[];                    // FAST_CAP candidates
-  __shared__ u32 ssum[1024];
+// Fast path, first launch (many workgroups).  Every workgroup brackets the K-th largest key in the coarse
+// histogram (top 13 key bits), then compacts its slice of the keys at or above the bracketing bin into a global
+// candidate list and counts the keys inside the bracketing bin in a second-level histogram (next 12 bits).
+// A single workgroup doing this scan is latency bound (m/1024 dependent trips to L2 per lane: 22 us at 65k
+// columns); a device-scope fence + ticket to finish in the same launch costs about as much (L2 write-back and
+// invalidate), so the sort is a second launch.
+__global__ __launch_bounds__(1024) void k_fast_compact(const u32* __restrict__ hist, u32* __restrict__ fine, FastCtl* __restrict__ ctl,
+                                                       const u64* __restrict__ keys, i64 m, u32 K, Cand* __restrict__ gcand) {
+  __shared__ u32 ssum[1024], wtot[16];
   __shared__ u32 fh[FINE_BINS];
-  __shared__ unsigned long long s_low, wbest;
-  __shared__ u32 s_n, s_above, s_last, s_cursor, s_fbin, s_nt;
+  __shared__ unsigned long long s_low;
+  __shared__ u32 s_n, s_above;
   const int t = threadIdx.x;
-  // ---- (1) bracketing bin: thread t owns bins [8t, 8t+8); inclusive suffix scan over the thread sums
+  // keys of this workgroup's slice first: their latency overlaps the bracket search
+  const i64 per = (m + gridDim.x - 1) / gridDim.x;
+  const i64 j0 = per * blockIdx.x, j1 = min(m, j0 + per);
+  u64 kk[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) kk[u] = (j0 + t + u * 1024 < j1) ? keys[j0 + t + u * 1024] : 0ull;
+  // thread t owns bins [8t, 8t+8); inclusive suffix scan over the thread sums
   u32 h[8], loc = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; }
-  ssum[t] = loc;
   for (int i = t; i < FINE_BINS; i += 1024) fh[i] = 0u;
-  if (t == 0) { s_low = 0ull; s_n = 0; s_above = 0; s_cursor = 0; wbest = 0ull; }
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
-    __syncthreads();
-    ssum[t] += v;
-    __syncthreads();
+  if (t == 0) { s_low = 0ull; s_n = 0; s_above = 0; }
+  {
+    const u32 suf = block_suffix_sum_1024(loc, wtot);
+    ssum[t] = suf;
   }
+  __syncthreads();
   {
     const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
     if (above < K && ssum[t] >= K) {
@@ -263,70 +280,78 @@ __global__ __launch_bounds__(1024) void k_fast_select(u32* __restrict__ hist, u3
   __syncthreads();
   const u32 n = s_n;
   const u64 low = s_low;
-  const bool too_many = n > GCAND_CAP || n == 0;
-  // ---- (2) compact this workgroup's slice
-  if (!too_many) {
-    const i64 per = (m + gridDim.x - 1) / gridDim.x;
-    const i64 j0 = per * blockIdx.x, j1 = min(m, j0 + per);
-    for (i64 j = j0 + t; j < j1; j += 1024) {
-      const u64 k = keys[j];
-      if (k >= low) {
+  if (blockIdx.x == 0 && t == 0) { ctl->n = n; ctl->above = s_above; ctl->low = low; }
+  if (n > GCAND_CAP || n == 0) return;             // k_fast_finish reports the fallback
+  for (i64 jb = j0; jb < j1; jb += 4096) {
+    if (jb > j0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) kk[u] = (jb + t + u * 1024 < j1) ? keys[jb + t + u * 1024] : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const i64 j = jb + t + u * 1024;
+      if (j < j1 && kk[u] >= low) {
         const u32 pos = atomicAdd(&ctl->cursor, 1u);
-        gcand[pos].key = k; gcand[pos].idx = (u32)j; gcand[pos].pad = 0;
-        if ((k >> FAST_SHIFT) == (low >> FAST_SHIFT)) atomicAdd(&fh[(u32)(k >> FINE_SHIFT) & (FINE_BINS - 1)], 1u);
+        gcand[pos].key = kk[u]; gcand[pos].idx = (u32)j; gcand[pos].pad = 0;
+        if ((kk[u] >> FAST_SHIFT) == (low >> FAST_SHIFT)) atomicAdd(&fh[(u32)(kk[u] >> FINE_SHIFT) & (FINE_BINS - 1)], 1u);
       }
     }
-    __syncthreads();
-    for (int i = t; i < FINE_BINS; i += 1024) if (fh[i]) atomicAdd(&fine[i], fh[i]);
   }
-  // ---- (3) ticket
-  __threadfence();
   __syncthreads();
-  if (t == 0) s_last = (atomicAdd(&ctl->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
+  for (int i = t; i < FINE_BINS; i += 1024) if (fh[i]) atomicAdd(&fine[i], fh[i]);
+}
+
+// Fast path, second launch (one workgroup): trims the candidates with the second-level histogram to K + a few,
+// sorts them in LDS by (|g| desc, column asc) -- rank sort up to 1024, bitonic above --, writes the top K,
+// v = the N-th key and w = the largest key below v, and re-zeroes the histograms and the control block.
+__global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u32* __restrict__ fine, FastCtl* __restrict__ ctl,
+                                                      u32 K, u32 Nth, const Cand* __restrict__ gcand, FastState* st,
+                                                      Cand* __restrict__ out, const double* __restrict__ extra_src,
+                                                      double* __restrict__ extra_dst) {
+  extern __shared__ Cand sc[];                    // FAST_CAP candidates
+  __shared__ u32 ssum[1024], wtot[16];
+  __shared__ unsigned long long wbest;
+  __shared__ u32 s_cursor, s_fbin, s_nt;
+  const int t = threadIdx.x;
   if (t == 0 && extra_src) *extra_dst = *extra_src;     // a caller scalar (the sweep's loss) rides in the same block
-  // ---- (4) second-level threshold: the largest fine bin f with above + #(fine bins >= f) >= K
+  const u32 n = ctl->n, above_bin = ctl->above;
+  const u64 low = ctl->low;
+  const bool too_many = n > GCAND_CAP || n == 0;
+  // second-level threshold: the largest fine bin f with above + #(fine bins >= f) >= K
   u32 fv[4], floc = 0;
-  if (!too_many) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) { fv[i] = fine[t * 4 + i]; floc += fv[i]; }
+  for (int i = 0; i < 4; i++) { fv[i] = fine[t * 4 + i]; floc += fv[i]; }
+  if (t == 0) { s_fbin = 0; s_nt = n; s_cursor = 0; wbest = 0ull; }
+  {
+    const u32 suf = block_suffix_sum_1024(floc, wtot);
+    ssum[t] = suf;
   }
-  ssum[t] = floc;
-  if (t == 0) { s_fbin = 0; s_nt = n; }
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
-    __syncthreads();
-    ssum[t] += v;
-    __syncthreads();
-  }
   if (!too_many) {
-    const u32 need = K - s_above;                  // >= 1 keys wanted from the bracketing bin
+    const u32 need = K - above_bin;                // >= 1 keys wanted from the bracketing bin
     const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
     if (above < need && ssum[t] >= need) {
       u32 cum = above;
       int b = 3;
       for (; b > 0; b--) { if (cum + fv[b] >= need) break; cum += fv[b]; }
       s_fbin = (u32)(t * 4 + b);
-      s_nt = s_above + cum + fv[b];
+      s_nt = above_bin + cum + fv[b];
     }
   }
   __syncthreads();
   const u32 nt = s_nt;
   const u64 lowfine = low | ((u64)s_fbin << FINE_SHIFT);
-  // re-zero what this call used (every other workgroup is done with it)
+  // re-zero what this call used
 #pragma unroll
   for (int i = 0; i < 8; i++) hist[t * 8 + i] = 0u;
 #pragma unroll
   for (int i = 0; i < 4; i++) fine[t * 4 + i] = 0u;
-  if (t == 0) { ctl->ticket = 0u; ctl->cursor = 0u; }
+  __syncthreads();                                 // every lane has read ctl
+  if (t < 16) ((u32*)ctl)[t] = 0u;
   if (too_many || nt > FAST_CAP) {                 // the host falls back to the exact radix select
     if (t == 0) { st->lowkey = low; st->ncand = too_many ? n : nt; st->cursor = 0; st->fallback = 1; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
     return;
   }
-  // ---- (5) trimmed candidates into LDS, sort
   for (u32 i = t; i < n; i += 1024) {
     const Cand c = gcand[i];
     if (c.key >= lowfine) { const u32 pos = atomicAdd(&s_cursor, 1u); sc[pos] = c; }
@@ -335,154 +360,17 @@ __global__ __launch_bounds__(1024) void k_fast_select(u32* __restrict__ hist, u3
   Cand* sorted = sc;
   if (nt <= 1024) {
     // rank sort: (key, column) pairs are distinct, so the ranks are a permutation
-    Cand my; u32 rank = 0;
-    if ((u32)t < nt) {
-      my = sc[t];
-      for (u32 j = 0; j < nt; j++) rank += cand_before(sc[j], my) ? 1u : 0u;
-    }
     sorted = sc + 1024;
-    if ((u32)t < nt) sorted[rank] = my;
-    __syncthreads();
-  } else {
-    u32 P = 2; while (P < nt) P <<= 1;
-    for (u32 i = nt + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
-    __syncthreads();
-    for (u32 size = 2; size <= P; size <<= 1) {
-      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-        for (u32 q = t; q < P / 2; q += 1024) {
-          const u32 lo = 2 * q - (q & (stride - 1));
-          const u32 hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          Cand a = sc[lo], b = sc[hi];
-          const bool swap = up ? cand_before(b, a) : cand_before(a, b);
-          if (swap) { sc[lo] = b; sc[hi] = a; }
-        }
-        __syncthreads();
-      }
-    }
-  }
-  // ---- (6) outputs
-  for (u32 i = t; i < K && i < nt; i += 1024) out[i] = sorted[i];
-  const u64 vkey = (Nth >= 1 && Nth <= nt) ? sorted[Nth - 1].key : 0ull;
-  for (u32 i = t; i < nt; i += 1024)
-    if (sorted[i].key < vkey && (i == 0 || sorted[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sorted[i].key | (1ull << 63));
-  __syncthreads();
-  if (t == 0) {
-    st->lowkey = lowfine; st->ncand = nt; st->cursor = nt; st->fallback = 0;
-    st->vkey = vkey; st->wfound = (wbest >> 63) ? 1u : 0u; st->wkey = wbest & ~(1ull << 63);
-  }
-}
-
-// The same selection by ONE workgroup, for m <= ONE_WG_MAX_M: no tickets and no device-scope fences (a fence
-// writes back and invalidates the XCD's L2, which costs more than the rest of the kernel at this size).  One pass
-// over the keys compacts everything at or above the bracketing bin into LDS; the second-level histogram, the trim
-// and the rank sort all work on that LDS list.
-#define ONE_WG_MAX_M 262144
-__global__ __launch_bounds__(1024) void k_fast_select_one(u32* __restrict__ hist, const u64* __restrict__ keys, i64 m, u32 K, u32 Nth,
-                                                          FastState* st, Cand* __restrict__ out,
-                                                          const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
-  extern __shared__ Cand sc[];                    // [FAST_CAP compacted | 1024 trimmed | 1024 sorted]
-  __shared__ u32 ssum[1024];
-  __shared__ u32 fh[FINE_BINS];
-  __shared__ unsigned long long s_low, wbest;
-  __shared__ u32 s_n, s_above, s_cursor, s_cur2, s_fbin, s_nt;
-  const int t = threadIdx.x;
-  if (t == 0 && extra_src) *extra_dst = *extra_src;
-  u32 h[8], loc = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { h[i] = hist[t * 8 + i]; loc += h[i]; hist[t * 8 + i] = 0u; }
-  ssum[t] = loc;
-  for (int i = t; i < FINE_BINS; i += 1024) fh[i] = 0u;
-  if (t == 0) { s_low = 0ull; s_n = 0; s_above = 0; s_cursor = 0; s_cur2 = 0; wbest = 0ull; }
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
-    __syncthreads();
-    ssum[t] += v;
-    __syncthreads();
-  }
-  {
-    const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
-    if (above < K && ssum[t] >= K) {
-      u32 cum = above;
-      int b = 7;
-      for (; b > 0; b--) { if (cum + h[b] >= K) break; cum += h[b]; }
-      s_low = ((u64)(t * 8 + b)) << FAST_SHIFT;
-      s_above = cum;
-      s_n = cum + h[b];
-    }
-  }
-  __syncthreads();
-  const u32 n = s_n;
-  const u64 low = s_low;
-  if (n > FAST_CAP || n == 0) {
-    if (t == 0) { st->lowkey = low; st->ncand = n; st->cursor = 0; st->fallback = 1; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
-    return;
-  }
-  // one pass over the keys, 4 independent loads per trip
-  for (i64 j = t; j < m; j += 4096) {
-    u64 k[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) k[u] = (j + u * 1024 < m) ? keys[j + u * 1024] : 0ull;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (k[u] >= low && j + u * 1024 < m) {
-        const u32 pos = atomicAdd(&s_cursor, 1u);
-        sc[pos].key = k[u]; sc[pos].idx = (u32)(j + u * 1024); sc[pos].pad = 0;
-        if ((k[u] >> FAST_SHIFT) == (low >> FAST_SHIFT)) atomicAdd(&fh[(u32)(k[u] >> FINE_SHIFT) & (FINE_BINS - 1)], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  // second-level threshold
-  u32 fv[4], floc = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) { fv[i] = fh[t * 4 + i]; floc += fv[i]; }
-  ssum[t] = floc;
-  if (t == 0) { s_fbin = 0; s_nt = n; }
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const u32 v = (t + o < 1024) ? ssum[t + o] : 0u;
-    __syncthreads();
-    ssum[t] += v;
-    __syncthreads();
-  }
-  {
-    const u32 need = K - s_above;
-    const u32 above = (t + 1 < 1024) ? ssum[t + 1] : 0u;
-    if (above < need && ssum[t] >= need) {
-      u32 cum = above;
-      int b = 3;
-      for (; b > 0; b--) { if (cum + fv[b] >= need) break; cum += fv[b]; }
-      s_fbin = (u32)(t * 4 + b);
-      s_nt = s_above + cum + fv[b];
-    }
-  }
-  __syncthreads();
-  u32 nt = s_nt;
-  const u64 lowfine = low | ((u64)s_fbin << FINE_SHIFT);
-  Cand* sorted;
-  if (nt <= 1024) {
-    Cand* trimmed = sc + FAST_CAP;
-    sorted = sc + FAST_CAP + 1024;
-    for (u32 i = t; i < n; i += 1024) {
-      const Cand c = sc[i];
-      if (c.key >= lowfine) { const u32 pos = atomicAdd(&s_cur2, 1u); trimmed[pos] = c; }
-    }
-    __syncthreads();
-    // rank sort: (key, column) pairs are distinct, so the ranks are a permutation
     if ((u32)t < nt) {
-      const Cand my = trimmed[t];
+      const Cand my = sc[t];
       u32 rank = 0;
-      for (u32 j = 0; j < nt; j++) rank += cand_before(trimmed[j], my) ? 1u : 0u;
+      for (u32 j = 0; j < nt; j++) rank += cand_before(sc[j], my) ? 1u : 0u;
       sorted[rank] = my;
     }
     __syncthreads();
   } else {
-    nt = n;                                          // bitonic over everything that was compacted
-    sorted = sc;
-    u32 P = 2; while (P < n) P <<= 1;
-    for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
+    u32 P = 2; while (P < nt) P <<= 1;
+    for (u32 i = nt + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
     __syncthreads();
     for (u32 size = 2; size <= P; size <<= 1) {
       for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
@@ -553,7 +441,7 @@ int sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist) {
   const size_t fm_bytes = sizeof(FastCtl) + (FAST_BINS + FINE_BINS) * sizeof(u32);
   KLR_TRY(ws_get(ctx, WS_MASK, fm_bytes, (void**)&fm));
   *hist = (u32*)(fm + sizeof(FastCtl));
-  if (ctx->sel_hist_zeroed != (void*)*hist) {          // k_fast_select re-zeroes what it used
+  if (ctx->sel_hist_zeroed != (void*)*hist) {          // k_fast_finish re-zeroes what was used
     KLR_HIP(ctx, hipMemsetAsync(fm, 0, fm_bytes, ctx->stream));
     ctx->sel_hist_zeroed = (void*)*hist;
   }
@@ -584,20 +472,16 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     }
     static bool attr = false;
     if (!attr) {
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select, hipFuncAttributeMaxDynamicSharedMemorySize,
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(FAST_CAP * sizeof(Cand))));
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_select_one, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((FAST_CAP + 2048) * sizeof(Cand))));
       attr = true;
     }
-    if (m <= ONE_WG_MAX_M) {
-      hipLaunchKernelGGL(k_fast_select_one, dim3(1), dim3(1024), (FAST_CAP + 2048) * sizeof(Cand), st, hist, keys, m, (u32)K, (u32)N,
-                         fs, out, extra_src, extra_dst);
-    } else {
+    {
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
-      const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 128));
-      hipLaunchKernelGGL(k_fast_select, dim3(grid), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, keys, m,
-                         (u32)K, (u32)N, cand, fs, out, extra_src, extra_dst);
+      const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 256));
+      hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m, (u32)K, cand);
+      hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K, (u32)N,
+                         cand, fs, out, extra_src, extra_dst);
     }
     KLR_HIP(ctx, hipGetLastError());
     // ONE device->host copy: [state | scalar | K candidates] into pinned memory

@@ -9,6 +9,7 @@
 // The column sweep is the HBM-roofline kernel (DESIGN.md "kernels"): algorithmic bytes per stored
 // nonzero = 4 (row id) + 4|8 (value); s (8n bytes) is gathered from L2.
 #include "klr_internal.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -397,44 +398,47 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__
 }
 
 template <int THREADS, int UNROLL, bool NT, int ABL = 0>
-static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part) {
+static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds_bytes = (size_t)TILE_DIM * 16;
   static bool attr_done = false;
   if (!attr_done) {
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL>), dim3(mat->nwg), dim3(THREADS), lds_bytes, ctx->stream, (const uint4*)mat->t_ent,
-                     (const uint4*)mat->t_piece, mat->t_wgpiece, mat->t_tileq, mat->nrt, mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->n, S, part);
+  // start / stop events ride on the dispatch packet itself (hipExtLaunchKernelGGL): recording them with
+  // hipEventRecord puts two barrier packets around the kernel and costs ~15 us per step
+  hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+                        (const uint4*)mat->t_ent, (const uint4*)mat->t_piece, (const u32*)mat->t_wgpiece, (const u32*)mat->t_tileq, mat->nrt,
+                        mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->n, S, part);
   return KLR_OK;
 }
 
 // variant switch for in-process A/B timing (tools/ab_sweep.py); 0 = the shipped configuration
 static int g_coo_variant = -1;
-static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part) {
+static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   if (g_coo_variant < 0) { const char* e = getenv("KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
   switch (g_coo_variant) {
-    case 1:  return launch_sweep_coo<512, 4, true>(ctx, mat, S, part);
-    case 2:  return launch_sweep_coo<512, 8, false>(ctx, mat, S, part);
-    case 3:  return launch_sweep_coo<512, 8, true>(ctx, mat, S, part);
-    case 4:  return launch_sweep_coo<1024, 4, false>(ctx, mat, S, part);
-    case 5:  return launch_sweep_coo<1024, 4, true>(ctx, mat, S, part);
-    case 6:  return launch_sweep_coo<1024, 2, false>(ctx, mat, S, part);
-    case 7:  return launch_sweep_coo<256, 8, false>(ctx, mat, S, part);
-    case 8:  return launch_sweep_coo<512, 4, true, 1>(ctx, mat, S, part);     // ablation: no atomics
-    case 9:  return launch_sweep_coo<512, 4, true, 2>(ctx, mat, S, part);     // ablation: no s gather
-    case 10: return launch_sweep_coo<512, 2, true>(ctx, mat, S, part);
-    case 11: return launch_sweep_coo<1024, 2, true>(ctx, mat, S, part);
-    case 12: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part);
-    case 13: return launch_sweep_coo<512, 1, true>(ctx, mat, S, part);
-    case 14: return launch_sweep_coo<1024, 1, false>(ctx, mat, S, part);
-    case 15: return launch_sweep_coo<768, 1, true>(ctx, mat, S, part);
-    case 16: return launch_sweep_coo<512, 4, false>(ctx, mat, S, part);
-    case 21: return launch_sweep_coo<1024, 1, true, 1>(ctx, mat, S, part);     // ablations of the shipped shape: no atomics
-    case 22: return launch_sweep_coo<1024, 1, true, 2>(ctx, mat, S, part);     //   no s gather
-    case 26: return launch_sweep_coo<1024, 1, true, 3>(ctx, mat, S, part);     //   stream only
-    case 50: return launch_sweep_coo<1024, 1, true, 4>(ctx, mat, S, part);     //   no multiply
-    default: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part);      // shipped: 32 waves/CU, nt loads
+    case 1:  return launch_sweep_coo<512, 4, true>(ctx, mat, S, part, e0, e1);
+    case 2:  return launch_sweep_coo<512, 8, false>(ctx, mat, S, part, e0, e1);
+    case 3:  return launch_sweep_coo<512, 8, true>(ctx, mat, S, part, e0, e1);
+    case 4:  return launch_sweep_coo<1024, 4, false>(ctx, mat, S, part, e0, e1);
+    case 5:  return launch_sweep_coo<1024, 4, true>(ctx, mat, S, part, e0, e1);
+    case 6:  return launch_sweep_coo<1024, 2, false>(ctx, mat, S, part, e0, e1);
+    case 7:  return launch_sweep_coo<256, 8, false>(ctx, mat, S, part, e0, e1);
+    case 8:  return launch_sweep_coo<512, 4, true, 1>(ctx, mat, S, part, e0, e1);     // ablation: no atomics
+    case 9:  return launch_sweep_coo<512, 4, true, 2>(ctx, mat, S, part, e0, e1);     // ablation: no s gather
+    case 10: return launch_sweep_coo<512, 2, true>(ctx, mat, S, part, e0, e1);
+    case 11: return launch_sweep_coo<1024, 2, true>(ctx, mat, S, part, e0, e1);
+    case 12: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part, e0, e1);
+    case 13: return launch_sweep_coo<512, 1, true>(ctx, mat, S, part, e0, e1);
+    case 14: return launch_sweep_coo<1024, 1, false>(ctx, mat, S, part, e0, e1);
+    case 15: return launch_sweep_coo<768, 1, true>(ctx, mat, S, part, e0, e1);
+    case 16: return launch_sweep_coo<512, 4, false>(ctx, mat, S, part, e0, e1);
+    case 21: return launch_sweep_coo<1024, 1, true, 1>(ctx, mat, S, part, e0, e1);     // ablations of the shipped shape: no atomics
+    case 22: return launch_sweep_coo<1024, 1, true, 2>(ctx, mat, S, part, e0, e1);     //   no s gather
+    case 26: return launch_sweep_coo<1024, 1, true, 3>(ctx, mat, S, part, e0, e1);     //   stream only
+    case 50: return launch_sweep_coo<1024, 1, true, 4>(ctx, mat, S, part, e0, e1);     //   no multiply
+    default: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part, e0, e1);      // shipped: 32 waves/CU, nt loads
   }
 }
 extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
@@ -443,11 +447,17 @@ extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
 //                      dim+2: loss limb0 | dim+3: loss limb1 | dim+4: non-finite loss terms
 #define IB_EXTRA 5
 
-// 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile, LDS combines
+// 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile (4 independent
+// loads in flight), LDS combines.  FUSE (no all-reduce between the two steps, i.e. one rank and no hook): the
+// sums are converted to f64 right here and the selection keys + coarse histogram are emitted, as k_int_to_g does.
+template <bool FUSE>
 __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
                                                      const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
-                                                     const i64* __restrict__ rowblk, i64 nrowblk, u32 CT) {
+                                                     const i64* __restrict__ rowblk, i64 nrowblk, u32 CT,
+                                                     double inv_scale, double* __restrict__ g, u64* __restrict__ keys,
+                                                     u32* __restrict__ hist) {
   __shared__ i64 sh[4][256];
+  __shared__ u32 shh[FUSE ? FAST_BINS : 1];
   if (blockIdx.x == gridDim.x - 1) {
     // last block: bias halves, loss limbs and the non-finite count from the row pass's block partials
     if (rowblk) {
@@ -455,27 +465,64 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
       i64 v = 0;
       if (q < 5) for (i64 b = l; b < nrowblk; b += 128) v += rowblk[b * 5 + q];
       __shared__ i64 sq[8][128];
+      __shared__ i64 tot[5];
       sq[q][l] = v;
       __syncthreads();
       if (threadIdx.x < 5) {
         i64 t = 0;
         for (int i = 0; i < 128; i++) t += sq[threadIdx.x][i];
-        ibuf[dim + threadIdx.x] = t;                      // sole writer: no zeroing needed beforehand
+        if (FUSE) tot[threadIdx.x] = t;
+        else ibuf[dim + threadIdx.x] = t;                 // sole writer: no zeroing needed beforehand
       }
+      if (FUSE) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          g[0] = ((double)tot[0] * 4294967296.0 + (double)tot[1]) * inv_scale;
+          const double l2 = ((double)tot[2] + (double)tot[3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
+          g[dim] = tot[4] ? nan("") : l2;
+        }
+      }
+    } else if (FUSE && threadIdx.x == 0) {                // k_fix_s has accumulated the five extras in ibuf
+      g[0] = ((double)ibuf[dim] * 4294967296.0 + (double)ibuf[dim + 1]) * inv_scale;
+      const double l2 = ((double)ibuf[dim + 2] + (double)ibuf[dim + 3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
+      g[dim] = ibuf[dim + 4] ? nan("") : l2;
     }
     return;
   }
   const int cx = threadIdx.x & 255, ly = threadIdx.x >> 8;
   const i64 j = (i64)blockIdx.x * 256 + cx;
+  if (FUSE && keys) { for (int i = threadIdx.x; i < FAST_BINS; i += 1024) shh[i] = 0u; }
   i64 v = 0;
   if (j < dim) {
     const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
     const u32 k1 = ctptr[ct + 1];
-    for (u32 k = ctptr[ct] + ly; k < k1; k += 4) v += part[(i64)ctlist[k] * TILE_DIM + c];
+    for (u32 k = ctptr[ct] + ly; k < k1; k += 32) {      // 8 guarded loads in flight per lane
+      u32 p[8]; i64 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) p[u] = (k + 4u * u < k1) ? ctlist[k + 4u * u] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = (p[u] != 0xFFFFFFFFu) ? part[(i64)p[u] * TILE_DIM + c] : 0;
+      v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
   }
   sh[ly][cx] = v;
   __syncthreads();
-  if (ly == 0 && j < dim && j > 0) ibuf[j] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+  if (ly == 0 && j < dim && j > 0) {
+    const i64 sum = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+    if (FUSE) {
+      const double gv = (double)sum * inv_scale;                // inv_scale is a power of two: exact
+      g[j] = gv;
+      if (keys) {
+        const u64 kk = abs_key(gv);
+        keys[j - 1] = kk;
+        atomicAdd(&shh[(u32)(kk >> FAST_SHIFT)], 1u);
+      }
+    } else ibuf[j] = sum;
+  }
+  if (FUSE && keys) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < FAST_BINS; i += 1024) if (shh[i]) atomicAdd(&hist[i], shh[i]);
+  }
 }
 
 // s -> int64 fixed point; bias sum and loss as exactly additive integer limbs
@@ -600,19 +647,22 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   if (ctx->prof_on) {
     KLR_HIP(ctx, hipEventCreate(&e0));
     KLR_HIP(ctx, hipEventCreate(&e1));
-    KLR_HIP(ctx, hipEventRecord(e0, st));
   }
-  KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part));
-  if (ctx->prof_on) {
-    KLR_HIP(ctx, hipEventRecord(e1, st));
-    ctx->prof_ev.emplace_back(e0, e1);
+  KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1));
+  if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
+  const dim3 fgrid((unsigned)ceil_div(dim, 256) + 1);
+  if (!ctx->ar_fn) {
+    // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
+    hipLaunchKernelGGL(k_finish_coo<true>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist);
+  } else {
+    hipLaunchKernelGGL(k_finish_coo<false>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist);
+    KLR_HIP(ctx, hipGetLastError());
+    KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
+    hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,
+                       keys, hist);
   }
-  hipLaunchKernelGGL(k_finish_coo, dim3((unsigned)ceil_div(dim, 256) + 1), dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist,
-                     dim, ibuf, (const i64*)rowblk, nrowblk, mat->tile_c);
-  KLR_HIP(ctx, hipGetLastError());
-  KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
-  hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,
-                     keys, hist);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }
