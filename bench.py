@@ -145,10 +145,11 @@ def main():
     # ---- roofline of the dominant kernel (column sweep k_xt_s), per launch ----------------------------
     lay = full.layout()
     if lay["tiled"]:
-        # single pass over the 2-D tiled packed COO stream: 4 B per stored entry ((count:8|col:12|row:12),
-        # padding included), one 32 KiB vector of int64 column sums written per (tile, workgroup) piece,
+        # single pass over the 2-D tiled packed stream: 3 B per unit entry (col:12|row:12; a count c is c entries)
+        # or 4 B per entry (count:8|col:12|row:12), whichever the ingest chose (value_bytes 0 / 1), padding
+        # included; one 32 KiB vector of int64 column sums written per (tile, workgroup) piece,
         # s read once (the per-piece s tiles are L2 hits and not counted)
-        alg_bytes = 4.0 * lay["padded_entries"] + lay["nseg"] * 4096.0 * 8 + 8.0 * n_local
+        alg_bytes = (3.0 + lay["value_bytes"]) * lay["padded_entries"] + lay["nseg"] * 4096.0 * 8 + 8.0 * n_local
         kname = "k_sweep_coo"
     else:
         # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column
@@ -186,7 +187,7 @@ def main():
             "config": {"workload": "synthetic %d seqs/GPU x %d 8-mer columns, %d draws/row, --lambda-auto=%d "
                                    "(BASELINE configs[2])" % (n_local, m, draws, N),
                        "rows_per_gpu": n_local, "rows_total": n_total, "features": m, "nnz_per_gpu": nnz,
-                       "selected": int(len(cols) - 1), "parallelism": "row-shards x%d, 1 RCCL all-reduce of m+2 f64 per sweep" % world},
+                       "selected": int(len(cols) - 1), "parallelism": "row-shards x%d, 1 RCCL all-reduce of m+6 int64 per sweep" % world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "cd_sweeps_per_s": round(cd_sweeps_per_s, 1),

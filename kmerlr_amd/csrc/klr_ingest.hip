@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_csc_scatter(const u32* __restrict__ sor
 
 // ---- tiles -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_keys(const u32* __restrict__ col, const float* __restrict__ val, const u32* __restrict__ erow,
-                                                   i64 nnz, u32 nrt, u32 nct, u32 RT, u32 CT, int rt_major, u32 ntile,
+                                                   i64 nnz, u32 nrt, u32 nct, u32 RT, u32 CT, int rt_major, u32 ntile, int u24,
                                                    u32* __restrict__ tkey, u32* __restrict__ ne, u32* __restrict__ tile_ne) {
   const i64 a = (i64)blockIdx.x * 256 + threadIdx.x;
   if (a >= nnz) return;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_tile_keys(const u32* __restrict__ col, 
   const u32 rt = erow[a] / RT, ct = c / CT;
   const u32 t = rt_major ? rt * nct + ct : ct * nrt + rt;
   const u32 v = (u32)val[a];
-  const u32 k = (v + 254u) / 255u;
+  const u32 k = u24 ? v : (v + 254u) / 255u;          // unit entries / 8-bit counts
   tkey[a] = t; ne[a] = k;
   atomicAdd(&tile_ne[t], k);
 }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const u32* __restrict__ sk
                                                       const i64* __restrict__ tile_first /* exscan of per-tile ne */,
                                                       const i64* __restrict__ tile_q /* exscan of quads */,
                                                       const u32* __restrict__ col, const float* __restrict__ val,
-                                                      const u32* __restrict__ erow, u32 RT, u32 CT, u32* __restrict__ ent) {
+                                                      const u32* __restrict__ erow, u32 RT, u32 CT, int u24, u32* __restrict__ ent) {
   const i64 k = (i64)blockIdx.x * 256 + threadIdx.x;
   if (k >= nnz) return;
   const u32 t = skey[k];
@@ -206,7 +206,33 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const u32* __restrict__ sk
   i64 pos = tile_q[t] * 4 + (ne_prefix[k] - tile_first[t]);
   u32 v = (u32)val[a];
   const u32 base = ((col[a] % CT) << TILE_BITS) | (erow[a] % RT);
+  if (u24) {
+    unsigned char* b = reinterpret_cast<unsigned char*>(ent) + (size_t)pos * 3;
+    for (; v > 0u; v--, b += 3) { b[0] = (unsigned char)base; b[1] = (unsigned char)(base >> 8); b[2] = (unsigned char)(base >> 16); }
+    return;
+  }
   while (v > 0u) { const u32 q = min(v, 255u); ent[pos++] = (q << 24) | base; v -= q; }
+}
+
+// sums over the stored (non-bias) values: [0] unit entries (sum of counts), [1] 4-byte entries (counts > 255 split)
+__global__ __launch_bounds__(256) void k_entry_totals(const u32* __restrict__ col, const float* __restrict__ val, i64 nnz,
+                                                      unsigned long long* __restrict__ out) {
+  unsigned long long t1 = 0, t4 = 0;
+  for (i64 a = (i64)blockIdx.x * 256 + threadIdx.x; a < nnz; a += (i64)gridDim.x * 256) {
+    if (col[a] == 0u) continue;
+    const u32 v = (u32)val[a];
+    t1 += v; t4 += (v + 254u) / 255u;
+  }
+  for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t4 += __shfl_xor(t4, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], t1); atomicAdd(&out[1], t4); }
+}
+
+// the stream pre-filled with null unit entries (row 4095, column 0): bytes FF 0F 00 repeating
+__global__ __launch_bounds__(256) void k_fill_u24_null(u32* __restrict__ w, i64 nwords) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nwords) return;
+  const u32 r = (u32)(i % 3);
+  w[i] = r == 0 ? 0xFF000FFFu : (r == 1 ? 0x0FFF000Fu : 0x000FFF00u);
 }
 
 // ---- small helpers -----------------------------------------------------------------------------------------
@@ -283,16 +309,27 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   const i64 ntile = nrt * nct;
   if (ntile >= ((i64)1 << 31)) return KLR_OK;
   const char* ord = getenv("KLR_TILE_ORDER");
-  bool rt_major = (double)nnz / (double)ntile >= 32768.0;
+  bool rt_major = (double)nnz / (double)ntile >= 32768.0 && ntile > 2 * (i64)ctx->n_cu;      // one tile per workgroup: column-tile major
   if (ord && ord[0] == 'r') rt_major = true;
   if (ord && ord[0] == 'c') rt_major = false;
+  // entry format: 3-byte unit entries when that is fewer bytes, else 4-byte entries with an 8-bit count
+  bool u24;
+  {
+    unsigned long long* d_tot; KLR_TRY(tmp.get(ctx, &d_tot, 2));
+    KLR_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
+    hipLaunchKernelGGL(k_entry_totals, dim3((unsigned)std::min<i64>(ceil_div(nnz, 256), 2048)), dim3(256), 0, st, m->col, val, nnz, d_tot);
+    unsigned long long h_tot[2];
+    KLR_TRY(d2h_sync(ctx, h_tot, d_tot, 16));
+    u24 = 3ull * h_tot[0] <= 4ull * h_tot[1];
+    if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
+  }
   u32 *tkey, *ne, *tile_ne, *tile_q4, *skey, *sne;
   KLR_TRY(tmp.get(ctx, &tkey, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &ne, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &skey, (size_t)nnz));
   KLR_TRY(tmp.get(ctx, &sne, (size_t)nnz));
   KLR_TRY(tmp.get(ctx, &tile_ne, (size_t)ntile + 1)); KLR_TRY(tmp.get(ctx, &tile_q4, (size_t)ntile + 1));
   KLR_HIP(ctx, hipMemsetAsync(tile_ne, 0, (size_t)(ntile + 1) * 4, st));
   hipLaunchKernelGGL(k_tile_keys, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, m->col, val, erow, nnz, (u32)nrt, (u32)nct,
-                     m->tile_r, m->tile_c, rt_major ? 1 : 0, (u32)ntile, tkey, ne, tile_ne);
+                     m->tile_r, m->tile_c, rt_major ? 1 : 0, (u32)ntile, u24 ? 1 : 0, tkey, ne, tile_ne);
   int tbits = 1; while (((i64)1 << tbits) < ntile + 1) tbits++;
   size_t tsz2 = 0;
   KLR_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tsz2, tkey, skey, vin, vout, (size_t)nnz, 0, tbits, st));
@@ -312,10 +349,12 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   if (total4 <= 0 || (u64)total4 * 4ull >= 0xFFFFFFF0ull) return KLR_OK;
   i64 h_stored = 0;
   KLR_TRY(d2h_sync(ctx, &h_stored, ne_prefix + nnz, 8));
-  KLR_TRY(dalloc(ctx, &m->t_ent, (size_t)total4 * 4));
-  KLR_HIP(ctx, hipMemsetAsync(m->t_ent, 0, (size_t)total4 * 16, st));
+  KLR_TRY(dalloc(ctx, &m->t_ent, (size_t)total4 * 4));                 // 16 bytes per quad (12 used by unit entries)
+  if (u24) hipLaunchKernelGGL(k_fill_u24_null, dim3((unsigned)ceil_div(total4 * 3, 256)), dim3(256), 0, st, m->t_ent, total4 * 3);
+  else KLR_HIP(ctx, hipMemsetAsync(m->t_ent, 0, (size_t)total4 * 16, st));
+  m->u24 = u24;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, skey, vout, nnz, (u32)ntile, ne_prefix,
-                     tile_first, tile_q, m->col, val, erow, m->tile_r, m->tile_c, m->t_ent);
+                     tile_first, tile_q, m->col, val, erow, m->tile_r, m->tile_c, u24 ? 1 : 0, m->t_ent);
   KLR_HIP(ctx, hipGetLastError());
   KLR_HIP(ctx, hipStreamSynchronize(st));
   std::vector<u64> toff4((size_t)ntile + 1);

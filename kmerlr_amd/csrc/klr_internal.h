@@ -103,7 +103,8 @@ struct klr_mat {
   u32* t_ent = nullptr;          // total4*4 packed entries
   u32* t_piece = nullptr;        // npiece * 4: {column tile, quad begin, quad end, first tile index}
   u32* t_tileq = nullptr;        // ntile+1 quad offsets of the tiles (column-tile major: tile = ct*nrt + rt)
-  u32* t_wgpiece = nullptr;      // nwg+1: pieces of workgroup w
+  u32* t_wgpiece = nullptr;      // 8 u32 per workgroup: its pieces and everything its first tile needs
+  bool u24 = false;              // entries are 3-byte unit entries (row:12|col:12) instead of 4-byte (count:8|col:12|row:12)
   u32 tile_r = 4096, tile_c = 4096;   // rows / columns per tile (<= TILE_DIM), chosen at ingest (tile_geometry)
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile

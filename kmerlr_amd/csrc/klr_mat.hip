@@ -13,6 +13,7 @@
 #include "klr_internal.h"
 
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 #include <thread>
 
@@ -49,7 +50,7 @@ extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows
   if (nseg) *nseg = mat->tiled ? (int64_t)mat->npiece : mat->nchunks;
   if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * 4 : mat->nnz_pad;
   if (lanes_per_segment) *lanes_per_segment = mat->tiled ? 0 : mat->group;
-  if (value_bytes) *value_bytes = mat->tiled ? 1 : (mat->val_f64 ? 8 : 4);
+  if (value_bytes) *value_bytes = mat->tiled ? (mat->u24 ? 0 : 1) : (mat->val_f64 ? 8 : 4);   // + 3 bytes of row/col per tiled entry
   return KLR_OK;
 }
 
@@ -150,7 +151,7 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
     for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
   }
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)npiece * 16));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, ((size_t)nwg + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 32));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_tileq, ((size_t)ntile + 2) * 4));
@@ -161,7 +162,21 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
     KLR_HIP(ctx, hipMemcpy(m->t_tileq, tq.data(), ((size_t)ntile + 2) * 4, hipMemcpyHostToDevice));
   }
   KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
-  KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, wgp.data(), ((size_t)nwg + 1) * 4, hipMemcpyHostToDevice));
+  {
+    // per-workgroup record: {first piece, end piece, first tile, its row tile} {-, quad begin, quad end of the first
+    // piece, quad end inside the first tile}
+    std::vector<u32> rec((size_t)nwg * 8, 0u);
+    for (u32 w = 0; w < nwg; w++) {
+      u32* r = &rec[(size_t)w * 8];
+      r[0] = wgp[w]; r[1] = wgp[w + 1];
+      if (wgp[w] == wgp[w + 1]) continue;
+      const u32* d = &piece[(size_t)wgp[w] * 4];
+      const i64 t0 = d[3];
+      r[2] = (u32)t0; r[3] = (u32)(rt_major ? t0 / nct : t0 % nrt);
+      r[5] = d[1]; r[6] = d[2]; r[7] = (u32)std::min<u64>(d[2], toff4[(size_t)t0 + 1]);
+    }
+    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 32, hipMemcpyHostToDevice));
+  }
   KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
   m->rt_major = rt_major; m->tiled = true; m->nrt = (u32)nrt; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
@@ -176,14 +191,15 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
 //   tile (rt, ct): rows [rt*RT, +RT) x columns [ct*CT, +CT), RT, CT <= 4096 (tile_geometry); tiles are stored COLUMN-TILE major
 //            (tile id = ct*nrt + rt) so a workgroup walks down one column tile, reloading only the s tile,
 //            and writes its 4096 column sums once per column tile it touches
-//   entry  = (count:8 << 24) | (col - ct*CT) << 12 | (row - rt*RT); counts > 255 are split into several
-//            entries (the sweep is additive); column 0 (bias, all ones) is not stored
+//   entry  = 4 bytes (count:8 << 24) | (col - ct*CT) << 12 | (row - rt*RT), counts > 255 split into several
+//            entries (the sweep is additive) -- or 3 bytes (col - ct*CT) << 12 | (row - rt*RT), a count c stored
+//            as c entries, whichever is fewer bytes; column 0 (bias, all ones) is not stored
 //   order  = row-major inside a tile (so consecutive entries share the row -> LDS broadcast reads of s
 //            and distinct columns -> few same-address LDS atomics); every tile padded to 4 entries
 //   pieces = the entry stream cut into nwg equal parts (one per workgroup), each part cut where the
 //            column tile changes; a piece produces one 4096-wide int64 partial column-sum vector
 // =================================================================================================
-// Tile geometry.  A tile is at most 4096 x 4096 (12-bit offsets in an entry, 32 KiB + 32 KiB of LDS).  Columns:
+// Tile geometry.  A tile is at most 4094 x 4096 (12-bit offsets in an entry, 32 KiB + 32 KiB of LDS).  Columns:
 // the fewest strips that cover dim, equally wide.  Rows: if the matrix is small enough for one tile per
 // workgroup (nrt_min * nct <= nwg), as many equally tall row tiles as give one tile per workgroup -- then a
 // workgroup starts and ends on tile boundaries and streams its whole part without boundary work in between
@@ -192,11 +208,12 @@ void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt_o
   i64 nct = std::max<i64>(1, ceil_div(dim, (i64)TILE_DIM));
   const i64 CT = std::max<i64>(1, ceil_div(dim, nct));
   nct = ceil_div(dim, CT);
-  const i64 nrt_min = std::max<i64>(1, ceil_div(n, (i64)TILE_DIM));
+  const i64 RT_MAX = TILE_DIM - 2;                           // slot 4095 of the s tile is the null entry's zero
+  const i64 nrt_min = std::max<i64>(1, ceil_div(n, RT_MAX));
   i64 nrt = nrt_min;
   if (nrt_min * nct <= (i64)nwg) nrt = std::max<i64>(nrt_min, (i64)nwg / nct);
   i64 RT = ceil_div(std::max<i64>(n, 1), nrt);
-  RT = std::min<i64>((RT + 1) & ~(i64)1, (i64)TILE_DIM);      // even: the s tile is read with 16-byte loads
+  RT = std::min<i64>((RT + 1) & ~(i64)1, RT_MAX);              // even: the s tile is read with 16-byte loads
   nrt = std::max<i64>(1, ceil_div(n, RT));
   *tile_r = (u32)RT; *tile_c = (u32)CT; *nrt_out = nrt; *nct_out = nct;
 }
@@ -213,21 +230,25 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   // 4096-wide output vector (one 32 KiB write per tile).  Column-tile major: it keeps the output vector and
   // reloads the s tile (32 KiB from L2, no HBM traffic).  Dense tiles (>= 32k entries, e.g. 100k x 65k k-mer
   // counts) amortise the writes and run fastest row-tile major; sparse tiles (1M columns) are dominated by the
-  // per-tile writes and run column-tile major (measured: profiles/README.md).  KLR_TILE_ORDER=rt|ct overrides.
+  // per-tile writes and run column-tile major (measured: profiles/README.md).  With one tile per workgroup the
+  // two orders do the same work; column-tile major measured 3-5 % faster (neighbouring workgroups then read
+  // different s tiles instead of 17 of them the same one).  KLR_TILE_ORDER=rt|ct overrides.
   const char* ord = getenv("KLR_TILE_ORDER");
-  bool rt_major = (double)m->nnz / (double)ntile >= 32768.0;
+  bool rt_major = (double)m->nnz / (double)ntile >= 32768.0 && ntile > 2 * (i64)ctx->n_cu;   // one tile per workgroup: column-tile major
   if (ord && ord[0] == 'r') rt_major = true;
   if (ord && ord[0] == 'c') rt_major = false;
   auto tix = [&](i64 rt, i64 ct) -> i64 { return rt_major ? rt * nct + ct : ct * nrt + rt; };
   int T = (int)std::min<i64>(std::max<unsigned>(1u, std::min(8u, std::thread::hardware_concurrency())), nrt);
   std::vector<int> bad(T, 0);
-  std::vector<u64> tlen((size_t)ntile, 0);           // entries per tile (after splitting)
+  std::vector<u64> tlen((size_t)ntile, 0);           // 4-byte entries per tile (counts > 255 split)
+  std::vector<u64> tlen1((size_t)ntile, 0);          // unit entries per tile (sum of the counts)
   std::vector<std::vector<double>> colsum(T, std::vector<double>((size_t)dim, 0.0));
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
       for (i64 rt = t; rt < nrt; rt += T) {
         u64* l = tlen.data();
+        u64* l1 = tlen1.data();
         const i64 r0 = rt * RT, r1 = std::min<i64>(n, r0 + RT);
         for (i64 a = rowptr[r0]; a < rowptr[r1]; a++) {
           const double v = val[a];
@@ -236,6 +257,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
           if (c == 0) continue;
           const u32 iv = (u32)v;
           l[(size_t)tix(rt, c / CT)] += (iv + 254u) / 255u;               // 0 -> no entry
+          l1[(size_t)tix(rt, c / CT)] += iv;
           colsum[t][(size_t)c] += v;
         }
       }
@@ -246,17 +268,27 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   double amax = 0.0;
   for (i64 j = 1; j < dim; j++) { double sj = 0.0; for (int t = 0; t < T; t++) sj += colsum[t][(size_t)j]; amax = std::max(amax, sj); }
   colsum.clear();
+  // entry format: 3-byte unit entries when that is fewer bytes (k-mer counts: a row's counts sum to its number
+  // of windows, so it almost always is), else 4-byte entries with an 8-bit count.  KLR_ENTRY_FORMAT=u24|u32 overrides.
+  u64 tot4 = 0, tot1 = 0;
+  for (i64 t = 0; t < ntile; t++) { tot4 += tlen[(size_t)t]; tot1 += tlen1[(size_t)t]; }
+  bool u24 = 3 * tot1 <= 4 * tot4;
+  if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
+  if (u24) tlen.swap(tlen1);
   std::vector<u64> toff4((size_t)ntile + 1);
   u64 run = 0, stored = 0;
   for (i64 t = 0; t < ntile; t++) { toff4[(size_t)t] = run; run += (tlen[(size_t)t] + 3) / 4; stored += tlen[(size_t)t]; }
   toff4[(size_t)ntile] = run;
   if (run >= 0xFFFFFFF0ull || run == 0) return KLR_OK;
   const i64 total4 = (i64)run;
-  std::vector<u32> ent((size_t)total4 * 4, 0u);
+  const size_t qbytes = u24 ? 12 : 16;                // a quad = 4 entries
+  std::vector<unsigned char> ent((size_t)total4 * qbytes, 0);
+  if (u24) for (size_t e = 0; e < (size_t)total4 * 4; e++) { ent[e * 3] = 0xFF; ent[e * 3 + 1] = 0x0F; }   // null entries: row 4095, column 0
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
       std::vector<u64> cur((size_t)nct);
+      u32* ent32 = reinterpret_cast<u32*>(ent.data());
       for (i64 rt = t; rt < nrt; rt += T) {
         for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)tix(rt, ct)] * 4;
         const i64 r0 = rt * RT, r1 = std::min<i64>(n, r0 + RT);
@@ -268,14 +300,19 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
             const i64 ct = c / CT;
             const u32 base = ((u32)(c - ct * CT) << TILE_BITS) | (u32)(i - r0);
             u64& cu = cur[(size_t)ct];
-            while (iv > 0) { const u32 q = std::min(iv, 255u); ent[cu++] = (q << 24) | base; iv -= q; }
+            if (u24) {
+              for (; iv > 0; iv--, cu++) { unsigned char* b = &ent[cu * 3]; b[0] = (unsigned char)base; b[1] = (unsigned char)(base >> 8); b[2] = (unsigned char)(base >> 16); }
+            } else {
+              while (iv > 0) { const u32 q = std::min(iv, 255u); ent32[cu++] = (q << 24) | base; iv -= q; }
+            }
           }
       }
     });
     for (auto& x : th) x.join();
   }
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)total4 * 16));
-  KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * 16, hipMemcpyHostToDevice));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)total4 * qbytes));
+  KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * qbytes, hipMemcpyHostToDevice));
+  m->u24 = u24;
   m->stored_entries = (i64)stored; m->col_abs_max = amax;
   KLR_TRY(build_pieces_and_upload(ctx, m, toff4, nrt, nct, rt_major));
   return KLR_OK;

@@ -322,30 +322,49 @@ __device__ __forceinline__ uint4 coo_load(const uint4* __restrict__ ent4, u32 q)
   return ent4[q];
 }
 
-template <int THREADS, int UNROLL, bool NT, int ABL = 0>
-__global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__ ent4, const uint4* __restrict__ piece,
-                                                       const u32* __restrict__ wgpiece, const u32* __restrict__ tileq,
+// Entry formats of the stream (chosen at ingest, whichever is fewer bytes):
+//   u32: (count:8 << 24) | col:12 << 12 | row:12, a quad = 16 bytes, zero-padded;
+//   u24: col:12 << 12 | row:12 in 3 bytes, little endian, a count c stored as c entries, a quad = 12 bytes read as
+//        one dwordx3 per lane; tiles are padded with the null entry row 4095 (s slot 4095 is kept zero:
+//        tile_geometry never gives a tile more than 4094 rows), column 0.  k-mer count rows sum to the number of
+//        windows, so unit entries cost at most windows/distinct more entries (0.9 % at configs[2]) for 25 % fewer
+//        bytes each, and the product S*count disappears.
+template <int THREADS, int UNROLL, bool NT, int ABL, bool U24>
+__global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ ent, const uint4* __restrict__ piece,
+                                                       const uint4* __restrict__ wgrec, const u32* __restrict__ tileq,
                                                        u32 nrt, u32 nct_or0, u32 RT, i64 n, const i64* __restrict__ S,
                                                        i64* __restrict__ part) {
+  static_assert(!U24 || UNROLL == 1, "unit entries: one quad per lane and trip");
   extern __shared__ unsigned long long coo_lds[];
   i64* sS = (i64*)coo_lds;
   unsigned long long* sG = coo_lds + TILE_DIM;
   const u32 tid = threadIdx.x;
-  const u32 p0 = wgpiece[blockIdx.x], p1 = wgpiece[blockIdx.x + 1];
+  // one 32-byte record per workgroup carries everything its first tile needs -- {first piece, end piece, first
+  // tile, its row tile} {-, quad begin, quad end of the piece, quad end inside the first tile} -- so the s tile and
+  // the first stream loads are one memory round trip away (piece -> tile offsets -> s tile -> stream used to be
+  // four, ~5 us of a 60 us kernel)
+  const uint4 w0 = wgrec[2 * blockIdx.x], w1 = wgrec[2 * blockIdx.x + 1];
+  const u32 p0 = w0.x, p1 = w0.y;
   unsigned long long sink = 0ull;
   u32 cur_rt = 0xFFFFFFFFu;
+  if (U24 && tid == 0) sS[TILE_DIM - 1] = 0;            // the null entry's s slot; never overwritten (RT <= 4094)
   for (u32 p = p0; p < p1; p++) {
-    const uint4 d = piece[p];                           // {column tile, quad begin, quad end, first tile}
+    uint4 d;                                            // {column tile, quad begin, quad end, first tile}
+    if (p == p0) d = make_uint4(0u, w1.y, w1.z, w0.z); else d = piece[p];
     const u32 pq0 = d.y, pq1 = d.z;
     __syncthreads();                                    // previous piece written out
     for (u32 i = tid; i < TILE_DIM; i += THREADS) sG[i] = 0ull;
-    // walk down the column tile: one s tile per row tile
+    // walk down the piece: one s tile per row tile
     for (u32 t = d.w; ; t++) {
-      const u32 tq0 = tileq[t], tq1 = tileq[t + 1];
-      if (tq0 >= pq1) break;
-      const u32 q0 = max(pq0, tq0), q1 = min(pq1, tq1);
-      if (q0 >= q1) continue;                           // empty tile
-      const u32 rt = nct_or0 ? t / nct_or0 : t % nrt;   // row-tile major / column-tile major
+      u32 q0, q1, rt;
+      if (p == p0 && t == d.w) { q0 = pq0; q1 = w1.w; rt = w0.w; }
+      else {
+        const u32 tq0 = tileq[t], tq1 = tileq[t + 1];
+        if (tq0 >= pq1) break;
+        q0 = max(pq0, tq0); q1 = min(pq1, tq1);
+        if (q0 >= q1) continue;                         // empty tile
+        rt = nct_or0 ? t / nct_or0 : t % nrt;           // row-tile major / column-tile major
+      }
       if (rt != cur_rt) {
         const i64 r0 = (i64)rt * RT;                    // RT is even: 16-byte aligned
         __syncthreads();                                // the previous s tile is no longer read
@@ -358,31 +377,46 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__
         cur_rt = rt;
       }
       __syncthreads();                                  // s tile (and the zeroed accumulators) visible
-      for (u32 q = q0 + tid; q < q1; q += THREADS * UNROLL) {
-        uint4 e[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-          const u32 qq = q + u * THREADS;
-          if (qq < q1) {
-            if (NT) {
-              typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-              const u32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ent4) + qq);
-              e[u] = make_uint4(tt.x, tt.y, tt.z, tt.w);
-            } else e[u] = ent4[qq];
-          } else e[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (U24) {
+        for (u32 q = q0 + tid; q < q1; q += THREADS) {
+          const u32* src = ent + 3ull * q;
+          u32 a0, a1, a2;
+          if (NT) { a0 = __builtin_nontemporal_load(src); a1 = __builtin_nontemporal_load(src + 1); a2 = __builtin_nontemporal_load(src + 2); }
+          else { a0 = src[0]; a1 = src[1]; a2 = src[2]; }
+          if (ABL == 3) { sink += a0 + a1 + a2; continue; }
+          const u32 e0 = a0 & 0xFFFFFFu;
+          const u32 e1 = __builtin_amdgcn_alignbit(a1, a0, 24) & 0xFFFFFFu;
+          const u32 e2 = __builtin_amdgcn_alignbit(a2, a1, 16) & 0xFFFFFFu;
+          const u32 e3 = a2 >> 8;
+          const unsigned long long s0 = (unsigned long long)sS[e0 & (TILE_DIM - 1)], s1 = (unsigned long long)sS[e1 & (TILE_DIM - 1)];
+          const unsigned long long s2 = (unsigned long long)sS[e2 & (TILE_DIM - 1)], s3 = (unsigned long long)sS[e3 & (TILE_DIM - 1)];
+          atomicAdd(&sG[e0 >> TILE_BITS], s0);
+          atomicAdd(&sG[e1 >> TILE_BITS], s1);
+          atomicAdd(&sG[e2 >> TILE_BITS], s2);
+          atomicAdd(&sG[e3 >> TILE_BITS], s3);
         }
+      } else {
+        const uint4* ent4 = reinterpret_cast<const uint4*>(ent);
+        for (u32 q = q0 + tid; q < q1; q += THREADS * UNROLL) {
+          uint4 e[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-          if (ABL == 0) {
-            coo_consume(e[u].x, sS, sG);
-            coo_consume(e[u].y, sS, sG);
-            coo_consume(e[u].z, sS, sG);
-            coo_consume(e[u].w, sS, sG);
-          } else {
-            coo_consume_abl<ABL>(e[u].x, sS, sG, sink);
-            coo_consume_abl<ABL>(e[u].y, sS, sG, sink);
-            coo_consume_abl<ABL>(e[u].z, sS, sG, sink);
-            coo_consume_abl<ABL>(e[u].w, sS, sG, sink);
+          for (int u = 0; u < UNROLL; u++) {
+            const u32 qq = q + u * THREADS;
+            if (qq < q1) e[u] = coo_load<NT>(ent4, qq); else e[u] = make_uint4(0u, 0u, 0u, 0u);
+          }
+#pragma unroll
+          for (int u = 0; u < UNROLL; u++) {
+            if (ABL == 0) {
+              coo_consume(e[u].x, sS, sG);
+              coo_consume(e[u].y, sS, sG);
+              coo_consume(e[u].z, sS, sG);
+              coo_consume(e[u].w, sS, sG);
+            } else {
+              coo_consume_abl<ABL>(e[u].x, sS, sG, sink);
+              coo_consume_abl<ABL>(e[u].y, sS, sG, sink);
+              coo_consume_abl<ABL>(e[u].z, sS, sG, sink);
+              coo_consume_abl<ABL>(e[u].w, sS, sG, sink);
+            }
           }
         }
       }
@@ -397,18 +431,18 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const uint4* __restrict__
   }
 }
 
-template <int THREADS, int UNROLL, bool NT, int ABL = 0>
+template <int THREADS, int UNROLL, bool NT, int ABL = 0, bool U24 = false>
 static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds_bytes = (size_t)TILE_DIM * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL, U24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
   // start / stop events ride on the dispatch packet itself (hipExtLaunchKernelGGL): recording them with
   // hipEventRecord puts two barrier packets around the kernel and costs ~15 us per step
-  hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
-                        (const uint4*)mat->t_ent, (const uint4*)mat->t_piece, (const u32*)mat->t_wgpiece, (const u32*)mat->t_tileq, mat->nrt,
+  hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL, U24>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+                        (const u32*)mat->t_ent, (const uint4*)mat->t_piece, (const uint4*)mat->t_wgpiece, (const u32*)mat->t_tileq, mat->nrt,
                         mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->n, S, part);
   return KLR_OK;
 }
@@ -417,6 +451,14 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
 static int g_coo_variant = -1;
 static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   if (g_coo_variant < 0) { const char* e = getenv("KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
+  if (mat->u24) {
+    switch (g_coo_variant) {
+      case 26: return launch_sweep_coo<1024, 1, true, 3, true>(ctx, mat, S, part, e0, e1);   // stream only
+      case 14: return launch_sweep_coo<1024, 1, false, 0, true>(ctx, mat, S, part, e0, e1);
+      case 13: return launch_sweep_coo<512, 1, true, 0, true>(ctx, mat, S, part, e0, e1);
+      default: return launch_sweep_coo<1024, 1, true, 0, true>(ctx, mat, S, part, e0, e1);   // shipped: 32 waves/CU, nt loads
+    }
+  }
   switch (g_coo_variant) {
     case 1:  return launch_sweep_coo<512, 4, true>(ctx, mat, S, part, e0, e1);
     case 2:  return launch_sweep_coo<512, 8, false>(ctx, mat, S, part, e0, e1);

@@ -314,11 +314,19 @@ def synth_tiled():
     return x, labels
 
 
-def test_tiled_sweep_matches_oracle(ctx, synth_tiled):
+@pytest.fixture(params=["u24", "u32"])
+def entry_format(request, monkeypatch):
+    # both packings of the tiled stream: 3-byte unit entries / 4-byte entries with an 8-bit count
+    monkeypatch.setenv("KLR_ENTRY_FORMAT", request.param)
+    return request.param
+
+
+def test_tiled_sweep_matches_oracle(ctx, synth_tiled, entry_format):
     x, labels = synth_tiled
     m = upload(ctx, x, labels)
     lay = m.layout()
-    assert lay["tiled"] and 0 < lay["tile_rows"] <= 4096 and lay["tile_rows"] % 2 == 0 and lay["value_bytes"] == 1
+    assert lay["tiled"] and 0 < lay["tile_rows"] <= 4094 and lay["tile_rows"] % 2 == 0
+    assert lay["value_bytes"] == (0 if entry_format == "u24" else 1)
     cw = O.class_weights(labels)
     rng = np.random.default_rng(1)
     for k in (0, 40):
@@ -333,7 +341,7 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled):
     np.testing.assert_array_equal(g, g2)
 
 
-def test_tiled_dense_counts(ctx):
+def test_tiled_dense_counts(ctx, entry_format):
     # dense count data: every (row, column) pair present, many same-column LDS atomics per wave
     rng = np.random.default_rng(2)
     dense = rng.integers(0, 5, size=(9000, 130)).astype(np.float64)
@@ -345,7 +353,7 @@ def test_tiled_dense_counts(ctx):
     assert_g_close(K.gradient_dense(ctx, m, theta), O.gradient(x, labels, theta))
 
 
-def test_tiled_large_counts_and_unpackable_values(ctx):
+def test_tiled_large_counts_and_unpackable_values(ctx, entry_format):
     rng = np.random.default_rng(3)
     x, labels = O.synth_csr(5, 0, 9000, 9000, 500, 150, 4)
     v = x.val.copy()
@@ -372,7 +380,7 @@ def test_full_size_properties(ctx):
     n, m, draws, N = 100000, 65536, 993, 100
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
     mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
-    assert mat.layout()["tiled"]
+    assert mat.layout()["tiled"] and mat.layout()["value_bytes"] == 0      # k-mer counts: 3-byte unit entries
     rows_fg = int(rowptr[n // 2])
     fg = np.bincount(col[:rows_fg], weights=val[:rows_fg], minlength=m + 1)
     bg = np.bincount(col[rows_fg:], weights=val[rows_fg:], minlength=m + 1)
