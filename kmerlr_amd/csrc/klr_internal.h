@@ -183,7 +183,8 @@ int   sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], doub
 int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
                        const unsigned long long* rowblk, i64 nrowblk);
 int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
-                          const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk);
+                          const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
+                          const double* theta_host = nullptr, i64 theta_len = 0);
 int   sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist);
 int   apply_transform_dev(klr_ctx* ctx, double* gbuf, i64 dim, const double* scale, const double* offset);
 

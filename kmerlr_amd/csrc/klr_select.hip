@@ -575,6 +575,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   KLR_TRY(ws_get(ctx, WS_G, (size_t)(dim + 8) * sizeof(double), (void**)&gbuf));
   // restoreNonzero (:194-219): b[0] = 1 and b[j] = 1 where theta_j != 0; c = count
   i64 c_prev = 0;
+  bool theta_inline = false;
   memset(b, 0, (size_t)dim);
   b[0] = 1;
   if (reduced) {
@@ -583,7 +584,10 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
       if (theta_red[p] != 0.0) { b[red_cols[p]] = 1; c_prev++; }
     }
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
-    KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
+    // count data and a small reduced problem: theta rides in the row pass's kernel arguments (a 1 KB upload
+    // is a 5 us blit kernel of its own)
+    theta_inline = full->tiled && c_plus_1 <= 128;
+    if (!theta_inline) KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
   }
   bool keys_ready = false;
   if (full->tiled) {
@@ -595,7 +599,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     unsigned long long* rowblk; i64 nrowblk;
     (void)acc;
     KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale_fx, S,
-                                &rowblk, &nrowblk));
+                                &rowblk, &nrowblk, theta_inline ? theta_red : nullptr, theta_inline ? c_plus_1 : 0));
     const bool tr = scale != nullptr || offset != nullptr;
     KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk));
     keys_ready = m > 0 && !tr;

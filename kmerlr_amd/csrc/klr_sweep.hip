@@ -12,6 +12,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 
 // ---------------------------------------------------------------------------------------------
@@ -33,12 +34,15 @@ __device__ __forceinline__ double group_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // row pass: G lanes per row
 // ---------------------------------------------------------------------------------------------
+#define THETA_INLINE_MAX 128
 struct RowPassArgs {
   const i64* rowptr; const u32* col; const void* val; const uint8_t* labels; const uint8_t* active;
   const double* theta; i64 n; double inv_n; double cw0, cw1;
   double* out0; double* out1; double* blk;   // blk: per-block loss partials
   double theta0_only; int const_mode;
   double fix_scale; i64* S; unsigned long long* acc;     // ROW_SWEEP_FIX
+  int theta_inline_n;                                    // > 0: theta travels in the kernel arguments (no upload)
+  double theta_inline[THETA_INLINE_MAX];
 };
 
 __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i, double r, double& loss_term) {
@@ -74,9 +78,15 @@ __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i
 template <typename VT, int G, int MODE>
 __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
   __shared__ double sh[256 / 64];
+  __shared__ double sth[THETA_INLINE_MAX];
   const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   double loss_term = 0.0;
+  const bool inl = a.theta_inline_n > 0;                 // theta of a small reduced problem: kernel arguments -> LDS
+  if (inl) {
+    if ((int)threadIdx.x < a.theta_inline_n) sth[threadIdx.x] = a.theta_inline[threadIdx.x];
+    __syncthreads();
+  }
   if (gid < a.n) {
     double r;
     if (a.const_mode) {
@@ -86,9 +96,10 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
       const VT* val = (const VT*)a.val;
       // LinearPdf (:47-68): r = theta[0] + sum_{j>=1} v_j theta[i_j]; entry 0 is the bias
       double acc = 0.0;
-      for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * a.theta[a.col[p]];
+      if (inl) { for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * sth[a.col[p]]; }
+      else     { for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * a.theta[a.col[p]]; }
       acc = group_sum<G>(acc);
-      r = a.theta[0] + acc;
+      r = (inl ? sth[0] : a.theta[0]) + acc;
     }
     if (lane == 0) row_finish(a, MODE, gid, r, loss_term);
   }
@@ -171,7 +182,8 @@ static void row_pass_group(int g, int mode, i64 n, hipStream_t st, const RowPass
 
 static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                            int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev,
-                           double fix_scale = 0.0, i64* S = nullptr, unsigned long long* acc = nullptr) {
+                           double fix_scale = 0.0, i64* S = nullptr, unsigned long long* acc = nullptr,
+                           const double* theta_host = nullptr, i64 theta_len = 0) {
   const i64 n = mat->n;
   int g = 64;
   if (const_mode || mat->avg_row <= 4.0) g = 1;
@@ -185,6 +197,11 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
   a.theta = theta_dev; a.n = n; a.inv_n = 1.0 / (double)mat->n_total; a.cw0 = cw[0]; a.cw1 = cw[1];
   a.out0 = out0; a.out1 = out1; a.blk = blk; a.theta0_only = theta0; a.const_mode = const_mode ? 1 : 0;
   a.fix_scale = fix_scale; a.S = S; a.acc = acc;
+  a.theta_inline_n = 0;
+  if (theta_host && !const_mode && theta_len > 0 && theta_len <= THETA_INLINE_MAX) {
+    a.theta_inline_n = (int)theta_len;
+    memcpy(a.theta_inline, theta_host, (size_t)theta_len * sizeof(double));
+  }
   if (n > 0) {
     if (mat->val_f64) row_pass_group<double>(g, mode, n, ctx->stream, a);
     else              row_pass_group<float>(g, mode, n, ctx->stream, a);
@@ -205,7 +222,8 @@ int launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, i
 }
 
 int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
-                        const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk) {
+                        const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
+                        const double* theta_host, i64 theta_len) {
   // the kernel writes 5 integer partials per block into the WS_BLK block-partial buffer
   int g = 64;
   if (const_mode || mat->avg_row <= 4.0) g = 1;
@@ -215,7 +233,8 @@ int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_de
   unsigned long long* blk;
   KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(unsigned long long), (void**)&blk));
   *rowblk = blk; *nrowblk = mat->n > 0 ? nb : 0;
-  return row_pass_common(ctx, mat, theta_dev, theta0, const_mode, ROW_SWEEP_FIX, cw, nullptr, nullptr, nullptr, scale, S, blk);
+  return row_pass_common(ctx, mat, theta_dev, theta0, const_mode, ROW_SWEEP_FIX, cw, nullptr, nullptr, nullptr, scale, S, blk,
+                         theta_host, theta_len);
 }
 
 int launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
@@ -424,10 +443,7 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
     if (ABL == 1 || ABL == 3) sG[tid] += sink;
     __syncthreads();
     i64* out = part + (i64)p * TILE_DIM;
-    for (u32 i = tid; i < TILE_DIM; i += THREADS) {
-      if (NT) __builtin_nontemporal_store((i64)sG[i], out + i);
-      else out[i] = (i64)sG[i];
-    }
+    for (u32 i = tid; i < TILE_DIM; i += THREADS) out[i] = (i64)sG[i];    // plain stores: the next kernel reads them back
   }
 }
 
