@@ -159,7 +159,8 @@ def main():
     traffic = None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if lay["tiled"] and pj["workload"]["nnz"] == nnz and pj["workload"]["features"] == m:
+        if (lay["tiled"] and pj["workload"]["nnz"] == nnz and pj["workload"]["features"] == m
+                and pj["workload"].get("entry_bytes") == 3 + lay["value_bytes"]):
             traffic = pj["kernels"]["k_sweep_coo"]["hbm_traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -168,7 +169,7 @@ def main():
     two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per MI355X_MICROARCH.md)" if traffic else None,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x1.994, calibrated for 12 B/lane loads as MI355X_MICROARCH.md prescribes)" if traffic else None,
                 "kernel": kname, "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "survey_two_pass_bytes": two_pass_bytes,
