@@ -91,6 +91,17 @@ int  klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows, int64_t*
  * col/val need klr_mat_shape's nnz entries. */
 int  klr_mat_to_csr(klr_ctx* ctx, const klr_mat* mat, int64_t* rowptr, int64_t* col, double* val);
 
+/* Co-occurrence features (CoeffIndex, kmerLr_coefficients_index.go:26-54; LinearPdf / Gradient with
+ * Cooccurrence, kmerLr_logistic_regression.go:69-85,183-195; featureSelection.Data :325-330).  For a base matrix
+ * with nb features the result has klr_coeff_dim(nb) = nb(nb+1)/2 + 1 columns: bias, the nb singles at k+1, the
+ * pairs k1 < k2 at klr_coeff_ind2sub(nb,k1,k2), value v_k1 * v_k2 for the stored entries of the row.  Built on
+ * the device; labels, n_total and the row mask are inherited.  Base matrices wider than 65,535 features must be
+ * pre-selected first (--co-preselection, kmerLr_estimator_ensemble.go:99-115). */
+int     klr_mat_expand_cooccurrence(klr_ctx* ctx, const klr_mat* base, klr_mat** out);
+int64_t klr_coeff_dim(int64_t nb);
+int64_t klr_coeff_ind2sub(int64_t nb, int64_t k1, int64_t k2);
+void    klr_coeff_sub2ind(int64_t nb, int64_t i, int64_t* k1, int64_t* k2);
+
 /* Restrict every sum over samples (gradient, loss, Gram, class counts) to the rows with mask[i] != 0 --
  * the training / test split of a cross-validation fold or ensemble member (filterCvGroup,
  * kmerLr_crossvalidation.go:96-120) without re-uploading the matrix.  n_active_total = number of active

@@ -41,6 +41,10 @@ SIGNATURES = {
                               C.POINTER(_int), C.POINTER(_int)]),
     "klr_mat_to_csr": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "klr_mat_set_active_rows": (_int, [_vp, _vp, _vp, _i64]),
+    "klr_mat_expand_cooccurrence": (_int, [_vp, _vp, _PVP]),
+    "klr_coeff_dim": (_i64, [_i64]),
+    "klr_coeff_ind2sub": (_i64, [_i64, _i64, _i64]),
+    "klr_coeff_sub2ind": (None, [_i64, _i64, _vp, _vp]),
     "klr_class_weights": (_int, [_vp, _vp, _vp]),
     "klr_gradient": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "klr_loss": (_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(_dbl)]),
@@ -241,6 +245,19 @@ class Matrix:
         self.ctx.check(lib().klr_mat_select_columns(self.ctx._h, self._h, _p(cols), len(cols), _p(scale), _p(offset),
                                                     C.byref(h)))
         return Matrix(self.ctx, h)
+
+
+    def expand_cooccurrence(self):
+        """Pair-feature matrix in CoeffIndex column order (klr_mat_expand_cooccurrence)."""
+        h = C.c_void_p()
+        self.ctx.check(lib().klr_mat_expand_cooccurrence(self.ctx._h, self._h, C.byref(h)))
+        return Matrix(self.ctx, h)
+
+
+def coeff_sub2ind(nb, i):
+    a, b = C.c_int64(), C.c_int64()
+    lib().klr_coeff_sub2ind(int(nb), int(i), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def gradient(ctx, mat, theta_idx, theta_val, cw=(1.0, 1.0), scale=None, offset=None):

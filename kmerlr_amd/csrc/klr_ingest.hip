@@ -454,3 +454,152 @@ extern "C" int klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int6
   *out = m;
   return KLR_OK;
 }
+
+// =================================================================================================================
+// Co-occurrence features.  The reference evaluates the pair features on the fly inside LinearPdf /
+// Gradient (kmerLr_logistic_regression.go:69-85, 183-195: every pair j1 < j2 of stored entries of a row contributes
+// v[j1]*v[j2] at parameter CoeffIndex.Ind2Sub(i[j1]-1, i[j2]-1), kmerLr_coefficients_index.go:35-42) and writes
+// them out only for selected columns (featureSelection.Data, kmerLr_feature_selection.go:325-330).  Here the pair
+// matrix of a (pre-selected) base matrix is written out once, on the device, in CoeffIndex column order; after that
+// it is an ordinary data matrix for the sweep, the selection, the column sub-select and the solver.
+// =================================================================================================================
+__device__ __forceinline__ i64 d_ind2sub(i64 n, i64 k1, i64 k2) {
+  return k1 == k2 ? k1 + 1 : n + (n * (n - 1) / 2) - (n - k1) * ((n - k1) - 1) / 2 + k2 - k1;
+}
+
+__global__ __launch_bounds__(256) void k_cooc_count(const i64* __restrict__ rowptr, i64 n, u32* __restrict__ len, u32* __restrict__ too_long) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const i64 q = rowptr[i + 1] - rowptr[i] - 1;
+  const i64 l = 1 + q + q * (q - 1) / 2;
+  if (l >= ((i64)1 << 31)) { atomicOr(too_long, 1u); len[i] = 0; return; }
+  len[i] = (u32)l;
+}
+
+// one wavefront per row: singles copied, then for every p1 the lanes take the p2 > p1
+template <typename VT>
+__global__ __launch_bounds__(256) void k_cooc_fill(const i64* __restrict__ rowptr, const u32* __restrict__ col, const VT* __restrict__ val,
+                                                   i64 n, i64 nb, const i64* __restrict__ orow, u32* __restrict__ ocol,
+                                                   double* __restrict__ oval, u32* __restrict__ erow, u32* __restrict__ not_count) {
+  const i64 i = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const i64 b = rowptr[i], q1 = rowptr[i + 1] - b;            // incl. bias
+  const i64 o = orow[i];
+  u32 bad = 0;
+  for (i64 p = lane; p < q1; p += 64) {
+    const double v = (double)val[b + p];
+    ocol[o + p] = col[b + p]; oval[o + p] = v; erow[o + p] = (u32)i;
+    if (!(v >= 0.0 && v <= 16777216.0 && v == floor(v))) bad = 1;
+  }
+  const i64 q = q1 - 1;
+  for (i64 p1 = 0; p1 + 1 < q; p1++) {
+    const u32 c1 = col[b + 1 + p1];
+    const double v1 = (double)val[b + 1 + p1];
+    const i64 base = o + q1 + p1 * (2 * q - p1 - 1) / 2;       // pairs (p1, *) follow those of all p < p1
+    for (i64 p2 = p1 + 1 + lane; p2 < q; p2 += 64) {
+      const double v = v1 * (double)val[b + 1 + p2];
+      const i64 pos = base + (p2 - p1 - 1);
+      ocol[pos] = (u32)d_ind2sub(nb, (i64)c1 - 1, (i64)col[b + 1 + p2] - 1);
+      oval[pos] = v; erow[pos] = (u32)i;
+      if (!(v >= 0.0 && v <= 16777216.0 && v == floor(v))) bad = 1;
+    }
+  }
+  if (bad) atomicOr(not_count, 1u);
+}
+
+__global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ a, i64 n, float* __restrict__ b) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = (float)a[i];
+}
+
+extern "C" int64_t klr_coeff_dim(int64_t n) { return (n + 1) * n / 2 + 1; }
+extern "C" int64_t klr_coeff_ind2sub(int64_t n, int64_t k1, int64_t k2) {
+  return k1 == k2 ? k1 + 1 : n + (n * (n - 1) / 2) - (n - k1) * ((n - k1) - 1) / 2 + k2 - k1;
+}
+extern "C" void klr_coeff_sub2ind(int64_t n, int64_t i, int64_t* k1, int64_t* k2) {
+  if (i < n) { if (k1) *k1 = i; if (k2) *k2 = i; return; }
+  i -= n;
+  const int64_t a = n - 2 - (int64_t)std::floor(std::sqrt((double)(-8 * i + 4 * n * (n - 1) - 7)) / 2.0 - 0.5);
+  if (k1) *k1 = a;
+  if (k2) *k2 = i + a + 1 - n * (n - 1) / 2 + (n - a) * ((n - a) - 1) / 2;
+}
+
+extern "C" int klr_mat_expand_cooccurrence(klr_ctx* ctx, const klr_mat* base, klr_mat** out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, base != nullptr && out != nullptr);
+  *out = nullptr;
+  const i64 n = base->n, nb = base->dim - 1;
+  KLR_ARG(ctx, nb >= 1 && nb < 65536);                              // Dim = nb (nb+1)/2 + 1 must stay below 2^31
+  const i64 dim = klr_coeff_dim(nb);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  TmpPool tmp;
+  u32 *len, *flags;
+  KLR_TRY(tmp.get(ctx, &len, (size_t)std::max<i64>(n, 1))); KLR_TRY(tmp.get(ctx, &flags, 2));
+  KLR_HIP(ctx, hipMemsetAsync(flags, 0, 8, st));
+  if (n) hipLaunchKernelGGL(k_cooc_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, base->rowptr, n, len, flags);
+  klr_mat* m = new klr_mat();
+  m->ctx = ctx; m->device = ctx->device; m->n = n; m->dim = dim; m->n_total = base->n_total; m->n_total_all = base->n_total_all;
+  m->n1_local = base->n1_local; m->h_labels = base->h_labels; m->val_f64 = true;
+  int rc = KLR_OK;
+  do {
+    if ((rc = dalloc(ctx, &m->rowptr, (size_t)n + 1))) break;
+    if ((rc = exscan64(ctx, len, n, m->rowptr))) break;
+    i64 nnz = 0;
+    if ((rc = d2h_sync(ctx, &nnz, m->rowptr + n, 8))) break;
+    u32 hflag = 0;
+    if ((rc = d2h_sync(ctx, &hflag, flags, 4))) break;
+    if (hflag || nnz >= ((i64)1 << 32)) { rc = klr_fail(ctx, KLR_EINVAL, "co-occurrence matrix too large (%lld entries): pre-select fewer features", (long long)nnz); break; }
+    m->nnz = nnz;
+    m->avg_row = n ? (double)nnz / (double)n : 0.0;
+    double* dval; u32* erow;
+    if ((rc = dalloc(ctx, &m->col, (size_t)nnz))) break;
+    if ((rc = tmp.get(ctx, &dval, (size_t)nnz))) break;
+    if ((rc = tmp.get(ctx, &erow, (size_t)nnz))) break;
+    if ((rc = dalloc(ctx, &m->labels, (size_t)std::max<i64>(n, 1)))) break;
+    if (n) {
+      const dim3 grid((unsigned)ceil_div(n, 4));
+      if (base->val_f64) hipLaunchKernelGGL(k_cooc_fill<double>, grid, dim3(256), 0, st, base->rowptr, base->col, (const double*)base->val, n, nb, m->rowptr, m->col, dval, erow, flags + 1);
+      else               hipLaunchKernelGGL(k_cooc_fill<float>, grid, dim3(256), 0, st, base->rowptr, base->col, (const float*)base->val, n, nb, m->rowptr, m->col, dval, erow, flags + 1);
+      if (hipMemcpyAsync(m->labels, base->labels, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "label copy failed"); break; }
+      if (base->active) {
+        if (hipMalloc((void**)&m->active, (size_t)n) != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "out of device memory"); break; }
+        if (hipMemcpyAsync(m->active, base->active, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "mask copy failed"); break; }
+      }
+    }
+    if (hipGetLastError() != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "co-occurrence kernels failed"); break; }
+    u32 not_count = 0;
+    if ((rc = d2h_sync(ctx, &not_count, flags + 1, 4))) break;
+    if (!not_count) {
+      // products of counts: the device ingest finishes CSC and tiles
+      m->val_f64 = false;
+      if ((rc = dev_alloc(ctx, &m->val, (size_t)std::max<i64>(nnz, 1) * 4))) break;
+      if (nnz) hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, dval, nnz, (float*)m->val);
+      rc = finish_from_device_csr(ctx, m, erow, tmp);
+    } else {
+      // real-valued scores (small, dense inputs): the host ingest builds the layouts from a copy of the CSR
+      std::vector<i64> h_rp((size_t)n + 1), h_col64((size_t)nnz);
+      std::vector<u32> h_col((size_t)nnz);
+      std::vector<double> h_val((size_t)nnz);
+      if ((rc = d2h_sync(ctx, h_rp.data(), m->rowptr, (size_t)(n + 1) * 8))) break;
+      if (nnz && (rc = d2h_sync(ctx, h_col.data(), m->col, (size_t)nnz * 4))) break;
+      if (nnz && (rc = d2h_sync(ctx, h_val.data(), dval, (size_t)nnz * 8))) break;
+      for (i64 a = 0; a < nnz; a++) h_col64[(size_t)a] = h_col[(size_t)a];
+      klr_mat* hm = nullptr;
+      rc = klr_mat_from_csr(ctx, n, dim, h_rp.data(), h_col64.data(), h_val.data(), base->h_labels.data(), base->n_total_all, &hm);
+      if (rc != KLR_OK) break;
+      if (base->active) {
+        std::vector<uint8_t> h_act((size_t)n);
+        if ((rc = d2h_sync(ctx, h_act.data(), base->active, (size_t)n))) { mat_free(hm); break; }
+        if ((rc = klr_mat_set_active_rows(ctx, hm, h_act.data(), base->n_total))) { mat_free(hm); break; }
+      }
+      mat_free(m);
+      m = hm;
+    }
+  } while (0);
+  if (rc == KLR_OK && hipStreamSynchronize(st) != hipSuccess) rc = klr_fail(ctx, KLR_EHIP, "co-occurrence expansion failed");
+  if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(m); ctx->err = keep; return rc; }
+  *out = m;
+  return KLR_OK;
+}

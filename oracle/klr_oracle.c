@@ -231,6 +231,50 @@ int klo_select_fixed(const double* g_full, int64_t m, uint8_t* b, int64_t c_prev
   return ok;
 }
 
+/* CoeffIndex.Dim / Ind2Sub / Sub2Ind, kmerLr_coefficients_index.go:30-54 */
+int64_t klo_coeff_dim(int64_t n) { return (n + 1) * n / 2 + 1; }                       /* :30-33 */
+int64_t klo_coeff_ind2sub(int64_t n, int64_t k1, int64_t k2) {                          /* :35-42 */
+  if (k1 == k2) return k1 + 1;
+  return n + (n * (n - 1) / 2) - (n - k1) * ((n - k1) - 1) / 2 + k2 - k1;
+}
+void klo_coeff_sub2ind(int64_t n, int64_t i, int64_t* k1, int64_t* k2) {                /* :44-54 */
+  if (i < n) { *k1 = i; *k2 = i; return; }
+  i -= n;
+  const int64_t a = n - 2 - (int64_t)floor(sqrt((double)(-8 * i + 4 * n * (n - 1) - 7)) / 2.0 - 0.5);
+  *k1 = a;
+  *k2 = i + a + 1 - n * (n - 1) / 2 + (n - a) * ((n - a) - 1) / 2;
+}
+
+/* The explicit form of what LinearPdf / Gradient compute on the fly with Cooccurrence set
+ * (kmerLr_logistic_regression.go:69-85 and :183-195): every pair j1 < j2 of stored non-bias entries of a row
+ * contributes v[j1]*v[j2] at parameter Ind2Sub(i[j1]-1, i[j2]-1).  Pairs come out in ascending column order
+ * because Ind2Sub is lexicographic in (k1, k2). */
+int klo_expand_cooccurrence(const klo_csr* x, int64_t** rowptr_out, int64_t** col_out, double** val_out) {
+  const int64_t n = x->n, nb = x->dim - 1;
+  int64_t* rp = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+  rp[0] = 0;
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t q = x->rowptr[i + 1] - x->rowptr[i] - 1;            /* stored non-bias entries */
+    rp[i + 1] = rp[i] + 1 + q + q * (q - 1) / 2;
+  }
+  const int64_t cap = rp[n];
+  int64_t* ci = (int64_t*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(int64_t));
+  double*  cv = (double*)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(double));
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t b = x->rowptr[i], e = x->rowptr[i + 1];
+    int64_t o = rp[i];
+    for (int64_t p = b; p < e; p++) { ci[o] = x->col[p]; cv[o] = x->val[p]; o++; }       /* bias + singles */
+    for (int64_t p1 = b + 1; p1 < e; p1++)
+      for (int64_t p2 = p1 + 1; p2 < e; p2++) {
+        ci[o] = klo_coeff_ind2sub(nb, x->col[p1] - 1, x->col[p2] - 1);
+        cv[o] = x->val[p1] * x->val[p2];
+        o++;
+      }
+  }
+  *rowptr_out = rp; *col_out = ci; *val_out = cv;
+  return 0;
+}
+
 /* featureSelection.Data, kmerLr_feature_selection.go:309-343, followed by Transform.Apply
  * (kmerLr_transform.go:584-629) with the already-selected scale/offset (length c+1).
  * cols = ascending selected column ids incl. 0. */

@@ -86,6 +86,16 @@ int    klo_select_columns(const klo_csr* x, const int64_t* cols, int64_t c_plus_
                           int64_t** rowptr_out, int64_t** col_out, double** val_out);
 void   klo_free(void* p);
 
+/* CoeffIndex (kmerLr_coefficients_index.go:26-54): parameter index of a feature pair in co-occurrence mode.
+ * n = number of base features (without bias); singles at k+1, pairs (k1<k2) after them, lexicographic. */
+int64_t klo_coeff_dim(int64_t n);
+int64_t klo_coeff_ind2sub(int64_t n, int64_t k1, int64_t k2);
+void    klo_coeff_sub2ind(int64_t n, int64_t i, int64_t* k1, int64_t* k2);
+/* The co-occurrence feature matrix written out: row = {0:1, k+1: v_k, Ind2Sub(k1,k2): v_k1*v_k2} for the stored
+ * entries of the base row (LinearPdf / Gradient with Cooccurrence, kmerLr_logistic_regression.go:69-85,183-195;
+ * featureSelection.Data :325-330).  Outputs are malloc'ed; free with klo_free. */
+int    klo_expand_cooccurrence(const klo_csr* x, int64_t** rowptr_out, int64_t** col_out, double** val_out);
+
 int    klo_eval_stopping(const double* xs, const double* x1, int64_t len,
                          double epsilon, double* delta_out);
 

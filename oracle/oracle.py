@@ -58,6 +58,13 @@ def lib():
         L.klo_select.argtypes = [vp, i64, vp, i64, i64, C.c_double, C.c_double, dp, C.POINTER(i64)]
         L.klo_select_fixed.restype = C.c_int
         L.klo_select_fixed.argtypes = [vp, i64, vp, i64, C.c_double, i64, C.POINTER(i64)]
+        L.klo_coeff_dim.restype = i64
+        L.klo_coeff_dim.argtypes = [i64]
+        L.klo_coeff_ind2sub.restype = i64
+        L.klo_coeff_ind2sub.argtypes = [i64, i64, i64]
+        L.klo_coeff_sub2ind.argtypes = [i64, i64, C.POINTER(i64), C.POINTER(i64)]
+        L.klo_expand_cooccurrence.restype = C.c_int
+        L.klo_expand_cooccurrence.argtypes = [C.POINTER(_Csr), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.klo_select_columns.restype = C.c_int
         L.klo_select_columns.argtypes = [C.POINTER(_Csr), vp, i64, vp, vp,
                                          C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -202,6 +209,34 @@ def select_columns(x, cols, scale=None, offset=None):
     for p in (rp, ci, cv):
         lib().klo_free(p)
     return Csr(n, len(cols), rowptr, col, val)
+
+
+def coeff_dim(n):
+    return int(lib().klo_coeff_dim(int(n)))
+
+
+def coeff_ind2sub(n, k1, k2):
+    return int(lib().klo_coeff_ind2sub(int(n), int(k1), int(k2)))
+
+
+def coeff_sub2ind(n, i):
+    a, b = C.c_int64(), C.c_int64()
+    lib().klo_coeff_sub2ind(int(n), int(i), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def expand_cooccurrence(x):
+    """Co-occurrence feature matrix of x in CoeffIndex column order (singles, then pairs)."""
+    rp, ci, cv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    lib().klo_expand_cooccurrence(x.ref, C.byref(rp), C.byref(ci), C.byref(cv))
+    n = x.n
+    rowptr = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+    nnz = int(rowptr[-1])
+    col = np.ctypeslib.as_array(C.cast(ci, C.POINTER(C.c_int64)), shape=(max(nnz, 1),))[:nnz].copy()
+    val = np.ctypeslib.as_array(C.cast(cv, C.POINTER(C.c_double)), shape=(max(nnz, 1),))[:nnz].copy()
+    for p in (rp, ci, cv):
+        lib().klo_free(p)
+    return Csr(n, coeff_dim(x.dim - 1), rowptr, col, val)
 
 
 def eval_stopping(xs, x1, eps):

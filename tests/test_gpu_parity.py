@@ -435,3 +435,65 @@ def test_transform_fit_on_device(ctx, synth_small, kind):
     assert (of is None) == (ofo is None)
     if of is not None:
         np.testing.assert_allclose(of, ofo, rtol=1e-12, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------------
+# co-occurrence features: the pair matrix written out on the device
+# ---------------------------------------------------------------------------------------------------
+def _assert_same_csr(m, e):
+    rp, col, val = m.to_csr()
+    np.testing.assert_array_equal(rp, e.rowptr)
+    np.testing.assert_array_equal(col, e.col)
+    np.testing.assert_array_equal(val, e.val)
+
+
+def test_cooccurrence_expansion_counts(ctx):
+    # k-mer counts restricted to 40 pre-selected columns: products of counts stay count data (device ingest)
+    x, labels = O.synth_csr(7, 0, 3000, 3000, 400, 120, 8)
+    cols = np.r_[0, 1 + np.sort(np.random.default_rng(5).choice(400, size=40, replace=False))]
+    xs = O.select_columns(x, cols)
+    base = upload(ctx, x, labels).select_columns(cols)
+    m = base.expand_cooccurrence()
+    e = O.expand_cooccurrence(xs)
+    assert m.dim == e.dim == 40 * 41 // 2 + 1
+    _assert_same_csr(m, e)
+    theta = np.zeros(e.dim); theta[0] = 0.1
+    theta[np.random.default_rng(6).choice(e.dim - 1, size=30, replace=False) + 1] = 0.01
+    assert_g_close(K.gradient_dense(ctx, m, theta), O.gradient(e, labels, theta))
+    assert abs(K.loss(ctx, m, theta) - O.loss(e, labels, theta)) < LOSS_ATOL
+
+
+def test_cooccurrence_expansion_scores_and_golden_selection(ctx, golden_dir):
+    # TestScores2 (scoresLr_test.go:64-91): real-valued scores; --lambda-auto=1 --co-occurrence picks the pair (1, 2)
+    import os
+    _, fg = O.read_scores_table(os.path.join(golden_dir, "scoresLr_test_co_fg.table"))
+    _, bg = O.read_scores_table(os.path.join(golden_dir, "scoresLr_test_co_bg.table"))
+    dense = np.concatenate([fg, bg], axis=0)
+    labels = np.array([1] * len(fg) + [0] * len(bg), dtype=np.uint8)
+    x = O.Csr.from_dense(dense)
+    m = upload(ctx, x, labels).expand_cooccurrence()
+    e = O.expand_cooccurrence(x)
+    _assert_same_csr(m, e)
+    r = K.sweep_select(ctx, m, None, None, np.zeros(1), (1.0, 1.0), 1, want_g=True)
+    assert_g_close(r["g"], O.gradient(e, labels, np.zeros(e.dim)))
+    picked = np.nonzero(r["b"])[0][1:]
+    assert len(picked) == 1 and K.coeff_sub2ind(dense.shape[1], int(picked[0]) - 1) == (1, 2)
+
+
+def test_cooccurrence_inherits_row_mask(ctx):
+    x, labels = O.synth_csr(9, 0, 2500, 2500, 60, 40, 4)
+    mat = upload(ctx, x, labels)
+    mask = (np.arange(x.n) % 5 != 2).astype(np.uint8)
+    mat.set_active_rows(mask)
+    m = mat.expand_cooccurrence()
+    keep = np.nonzero(mask)[0]
+    xe = O.expand_cooccurrence(x)
+    sub = O.Csr.from_rows(xe, keep) if hasattr(O.Csr, "from_rows") else None
+    theta = np.zeros(xe.dim); theta[0] = -0.2; theta[5] = 0.03
+    g = K.gradient_dense(ctx, m, theta)
+    if sub is not None:
+        assert_g_close(g, O.gradient(sub, labels[keep], theta))
+    else:
+        # the masked gradient equals the gradient of the kept rows: compare through a re-upload of those rows
+        d = xe.to_dense()[keep]
+        assert_g_close(g, O.gradient(O.Csr.from_dense(d[:, 1:]), labels[keep], theta))

@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/klr_oracle.c) against the reference's own known answers
 (SURVEY.md section 8(c), G1-G7).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,3 +226,59 @@ def test_transform_fit_definitions():
     np.testing.assert_allclose(sc3[1:][d.max(axis=0) > 0], 1.0 / d.max(axis=0)[d.max(axis=0) > 0])
     sc4, _ = O.transform_fit(x, "mean-scaler")
     np.testing.assert_allclose(sc4[1:][d.sum(axis=0) > 0], 120.0 / d.sum(axis=0)[d.sum(axis=0) > 0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# co-occurrence features: CoeffIndex and the written-out pair matrix
+# ---------------------------------------------------------------------------------------------------
+def _co_tables(golden_dir):
+    _, fg = O.read_scores_table(os.path.join(golden_dir, "scoresLr_test_co_fg.table"))
+    _, bg = O.read_scores_table(os.path.join(golden_dir, "scoresLr_test_co_bg.table"))
+    x = np.concatenate([fg, bg], axis=0)
+    labels = np.array([1] * len(fg) + [0] * len(bg), dtype=np.uint8)
+    return O.Csr.from_dense(x), labels, x
+
+
+def test_coeff_index_is_a_bijection():
+    # kmerLr_coefficients_index.go:30-54: Ind2Sub / Sub2Ind are inverse, pairs are lexicographic after the singles
+    for n in (1, 2, 7, 50):
+        seen = []
+        for k1 in range(n):
+            for k2 in range(k1, n):
+                j = O.coeff_ind2sub(n, k1, k2)
+                assert O.coeff_sub2ind(n, j - 1) == (k1, k2)
+                seen.append(j)
+        assert sorted(seen) == list(range(1, O.coeff_dim(n)))
+        pairs = [O.coeff_ind2sub(n, k1, k2) for k1 in range(n) for k2 in range(k1 + 1, n)]
+        assert pairs == sorted(pairs)
+
+
+def test_cooccurrence_expansion_matches_definition(golden_dir):
+    x, labels, dense = _co_tables(golden_dir)
+    e = O.expand_cooccurrence(x)
+    n = dense.shape[1]
+    assert e.dim == n * (n + 1) // 2 + 1
+    de = e.to_dense()
+    for k1 in range(n):
+        np.testing.assert_array_equal(de[:, k1 + 1], dense[:, k1])
+        for k2 in range(k1 + 1, n):
+            np.testing.assert_array_equal(de[:, O.coeff_ind2sub(n, k1, k2)], dense[:, k1] * dense[:, k2])
+    # LinearPdf with Cooccurrence (kmerLr_logistic_regression.go:69-85) == plain LinearPdf on the written-out matrix
+    rng = np.random.default_rng(0)
+    theta = rng.normal(size=e.dim) * 1e-3
+    for i in range(x.n):
+        r = theta[0] + sum(dense[i, k] * theta[k + 1] for k in range(n))
+        r += sum(dense[i, k1] * dense[i, k2] * theta[O.coeff_ind2sub(n, k1, k2)] for k1 in range(n) for k2 in range(k1 + 1, n))
+        assert abs(O.linear_pdf(e, i, theta) - r) <= 1e-12 * max(1.0, abs(r))
+
+
+def test_golden_scores2_cooccurrence_selection(golden_dir):
+    # TestScores2 (scoresLr_test.go:64-91): --lambda-auto=1 --co-occurrence selects the pair of features (1, 2)
+    x, labels, dense = _co_tables(golden_dir)
+    e = O.expand_cooccurrence(x)
+    g = O.gradient(e, labels, np.zeros(e.dim))
+    b = np.zeros(e.dim, dtype=np.uint8); b[0] = 1
+    ok, lam, c, b2 = O.select(g[1:], b, 0, 1)
+    picked = np.nonzero(b2)[0][1:]
+    assert len(picked) == 1
+    assert O.coeff_sub2ind(dense.shape[1], int(picked[0]) - 1) == (1, 2)
