@@ -42,6 +42,7 @@ typedef struct klr_backend {
                    int64_t, klr_iter_rec*, int64_t, int64_t*);
   int  (*set_active_rows)(klr_ctx*, klr_mat*, const uint8_t*, int64_t);
   int  (*log_pdf)(klr_ctx*, const klr_mat*, const double*, double*);
+  int  (*expand_cooccurrence)(klr_ctx*, const klr_mat*, klr_mat**);      /* co-occurrence mode only; may be NULL */
 } klr_backend;
 
 /* the HIP table for an existing context */
@@ -63,6 +64,8 @@ typedef struct klr_config {
   int     save_path;         /* --save-path                                          */
   int     verbose;           /* -v / -vv                                             */
   double  l2reg;             /* L2Reg of the estimator (0 in the reference's CLI)    */
+  int     cooccurrence;      /* --co-occurrence (used by klr_cooccurrence_prepare's callers) */
+  int64_t copreselection;    /* --co-preselection, 0 = none                          */
 } klr_config;
 
 void klr_config_default(klr_config* cfg);
@@ -116,6 +119,23 @@ void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t row0, int64_
 int  klr_save_crossvalidation(const char* filename, const double* predictions, const uint8_t* labels,
                               const int32_t* groups, int64_t n, int k_fold);
 int  klr_save_crossvalidation_loss(const char* filename, const double* loss_train, const double* loss_test, int k_fold);
+
+/* Co-occurrence set-up ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:98-117,
+ * scoresLr_estimator_ensemble.go:98-117).  With cfg.copreselection = q > 0 a first estimate_loop with lambda_auto = q
+ * and WITHOUT co-occurrence runs on `data` (transform pre_scale / pre_offset, nullable), the data are restricted to
+ * the q selected features (raw values, SelectData) and the estimator state is discarded (Reset); then the pair matrix
+ * of the (restricted) data is written out (klr_mat_expand_cooccurrence) and returned -- an ordinary data matrix for
+ * klr_estimator_estimate, klr_transform_fit, ... whose column j >= 1 is the feature pair
+ *   (k1, k2) = klr_coeff_sub2ind(nb, j-1)  ->  original 0-based features (base_cols[k1+1]-1, base_cols[k2+1]-1).
+ *   base_cols   out, capacity = dim of `data`: ascending columns of `data` kept (incl. 0); n_base_cols = nb + 1 */
+int  klr_cooccurrence_prepare(const klr_backend* be, const klr_config* cfg, const klr_mat* data, const double* pre_scale,
+                              const double* pre_offset, klr_mat** expanded, int64_t* base_cols, int64_t* n_base_cols,
+                              char* errbuf, int64_t errcap);
+/* model JSON with feature pairs (Cooccurrence = true): pairs[2k], pairs[2k+1] = 0-based original features of the
+ * k-th selected column (equal for a single feature).  "Index" = the distinct features used, ascending; "Features" =
+ * positions in Index (scoresLr_feature.go:75-80, kmerLr_features.go:224-235). */
+int  klr_estimator_save_model_pairs(const klr_estimator* est, int64_t i, const char* filename, const char* type_name,
+                                    const char* const* names, const int64_t* pairs);
 
 /* Trace.Export (kmerLr_estimator_trace.go:49-78) */
 int  klr_estimator_save_trace(const klr_estimator* est, const char* filename);

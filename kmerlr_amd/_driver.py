@@ -12,7 +12,7 @@ from . import _capi
 class Backend(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ctx", "last_error", "mat_shape", "mat_destroy", "class_weights", "gradient",
                                           "loss", "select_columns", "sweep_select", "cd_solve", "set_active_rows",
-                                          "log_pdf")]
+                                          "log_pdf", "expand_cooccurrence")]
 
 
 class Config(C.Structure):
@@ -20,7 +20,8 @@ class Config(C.Structure):
     _fields_ = [("lambda_", C.c_double), ("max_features", C.c_int64), ("max_epochs", C.c_int64),
                 ("max_iterations", C.c_int64), ("epsilon", C.c_double), ("epsilon_lambda", C.c_double),
                 ("epsilon_loss", C.c_double), ("eval_loss", C.c_int), ("balance", C.c_int), ("penalty_free", C.c_int),
-                ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double)]
+                ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double),
+                ("cooccurrence", C.c_int), ("copreselection", C.c_int64)]
 
 
 def bind_driver(L):
@@ -57,7 +58,28 @@ def bind_driver(L):
     L.klr_save_crossvalidation_loss.argtypes = [C.c_char_p, vp, vp, C.c_int]
     L.klr_estimator_save_model.restype = C.c_int
     L.klr_estimator_save_model.argtypes = [vp, i64, C.c_char_p, C.c_char_p, vp]
+    L.klr_estimator_save_model_pairs.restype = C.c_int
+    L.klr_estimator_save_model_pairs.argtypes = [vp, i64, C.c_char_p, C.c_char_p, vp, vp]
+    L.klr_cooccurrence_prepare.restype = C.c_int
+    L.klr_cooccurrence_prepare.argtypes = [C.POINTER(Backend), C.POINTER(Config), vp, vp, vp, C.POINTER(vp), vp, C.POINTER(i64),
+                                           C.c_char_p, i64]
     return L
+
+
+def cooccurrence_prepare(L, backend, cfg, mat_handle, dim, pre_scale=None, pre_offset=None):
+    """klr_cooccurrence_prepare: returns (expanded matrix handle, base_cols).  The caller destroys the handle
+    through the backend's mat_destroy."""
+    out = C.c_void_p()
+    cols = np.zeros(dim, dtype=np.int64)
+    nb1 = C.c_int64()
+    err = C.create_string_buffer(512)
+    ps = None if pre_scale is None else np.ascontiguousarray(pre_scale, dtype=np.float64)
+    po = None if pre_offset is None else np.ascontiguousarray(pre_offset, dtype=np.float64)
+    rc = L.klr_cooccurrence_prepare(C.byref(backend), C.byref(cfg), mat_handle, None if ps is None else ps.ctypes.data,
+                                    None if po is None else po.ctypes.data, C.byref(out), cols.ctypes.data, C.byref(nb1), err, 512)
+    if rc != 0:
+        raise _capi.KlrError("klr_cooccurrence_prepare failed (%d): %s" % (rc, err.value.decode()))
+    return out, cols[:nb1.value].copy()
 
 
 def default_config(L, **kw):
@@ -174,6 +196,16 @@ class Estimator:
             arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
         self._check(self.L.klr_estimator_save_model(self._h, i, filename.encode(), type_name.encode(),
                                                     None if arr is None else C.cast(arr, C.c_void_p)))
+
+
+    def save_model_pairs(self, i, filename, pairs, type_name="scoresLr", names=None):
+        """pairs: [(f1, f2)] 0-based original features of every selected column (co-occurrence models)."""
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+        pr = np.ascontiguousarray(np.asarray(pairs, dtype=np.int64).reshape(-1))
+        self._check(self.L.klr_estimator_save_model_pairs(self._h, i, filename.encode(), type_name.encode(),
+                                                          None if arr is None else C.cast(arr, C.c_void_p), pr.ctypes.data))
 
 
 def hip_estimator(ctx, **config):

@@ -187,6 +187,58 @@ static std::vector<double> json_numbers_after(const std::string& s, const std::s
   return out;
 }
 
+// The data restricted to a model's features, transform applied (SelectData, kmerLr_classifier.go:125-147): plain
+// models select the Index columns; co-occurrence models (Cooccurrence = true) select them, write out the pair matrix
+// of that restriction and pick the columns of the Features pairs.  theta is permuted along if the columns need sorting.
+static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& js, std::vector<double>& theta) {
+  size_t pos = 0;
+  std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
+  const size_t dpos = js.find("\"Distributions\"");
+  theta = json_numbers_after(js, "Parameters", dpos, &pos);
+  std::vector<double> offset = json_numbers_after(js, "Offset", pos, nullptr);
+  std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
+  const size_t cp = js.find("\"Cooccurrence\"");
+  const bool co = cp != std::string::npos && js.compare(js.find(':', cp) + 1, 5, " true") == 0;
+  std::vector<int64_t> cols{0};
+  for (double v : index) cols.push_back((int64_t)v + 1);
+  klr_mat* red = nullptr;
+  if (!co) {
+    if (theta.size() != index.size() + 1) die("invalid config file");
+    if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
+                               offset.empty() ? nullptr : offset.data(), &red) != KLR_OK)
+      die("%s", klr_last_error(ctx));
+    return red;
+  }
+  std::vector<double> feat = json_numbers_after(js, "Features", 0, nullptr);
+  const size_t nf = feat.size() / 2;
+  if (theta.size() != nf + 1) die("invalid config file");
+  const int64_t q = (int64_t)index.size();
+  klr_mat *base = nullptr, *ex = nullptr;
+  if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), nullptr, nullptr, &base) != KLR_OK) die("%s", klr_last_error(ctx));
+  if (klr_mat_expand_cooccurrence(ctx, base, &ex) != KLR_OK) die("%s", klr_last_error(ctx));
+  std::vector<std::pair<int64_t, size_t>> order;                       // expanded column, position in the model
+  for (size_t k = 0; k < nf; k++) {
+    const int64_t a = (int64_t)std::min(feat[2 * k], feat[2 * k + 1]), b = (int64_t)std::max(feat[2 * k], feat[2 * k + 1]);
+    if (a < 0 || b >= q) die("invalid config file");
+    order.emplace_back(klr_coeff_ind2sub(q, a, b), k);
+  }
+  std::sort(order.begin(), order.end());
+  std::vector<int64_t> ecols{0};
+  std::vector<double> th{theta[0]}, sc, of;
+  if (!scale.empty()) sc.push_back(scale[0]);
+  if (!offset.empty()) of.push_back(offset[0]);
+  for (auto& pr : order) {
+    ecols.push_back(pr.first); th.push_back(theta[pr.second + 1]);
+    if (!scale.empty()) sc.push_back(scale[pr.second + 1]);
+    if (!offset.empty()) of.push_back(offset[pr.second + 1]);
+  }
+  if (klr_mat_select_columns(ctx, ex, ecols.data(), (int64_t)ecols.size(), sc.empty() ? nullptr : sc.data(), of.empty() ? nullptr : of.data(), &red) != KLR_OK)
+    die("%s", klr_last_error(ctx));
+  klr_mat_destroy(ex); klr_mat_destroy(base);
+  theta = th;
+  return red;
+}
+
 struct Options { std::map<std::string, std::string> kv; std::vector<std::string> pos; };
 static Options parse(int argc, char** argv, int from) {
   Options o;
@@ -257,7 +309,11 @@ int main(int argc, char** argv) {
     if (kfold < 1) die("invalid --k-fold-cv");
     if (atoi(opt(o, "ensemble-size", "1").c_str()) != 1)
       die("--ensemble-size is not part of this build (DESIGN.md, out of scope)");
-    if (flag(o, "co-occurrence")) die("--co-occurrence is not part of this build (DESIGN.md, out of scope)");
+    cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;
+    cfg.copreselection = atoll(opt(o, "co-preselection", "0").c_str());
+    if (cfg.copreselection != 0 && !cfg.cooccurrence) die("--co-preselection needs --co-occurrence");
+    if (cfg.cooccurrence && cfg.copreselection > 0 && kfold > 1)
+      die("--co-preselection together with --k-fold-cv is not part of this build (the pre-selection would have to run per fold)");
 
     DataSet d;
     SeqSet sq;
@@ -288,6 +344,42 @@ int main(int argc, char** argv) {
     } else {
       mat = count_kmers(ctx, sq, ks);
     }
+    // co-occurrence mode ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:98-117): optional
+    // pre-selection with the transform fitted on the base data, then the pair matrix takes the place of the data
+    klr_mat* base_mat = nullptr;
+    std::vector<int64_t> base_cols;
+    int64_t nb1 = 0;
+    if (cfg.cooccurrence) {
+      std::vector<double> ps, po;
+      if (cfg.copreselection > 0) fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), ps, po);
+      base_cols.assign((size_t)d.dim, 0);
+      klr_mat* ex = nullptr;
+      char eb[512] = "";
+      say(1, "Compiling co-occurrence features... ");
+      if (klr_cooccurrence_prepare(&be, &cfg, mat, ps.empty() ? nullptr : ps.data(), po.empty() ? nullptr : po.data(), &ex, base_cols.data(), &nb1,
+                                   eb, sizeof(eb)) != KLR_OK)
+        die("failed\n%s", eb);
+      say(1, "done\n");
+      base_mat = mat;
+      mat = ex;
+      d.dim = klr_coeff_dim(nb1 - 1);
+    }
+    // 0-based original features of expanded column j >= 1
+    auto pair_of = [&](int64_t j, int64_t* f1, int64_t* f2) {
+      int64_t k1, k2;
+      klr_coeff_sub2ind(nb1 - 1, j - 1, &k1, &k2);
+      *f1 = base_cols[(size_t)k1 + 1] - 1; *f2 = base_cols[(size_t)k2 + 1] - 1;
+    };
+    auto save_model = [&](klr_estimator* e, int64_t i, const char* fn, const std::vector<const char*>& nm) {
+      const char* tn = scores ? "scoresLr" : "kmerLr";
+      if (!cfg.cooccurrence) return klr_estimator_save_model(e, i, fn, tn, nm.empty() ? nullptr : nm.data());
+      int64_t c1 = 0; const int64_t* cc = nullptr;
+      klr_estimator_classifier(e, i, &c1, &cc, nullptr, nullptr, nullptr, nullptr);
+      std::vector<int64_t> pairs;
+      for (int64_t k = 1; k < c1; k++) { int64_t f1, f2; pair_of(cc[k], &f1, &f2); pairs.push_back(f1); pairs.push_back(f2); }
+      if (pairs.empty()) pairs.push_back(0);
+      return klr_estimator_save_model_pairs(e, i, fn, tn, nm.empty() ? nullptr : nm.data(), pairs.data());
+    };
     std::vector<double> scale, offset;
     fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), scale, offset);
     klr_estimator* est = nullptr;
@@ -308,7 +400,7 @@ int main(int argc, char** argv) {
         if (nla == 1) snprintf(fn, sizeof(fn), "%s_cv%d.json", base.c_str(), f + 1);
         else snprintf(fn, sizeof(fn), "%s_cv%d_%lld.json", base.c_str(), f + 1, (long long)la[(size_t)j]);
         say(1, "Exporting model to `%s'... ", fn);
-        if (klr_estimator_save_model(est, f * nla + j, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data()) != KLR_OK) die("failed");
+        if (save_model(est, f * nla + j, fn, names) != KLR_OK) die("failed");
         say(1, "done\n");
       }
       for (int64_t j = 0; j < nla; j++) {                                                    // learn_cv :78-86
@@ -323,6 +415,7 @@ int main(int argc, char** argv) {
       }
       klr_estimator_destroy(est);
       klr_mat_destroy(mat);
+      if (base_mat) klr_mat_destroy(base_mat);
       klr_ctx_destroy(ctx);
       return 0;
     }
@@ -347,24 +440,19 @@ int main(int argc, char** argv) {
       if (nc == 1) snprintf(fn, sizeof(fn), "%s.json", base.c_str());
       else snprintf(fn, sizeof(fn), "%s_%lld.json", base.c_str(), (long long)la[(size_t)i]);
       say(1, "Exporting model to `%s'... ", fn);
-      if (klr_estimator_save_model(est, i, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data()) != KLR_OK) die("failed");
+      if (save_model(est, i, fn, names) != KLR_OK) die("failed");
       say(1, "done\n");
     }
     klr_estimator_destroy(est);
     klr_mat_destroy(mat);
+    if (base_mat) klr_mat_destroy(base_mat);
   } else if (cmd == "loss") {
     if (o.pos.size() != 3) die("usage: kmerlr loss [--lambda=F] MODEL.json FG BG");
     std::ifstream jf(o.pos[0]);
     if (!jf) die("cannot open `%s'", o.pos[0].c_str());
     std::stringstream buf; buf << jf.rdbuf();
     const std::string js = buf.str();
-    size_t pos = 0;
-    std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
-    size_t dpos = js.find("\"Distributions\"");
-    std::vector<double> theta = json_numbers_after(js, "Parameters", dpos, &pos);
-    std::vector<double> offset = json_numbers_after(js, "Offset", pos, nullptr);
-    std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
-    if (theta.size() != index.size() + 1) die("invalid config file");
+    std::vector<double> theta;
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
     if (scores) {
@@ -379,11 +467,7 @@ int main(int argc, char** argv) {
       read_fasta(o.pos[1], 1, sq); read_fasta(o.pos[2], 0, sq);
       mat = count_kmers(ctx, sq, ks);
     }
-    std::vector<int64_t> cols{0};
-    for (double v : index) cols.push_back((int64_t)v + 1);
-    if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
-                               offset.empty() ? nullptr : offset.data(), &red) != KLR_OK)
-      die("%s", klr_last_error(ctx));
+    red = model_data(ctx, mat, js, theta);
     const double cw[2] = {1.0, 1.0};
     double out = 0.0;
     if (klr_loss(ctx, red, theta.data(), cw, strtod(opt(o, "lambda", "NaN").c_str(), nullptr), &out) != KLR_OK) die("%s", klr_last_error(ctx));
@@ -396,13 +480,7 @@ int main(int argc, char** argv) {
     if (!jf) die("cannot open `%s'", o.pos[0].c_str());
     std::stringstream buf; buf << jf.rdbuf();
     const std::string js = buf.str();
-    size_t pos = 0;
-    std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
-    size_t dpos = js.find("\"Distributions\"");
-    std::vector<double> theta = json_numbers_after(js, "Parameters", dpos, &pos);
-    std::vector<double> offset = json_numbers_after(js, "Offset", pos, nullptr);
-    std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
-    if (theta.size() != index.size() + 1) die("invalid config file");
+    std::vector<double> theta;
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
     int64_t n = 0;
@@ -420,11 +498,7 @@ int main(int argc, char** argv) {
       n = (int64_t)sq.labels.size();
       mat = count_kmers(ctx, sq, ks);
     }
-    std::vector<int64_t> cols{0};
-    for (double v : index) cols.push_back((int64_t)v + 1);
-    if (klr_mat_select_columns(ctx, mat, cols.data(), (int64_t)cols.size(), scale.empty() ? nullptr : scale.data(),
-                               offset.empty() ? nullptr : offset.data(), &red) != KLR_OK)
-      die("%s", klr_last_error(ctx));
+    red = model_data(ctx, mat, js, theta);
     std::vector<double> out((size_t)std::max<int64_t>(n, 1));
     if (klr_log_pdf(ctx, red, theta.data(), out.data()) != KLR_OK) die("%s", klr_last_error(ctx));
     FILE* f = o.pos.size() == 3 ? fopen(o.pos[2].c_str(), "w") : stdout;

@@ -273,5 +273,6 @@ extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
   out->cd_solve = klr_cd_solve;
   out->set_active_rows = klr_mat_set_active_rows;
   out->log_pdf = klr_log_pdf;
+  out->expand_cooccurrence = klr_mat_expand_cooccurrence;
   return KLR_OK;
 }

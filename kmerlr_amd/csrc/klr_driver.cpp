@@ -501,3 +501,79 @@ extern "C" int klr_estimator_save_model(const klr_estimator* e, int64_t i, const
   fclose(f);
   return KLR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// co-occurrence mode
+// ---------------------------------------------------------------------------------------------------
+extern "C" int klr_cooccurrence_prepare(const klr_backend* be, const klr_config* cfg, const klr_mat* data, const double* pre_scale,
+                                        const double* pre_offset, klr_mat** expanded, int64_t* base_cols, int64_t* n_base_cols,
+                                        char* errbuf, int64_t errcap) {
+  auto err = [&](const char* what, const char* detail) {
+    if (errbuf && errcap > 0) snprintf(errbuf, (size_t)errcap, "%s%s%s", what, detail && *detail ? ": " : "", detail ? detail : "");
+  };
+  if (!be || !cfg || !data || !expanded || !base_cols || !n_base_cols) return KLR_EINVAL;
+  *expanded = nullptr;
+  if (!be->expand_cooccurrence) { err("this backend has no co-occurrence expansion", ""); return KLR_EINVAL; }
+  int64_t n = 0, dim = 0;
+  if (be->mat_shape(data, &n, &dim, nullptr, nullptr) != KLR_OK) { err("mat_shape failed", ""); return KLR_EINVAL; }
+  const klr_mat* base = data;
+  klr_mat* owned = nullptr;
+  int64_t nb1 = dim;
+  for (int64_t j = 0; j < dim; j++) base_cols[j] = j;
+  if (cfg->copreselection > 0 && cfg->copreselection < dim - 1) {
+    // estimate_loop(config, data_train, transform, config.Copreselection, false), then SelectData and Reset
+    klr_config c2 = *cfg;
+    c2.lambda = NAN; c2.cooccurrence = 0; c2.copreselection = 0; c2.save_trace = 0; c2.save_path = 0;
+    klr_estimator* e = nullptr;
+    int rc = klr_estimator_create(be, &c2, &e);
+    if (rc != KLR_OK) { err("co-preselection: estimator_create failed", ""); return rc; }
+    const int64_t q = cfg->copreselection;
+    rc = klr_estimator_estimate(e, data, &q, 1, pre_scale, pre_offset);
+    if (rc != KLR_OK) { err("co-preselection failed", klr_estimator_error(e)); klr_estimator_destroy(e); return rc; }
+    int64_t c1 = 0; const int64_t* cols = nullptr;
+    klr_estimator_classifier(e, 0, &c1, &cols, nullptr, nullptr, nullptr, nullptr);
+    for (int64_t k = 0; k < c1; k++) base_cols[k] = cols[k];
+    nb1 = c1;
+    klr_estimator_destroy(e);
+    if ((rc = be->select_columns(be->ctx, data, base_cols, nb1, nullptr, nullptr, &owned)) != KLR_OK) {
+      err("co-preselection: select_columns failed", be->last_error ? be->last_error(be->ctx) : "");
+      return rc;
+    }
+    base = owned;
+  }
+  *n_base_cols = nb1;
+  const int rc = be->expand_cooccurrence(be->ctx, base, expanded);
+  if (rc != KLR_OK) err("co-occurrence expansion failed", be->last_error ? be->last_error(be->ctx) : "");
+  if (owned) be->mat_destroy(owned);
+  return rc;
+}
+
+extern "C" int klr_estimator_save_model_pairs(const klr_estimator* e, int64_t i, const char* filename, const char* type_name,
+                                              const char* const* names, const int64_t* pairs) {
+  if (!e || !filename || !pairs || i < 0 || i >= (int64_t)e->out.size()) return KLR_EINVAL;
+  const Classifier& c = e->out[(size_t)i];
+  const size_t nf = c.cols.size() - 1;
+  std::vector<int64_t> index(pairs, pairs + 2 * nf);
+  std::sort(index.begin(), index.end());
+  index.erase(std::unique(index.begin(), index.end()), index.end());
+  auto pos = [&](int64_t f) { return (size_t)(std::lower_bound(index.begin(), index.end(), f) - index.begin()); };
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  fprintf(f, "{\n  \"Name\": ");
+  json_str(f, type_name ? type_name : "scoresLr");
+  fprintf(f, ",\n  \"Parameters\": {\n    \"Cooccurrence\": true,\n    \"Features\": [");
+  for (size_t k = 0; k < nf; k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", pos(pairs[2 * k]), pos(pairs[2 * k + 1]));
+  fprintf(f, "],\n    \"Index\": [");
+  for (size_t k = 0; k < index.size(); k++) fprintf(f, "%s%lld", k ? "," : "", (long long)index[k]);
+  fprintf(f, "],\n    \"Names\": [");
+  if (names) for (size_t k = 0; k < index.size(); k++) { if (k) fputc(',', f); json_str(f, names[index[k]]); }
+  fprintf(f, "]\n  },\n  \"Distributions\": [\n    {\"Name\": \"vector:logistic regression\", \"Parameters\": [");
+  for (size_t k = 0; k < c.theta.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.theta[k]);
+  fprintf(f, "], \"Distributions\": null},\n    {\"Name\": \"transform\", \"Parameters\": {\"Offset\": [");
+  for (size_t k = 0; k < c.offset.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.offset[k]);
+  fprintf(f, "], \"Scale\": [");
+  for (size_t k = 0; k < c.scale.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.scale[k]);
+  fprintf(f, "]}, \"Distributions\": null}\n  ]\n}\n");
+  fclose(f);
+  return KLR_OK;
+}

@@ -120,6 +120,20 @@ static int ob_select_columns(klr_ctx* c, const klr_mat* m, const int64_t* cols, 
   return 0;
 }
 
+static int ob_expand_cooccurrence(klr_ctx* c, const klr_mat* m, klr_mat** out) {
+  int64_t *rp, *ci; double* cv;
+  klo_expand_cooccurrence(&m->all, &rp, &ci, &cv);
+  klr_mat* r = (klr_mat*)calloc(1, sizeof(klr_mat));
+  r->rowptr = rp; r->col = ci; r->val = cv;
+  r->labels = (uint8_t*)malloc((size_t)(m->all.n > 0 ? m->all.n : 1)); memcpy(r->labels, m->a_labels, (size_t)m->all.n);
+  r->x.n = m->all.n; r->x.dim = klo_coeff_dim(m->all.dim - 1); r->x.rowptr = rp; r->x.col = ci; r->x.val = cv;
+  r->n_total = m->n_total_all;
+  r->all = r->x; r->a_rowptr = rp; r->a_col = ci; r->a_val = cv; r->a_labels = r->labels; r->n_total_all = m->n_total_all;
+  if (m->mask) ob_set_active_rows(c, r, m->mask, m->n_total);
+  *out = r;
+  return 0;
+}
+
 static int ob_sweep_select(klr_ctx* c, const klr_mat* full, const klr_mat* red, const int64_t* red_cols, const double* theta_red,
                            int64_t c1, const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
                            const double* scale, const double* offset, uint8_t* b, double* lambda_out, int64_t* c_out,
@@ -165,6 +179,7 @@ void klo_backend_table(klr_backend* out) {
   out->cd_solve = ob_cd_solve;
   out->set_active_rows = ob_set_active_rows;
   out->log_pdf = ob_log_pdf;
+  out->expand_cooccurrence = ob_expand_cooccurrence;
 }
 
 void klo_backend_mat_destroy(klr_mat* m) { ob_mat_destroy(m); }

@@ -165,3 +165,78 @@ def test_crossvalidation_matches_explicit_subsets(tmp_path):
     lt, ls = np.ascontiguousarray(r["loss_train"][0]), np.ascontiguousarray(r["loss_test"][0])
     assert L.klr_save_crossvalidation_loss(fn2.encode(), lt.ctypes.data, ls.ctypes.data, k) == 0
     assert open(fn2).read().splitlines()[1] == "%15e\t%15e" % (lt[0], ls[0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# co-occurrence mode
+# ---------------------------------------------------------------------------------------------------
+def _co_data(golden_dir):
+    _, fg = O.read_scores_table(os.path.join(golden_dir, "scoresLr_test_co_fg.table"))
+    _, bg = O.read_scores_table(os.path.join(golden_dir, "scoresLr_test_co_bg.table"))
+    dense = np.concatenate([fg, bg], axis=0)
+    labels = np.array([1] * len(fg) + [0] * len(bg), dtype=np.uint8)
+    return O.Csr.from_dense(dense), labels, dense, len(fg)
+
+
+def test_scores2_cooccurrence_lambda_auto_1(golden_dir, tmp_path):
+    # TestScores2 (scoresLr_test.go:64-125): learn --lambda-auto=1 --co-occurrence on scoresLr_test_co_*.table
+    from kmerlr_amd import _driver as D
+    x, labels, dense, nfg = _co_data(golden_dir)
+    h = OD.matrix(x, labels)
+    est = OD.estimator(cooccurrence=1)
+    L = OD.lib()
+    exp_h, base_cols = D.cooccurrence_prepare(L, est.backend, est.cfg, h, x.dim)
+    assert list(base_cols) == list(range(x.dim))              # no pre-selection
+    cls = est.estimate(exp_h, [1])
+    c = cls[0]
+    nb = x.dim - 1
+    assert len(c["cols"]) == 2                                # len(classifier.Theta) == 2
+    pair = O.coeff_sub2ind(nb, int(c["cols"][1]) - 1)
+    assert pair == (1, 2)                                     # Index[f[0]] == 1, Index[f[1]] == 2
+    # The Theta goldens (-3.67e-06, 2.478e-04) are SAGA's barely-moved iterate from theta = 0 (the pair feature has
+    # values in the hundreds, SAGA's step is tiny and it stops early): solver trajectory, parity unpinned.  Solver
+    # independent and pinned here: at the REFERENCE's theta the loss (scoresLr_test.go:88) and all 16 predictions
+    # (:91-122) are reproduced to the last digit -- co-occurrence feature values, LogPdf and Loss arithmetic.
+    e = O.expand_cooccurrence(x)
+    red = O.select_columns(e, c["cols"])
+    th_ref = np.array([-3.6698336905701286e-06, 0.000247759511599005])
+    assert abs(O.loss(red, labels, th_ref, lam=0.0) - 0.6699931965725273) < 1e-15
+    w_fg = [-0.6662065007234194, -0.6477490377012717, -0.6539634473226117, -0.6063887787494636,
+            -0.5995933447812485, -0.4461679042826637, -0.6290620668667339, -0.6750691863398406]
+    w_bg = [-0.664436851779278, -0.6884446417698201, -0.648046764432194, -0.6861810564115558,
+            -0.679086111385735, -0.6738126996571452, -0.688649950605459, -0.5832453150753549]
+    pred = [O.class_log_pdf(red, i, th_ref, y=1) for i in range(x.n)]
+    np.testing.assert_allclose(pred[:nfg], w_fg, atol=2e-15)
+    np.testing.assert_allclose(pred[nfg:], w_bg, atol=2e-15)
+    # our solver goes on to the optimum of the same objective: lower penalised loss than at the reference's theta
+    lam = c["lam"]
+    assert O.loss(red, labels, c["theta"], lam=lam) < O.loss(red, labels, th_ref, lam=lam)
+    # model file with feature pairs
+    est.save_model_pairs(0, str(tmp_path / "co.json"), [pair])
+    m = json.load(open(tmp_path / "co.json"))
+    assert m["Parameters"]["Cooccurrence"] is True and m["Parameters"]["Index"] == [1, 2] and m["Parameters"]["Features"] == [[0, 1]]
+    OD.free_matrix(exp_h); OD.free_matrix(h)
+
+
+def test_scores3_copreselection_selectdata(golden_dir):
+    # TestScores3 (scoresLr_test.go:127-160): --lambda-auto=3 --co-occurrence --co-preselection=5: every selected
+    # column of the data the classifier is trained on equals the single feature or the product of its two features
+    from kmerlr_amd import _driver as D
+    x, labels, dense, nfg = _co_data(golden_dir)
+    h = OD.matrix(x, labels)
+    est = OD.estimator(cooccurrence=1, copreselection=5)
+    L = OD.lib()
+    exp_h, base_cols = D.cooccurrence_prepare(L, est.backend, est.cfg, h, x.dim)
+    assert len(base_cols) == 6 and base_cols[0] == 0          # bias + 5 pre-selected features
+    cls = est.estimate(exp_h, [3])
+    c = cls[0]
+    assert len(c["cols"]) == 4
+    xs = O.select_columns(x, base_cols)
+    e = O.expand_cooccurrence(xs)
+    sel = O.select_columns(e, c["cols"]).to_dense()
+    for j, col in enumerate(c["cols"][1:]):
+        k1, k2 = O.coeff_sub2ind(5, int(col) - 1)
+        f1, f2 = base_cols[k1 + 1] - 1, base_cols[k2 + 1] - 1
+        want = dense[:, f1] if f1 == f2 else dense[:, f1] * dense[:, f2]
+        np.testing.assert_allclose(sel[:, j + 1], want, atol=1e-10)
+    OD.free_matrix(exp_h); OD.free_matrix(h)

@@ -131,3 +131,64 @@ def test_predict_and_data_transform(tmp_path):
     np.testing.assert_allclose(scale[1:], 1.0 / sd[idx], rtol=1e-10)
     r_lin = theta[0] + (xf[:, idx] * scale[1:]) @ theta[1:]
     np.testing.assert_allclose([float(v) for v in out[1:]], -np.log1p(np.exp(-r_lin)), rtol=1e-6)
+
+
+def _co_tables():
+    fg, bg = os.path.join(GOLDEN, "scoresLr_test_co_fg.table"), os.path.join(GOLDEN, "scoresLr_test_co_bg.table")
+    _, xf = O.read_scores_table(fg); _, xb = O.read_scores_table(bg)
+    dense = np.concatenate([xf, xb])
+    labels = np.array([1] * len(xf) + [0] * len(xb), dtype=np.uint8)
+    return fg, bg, dense, labels
+
+
+def test_scores2_cooccurrence_cli(tmp_path):
+    # TestScores2 (scoresLr_test.go:64-125): learn --lambda-auto=1 --co-occurrence, then loss and predict with the model
+    fg, bg, dense, labels = _co_tables()
+    run(["--type=scoresLr", "learn", "--lambda-auto=1", "--co-occurrence", fg, bg, "co"], tmp_path)
+    m = json.load(open(tmp_path / "co.json"))
+    assert m["Parameters"]["Cooccurrence"] is True
+    assert m["Parameters"]["Index"] == [1, 2] and m["Parameters"]["Features"] == [[0, 1]]     # :83-85
+    theta = m["Distributions"][0]["Parameters"]
+    assert len(theta) == 2                                                                       # :73
+    # loss / predict commands evaluate the pair feature x1*x2 (SelectData + Loss / Predict): oracle on the same theta
+    x = O.Csr.from_dense(dense)
+    red = O.select_columns(O.expand_cooccurrence(x), [0, O.coeff_ind2sub(7, 1, 2)])
+    out = run(["--type=scoresLr", "loss", "co.json", fg, bg], tmp_path).stdout
+    ref = O.loss(red, labels, theta)
+    assert abs(float(out) - ref) < 1e-6 * ref
+    pred = run(["--type=scoresLr", "predict", "co.json", fg], tmp_path).stdout.split()[1:]
+    want = [O.class_log_pdf(red, i, theta, y=1) for i in range(8)]
+    np.testing.assert_allclose([float(v) for v in pred], want, rtol=1e-6)
+    # the reference's own numbers for this model (its theta, :76-81) through OUR loss / predict commands
+    m["Distributions"][0]["Parameters"] = [-3.6698336905701286e-06, 0.000247759511599005]
+    json.dump(m, open(tmp_path / "ref.json", "w"))
+    out = run(["--type=scoresLr", "loss", "ref.json", fg, bg], tmp_path).stdout
+    assert abs(float(out) - 0.6699931965725273) < 1e-6                                          # :88 (printed with %e)
+    pred = run(["--type=scoresLr", "predict", "ref.json", bg], tmp_path).stdout.split()[1:]
+    w_bg = [-0.664436851779278, -0.6884446417698201, -0.648046764432194, -0.6861810564115558,
+            -0.679086111385735, -0.6738126996571452, -0.688649950605459, -0.5832453150753549]   # :108-112
+    np.testing.assert_allclose([float(v) for v in pred], w_bg, atol=1e-6)
+
+
+def test_scores3_copreselection_cli(tmp_path):
+    # TestScores3 (scoresLr_test.go:127-160): --lambda-auto=3 --co-occurrence --co-preselection=5; same selection as the
+    # oracle-served driver, and the model's features are singles / pairs of the pre-selected features
+    from kmerlr_amd import _driver as D
+    fg, bg, dense, labels = _co_tables()
+    run(["--type=scoresLr", "learn", "--lambda-auto=3", "--co-occurrence", "--co-preselection=5", fg, bg, "co3"], tmp_path)
+    m = json.load(open(tmp_path / "co3.json"))
+    x = O.Csr.from_dense(dense)
+    h = OD.matrix(x, labels)
+    est = OD.estimator(cooccurrence=1, copreselection=5)
+    exp_h, base_cols = D.cooccurrence_prepare(OD.lib(), est.backend, est.cfg, h, x.dim)
+    c = est.estimate(exp_h, [3])[0]
+    pairs = []
+    for col in c["cols"][1:]:
+        k1, k2 = O.coeff_sub2ind(5, int(col) - 1)
+        pairs.append((int(base_cols[k1 + 1] - 1), int(base_cols[k2 + 1] - 1)))
+    idx = m["Parameters"]["Index"]
+    got = [(idx[a], idx[b]) for a, b in m["Parameters"]["Features"]]
+    assert got == pairs and len(got) == 3
+    assert set(idx) <= set(int(v) - 1 for v in base_cols[1:])
+    np.testing.assert_allclose(m["Distributions"][0]["Parameters"], c["theta"], rtol=1e-6, atol=1e-9)
+    OD.free_matrix(exp_h); OD.free_matrix(h)
