@@ -229,19 +229,42 @@ __device__ __forceinline__ double gram_at(const double* __restrict__ Gg, i64 idx
   return GLDS ? lds[idx] : Gg[idx];
 }
 
+// One coordinate step (coordinate.go:56-69) on slot S0 of q.  G / C / O / I are this step's operands (row j of the
+// Gram matrix, c_j, the old theta_j, 1/(norm_j + l2)), GN / CN / ON / IN receive those of step j+1, requested
+// first so that their LDS latency hides behind the chain.  The chain q_j -> t -> delta -> q is branch free (7
+// dependent f64 operations); a coordinate whose value does not move gives delta = 0 and q += 0 * row.
+#define CD_STEP(S0, J, L1, G, C, O, I, GN, CN, ON, IN)                                                        \
+  {                                                                                                            \
+    const int jn_ = (J) + 1 < d ? (J) + 1 : (J);                                                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < QPL; s_++) GN[s_] = gram_at<GLDS>(Gg, (i64)jn_ * d + off[s_]);      \
+    const double2 p01_ = *reinterpret_cast<const double2*>(pk + 4 * jn_);                                      \
+    CN = p01_.x; ON = p01_.y; IN = pk[4 * jn_ + 2];                                                            \
+    const double qj_ = bcast_lane(q[S0], (J) & 63);                                                            \
+    const double t0_ = C - qj_;                                   /* coordinate.go:56-59 */                    \
+    const double m_ = fmax(fabs(t0_) - (L1), 0.0);                /* :60-67 soft threshold */                  \
+    const double tn_ = copysign(m_, t0_) * I;                     /* :69 (reciprocal) */                       \
+    const double dl_ = tn_ - O;                                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < QPL; s_++) q[s_] = fma(dl_, G[s_], q[s_]);                          \
+    thl[(J)] = tn_;                                               /* every lane, same value, same address */   \
+  }
+
 template <int QPL, bool GLDS>
 __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
   // 256 threads stage the Gram matrix into LDS (one wave alone would spend ~1 us per dependent load);
-  // wavefront 0 then runs the sweeps.
-  // LDS: [G d*d (GLDS)] | c[d] | theta[d] | inv[d].  Only q_j travels through the dependency chain of a
-  // coordinate step: c_j = xy_j + norm_j theta_j is formed for all j at the start of a sweep (theta_j only
-  // changes at its own step), theta_j / c_j / 1/(norm_j + l2) / row j of G are fetched one step ahead.
+  // wavefront 0 then runs the sweeps.  A single wavefront cannot hide anything: every instruction of a step
+  // costs its issue slots (the first version spent ~75 instructions = ~360 cycles per coordinate, four times the
+  // length of the dependency chain), so the step is kept to the chain plus one prefetch:
+  //   * per-coordinate operands {c_j = xy_j + norm_j theta_j, old theta_j, 1/(norm_j + l2)} are packed in LDS at
+  //     the start of a sweep (theta_j only changes at its own step) and fetched one step ahead;
+  //   * row reads are unguarded (lanes past d read column d-1 again; their q slots are never used);
+  //   * two register sets alternate (no copies), the q slot is static (the j loop is split at multiples of 64);
+  //   * max|theta|, max|delta| and the NaN check of eval_stopping are lane-parallel work after the sweep.
+  // LDS: [G d*d (GLDS)] | pk[4d] | theta[d].  Same arithmetic and order as k_cd_sweeps.
   extern __shared__ double lds[];
   const int d = a.d, lane = threadIdx.x & 63;
   const double* __restrict__ Gg = a.G;
-  double* cl = lds + (GLDS ? (size_t)d * d : 0);
-  double* thl = cl + d;
-  double* invl = thl + d;
+  double* pk = lds + (GLDS ? (size_t)d * d : 0);
+  double* thl = pk + 4 * (size_t)d;
   if (GLDS) {
     const i64 dd = (i64)d * d;
 #pragma unroll 8
@@ -249,14 +272,17 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
-  double q[QPL], xy[QPL], dg[QPL];
+  double q[QPL], xy[QPL], dg[QPL], inv[QPL];
+  int off[QPL];
 #pragma unroll
   for (int s = 0; s < QPL; s++) {
     const int i = s * 64 + lane;
+    off[s] = i < d ? i : d - 1;
     xy[s] = i < d ? a.xy[i] : 0.0;
     dg[s] = i < d ? a.G[(i64)i * d + i] : 1.0;
+    inv[s] = 1.0 / (dg[s] + a.l2reg);                  // :69 as a reciprocal (<= 1 ulp)
     q[s] = 0.0;
-    if (i < d) { thl[i] = a.theta[i]; invl[i] = 1.0 / (dg[s] + a.l2reg); }      // :69 as a reciprocal (<= 1 ulp)
+    if (i < d) thl[i] = a.theta[i];
   }
   __builtin_amdgcn_wave_barrier();                     // single wave from here on: LDS ops are in order
   // q = G theta (skipping zero coefficients)
@@ -264,53 +290,75 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
     const double t = thl[k];
     if (t != 0.0) {
 #pragma unroll
-      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) q[s] += gram_at<GLDS>(Gg, (i64)k * d + i) * t; }
+      for (int s = 0; s < QPL; s++) q[s] += gram_at<GLDS>(Gg, (i64)k * d + off[s]) * t;
     }
   }
   int done = 0;
   for (int k = 0; k < a.K; k++) {
+    double told[QPL];
 #pragma unroll
-    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) cl[i] = xy[s] + dg[s] * thl[i]; }   // :56
-    __builtin_amdgcn_wave_barrier();
-    double max_x = 0.0, max_delta = 0.0;
-    int isnan_ = 0;
-    // step 0 operands
-    double grow[QPL];
-#pragma unroll
-    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; grow[s] = i < d ? gram_at<GLDS>(Gg, i) : 0.0; }
-    double cj = cl[0], old = thl[0], inv = invl[0];
-    for (int j = 0; j < d; j++) {
-      // operands of step j+1 (independent of this step's result, except theta which only step j+1 writes)
-      const int jn = j + 1 < d ? j + 1 : j;
-      double gnext[QPL];
-#pragma unroll
-      for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; gnext[s] = i < d ? gram_at<GLDS>(Gg, (i64)jn * d + i) : 0.0; }
-      const double cn = cl[jn], oldn = thl[jn], invn = invl[jn];
-      // ---- the chain: q_j -> t -> delta -> q, branch free (7 dependent f64 operations).  A coordinate whose
-      // value does not move gives delta = 0 and q += 0 * row: exactly the skipped update.
-      double qs = q[0];
-#pragma unroll
-      for (int s = 1; s < QPL; s++) if ((j >> 6) == s) qs = q[s];
-      const double qj = bcast_lane(qs, j & 63);
-      const double l1j = j > 0 ? a.l1reg : 0.0;                    // the bias is not penalised (:60)
-      const double t0 = cj - qj;                                   // coordinate.go:56-59
-      const double m = fmax(fabs(t0) - l1j, 0.0);                  // :60-67 soft threshold
-      const double tn = copysign(m, t0) * inv;                     // :69 (reciprocal)
-      const double dl = tn - old;
-#pragma unroll
-      for (int s = 0; s < QPL; s++) q[s] = fma(dl, grow[s], q[s]);
-      // off the chain: bookkeeping
-      if (lane == 0) thl[j] = tn;
-      isnan_ |= (tn != tn) ? 1 : 0;
-      max_x = fmax(max_x, fabs(tn));
-      max_delta = fmax(max_delta, fabs(dl));
-      cj = cn; old = oldn; inv = invn;
-#pragma unroll
-      for (int s = 0; s < QPL; s++) grow[s] = gnext[s];
+    for (int s = 0; s < QPL; s++) {
+      const int i = s * 64 + lane;
+      told[s] = 0.0;
+      if (i < d) {
+        const double t = thl[i];
+        told[s] = t;
+        pk[4 * i] = xy[s] + dg[s] * t;                 // :56
+        pk[4 * i + 1] = t;
+        pk[4 * i + 2] = inv[s];
+      }
     }
     __builtin_amdgcn_wave_barrier();
+    double gA[QPL], gB[QPL], cA, oA, iA, cB, oB, iB;
 #pragma unroll
-    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.hist[(i64)k * d + i] = thl[i]; }
+    for (int s = 0; s < QPL; s++) gA[s] = gram_at<GLDS>(Gg, off[s]);
+    cA = pk[0]; oA = pk[1]; iA = pk[2];
+    const double l1 = a.l1reg;
+#pragma unroll
+    for (int s0 = 0; s0 < QPL; s0++) {
+      const int j0 = s0 * 64, j1 = d < j0 + 64 ? d : j0 + 64;     // an even number of steps unless it is the last slot
+      int j = j0;
+      if (s0 == 0 && j < j1) {                                      // the bias is not penalised (:60)
+        CD_STEP(s0, j, 0.0, gA, cA, oA, iA, gB, cB, oB, iB);
+        j++;
+        if (j < j1) { CD_STEP(s0, j, l1, gB, cB, oB, iB, gA, cA, oA, iA); j++; }
+        else {                                                      // d == 1: keep the sets aligned
+#pragma unroll
+          for (int s = 0; s < QPL; s++) gA[s] = gB[s];
+          cA = cB; oA = oB; iA = iB;
+        }
+      }
+      for (; j + 1 < j1; j += 2) {
+        CD_STEP(s0, j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
+        CD_STEP(s0, j + 1, l1, gB, cB, oB, iB, gA, cA, oA, iA);
+      }
+      if (j < j1) {                                                 // odd tail (last slot only): one step, sets swapped back
+        CD_STEP(s0, j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
+#pragma unroll
+        for (int s = 0; s < QPL; s++) gA[s] = gB[s];
+        cA = cB; oA = oB; iA = iB;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // eval_stopping (proximal.go:30-52) from the old and the new iterate, lane parallel
+    double max_x = 0.0, max_delta = 0.0;
+    int isnan_ = 0;
+#pragma unroll
+    for (int s = 0; s < QPL; s++) {
+      const int i = s * 64 + lane;
+      if (i < d) {
+        const double tn = thl[i];
+        a.hist[(i64)k * d + i] = tn;
+        isnan_ |= (tn != tn) ? 1 : 0;
+        max_x = fmax(max_x, fabs(tn));
+        max_delta = fmax(max_delta, fabs(tn - told[s]));
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      max_x = fmax(max_x, __shfl_xor(max_x, o, 64));
+      max_delta = fmax(max_delta, __shfl_xor(max_delta, o, 64));
+      isnan_ |= __shfl_xor(isnan_, o, 64);
+    }
     double delta; int stop;
     if (isnan_) { delta = nan(""); stop = 1; }
     else {
@@ -325,6 +373,7 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
   for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.theta[i] = thl[i]; }
   if (lane == 0) *a.ndone = done;
 }
+#undef CD_STEP
 
 // log-loss of up to KSPEC iterates in one pass over the reduced rows (thread per row); the iterates
 // are staged in LDS, each stored entry is read once and applied to all of them
@@ -431,8 +480,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     return klr_fail(ctx, KLR_EINVAL, "%d selected features exceed the device solver's limit (%zu)", d - 1, LDS_MAX / 32 - 1);
   const int g_in_lds = lds_big <= LDS_MAX;
   const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
-  // wave variant: theta, diag, xy (+ G) in LDS
-  const size_t lds_wave = (size_t)3 * d * sizeof(double) + (g_in_lds ? (size_t)d * d * sizeof(double) : 0);
+  // wave variant: packed per-coordinate operands (4 per coordinate), theta (+ G) in LDS
+  const size_t lds_wave = (size_t)5 * d * sizeof(double) + (g_in_lds ? (size_t)d * d * sizeof(double) : 0);
   static bool attr_set = false;
   if (!attr_set) {
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
