@@ -501,15 +501,18 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
   KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)(2 + gram_blocks) * d * d * 8, (void**)&G));
   Gi = (i64*)(G + (size_t)d * d);
-  // vec: a0[d] nm[d] xy[d] theta[d] hist[K*d] delta[K] gsc[2] | ints: stopf[K] ndone
-  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int);
+  // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
+  // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
+  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int);
   KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
   double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d; double* hist = thd + d;
-  double* delta = hist + (size_t)KSPEC * d; double* gsc = delta + KSPEC;
+  double* delta = hist + (size_t)KSPEC * d; double* losses = delta + KSPEC; double* gsc = losses + KSPEC;
   int* stopf = (int*)(gsc + 2); int* ndone = stopf + KSPEC;
+  const size_t report_bytes = ((size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 1) * sizeof(int);
+  char* pin_report;
+  KLR_TRY(pin_get(ctx, report_bytes, (void**)&pin_report));
   const i64 nb = std::max<i64>(1, ceil_div(n, 256));
   KLR_TRY(ws_get(ctx, WS_CD_LOSS, ((size_t)nb * KSPEC + KSPEC) * 8, (void**)&lossb));
-  double* losses = lossb + (size_t)nb * KSPEC;
 
   std::vector<double> th(theta, theta + d), tp(d), hhist((size_t)KSPEC * d), hdelta(KSPEC), hloss(KSPEC);
   std::vector<int> hstop(KSPEC + 1);
@@ -574,12 +577,17 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
         hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
         KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
-        KLR_HIP(ctx, hipMemcpyAsync(hloss.data(), losses, KSPEC * 8, hipMemcpyDeviceToHost, st));
       }
       KLR_HIP(ctx, hipGetLastError());
-      KLR_HIP(ctx, hipMemcpyAsync(hhist.data(), hist, (size_t)Kb * d * 8, hipMemcpyDeviceToHost, st));
-      KLR_HIP(ctx, hipMemcpyAsync(hdelta.data(), delta, KSPEC * 8, hipMemcpyDeviceToHost, st));
-      KLR_TRY(d2h_sync(ctx, hstop.data(), stopf, (KSPEC + 1) * sizeof(int)));
+      KLR_HIP(ctx, hipMemcpyAsync(pin_report, hist, report_bytes, hipMemcpyDeviceToHost, st));
+      KLR_HIP(ctx, hipStreamSynchronize(st));
+      {
+        const double* pr = (const double*)pin_report;
+        memcpy(hhist.data(), pr, (size_t)KSPEC * d * 8);
+        memcpy(hdelta.data(), pr + (size_t)KSPEC * d, KSPEC * 8);
+        memcpy(hloss.data(), pr + (size_t)KSPEC * d + KSPEC, KSPEC * 8);
+        memcpy(hstop.data(), pr + (size_t)KSPEC * d + 2 * KSPEC + 2, (KSPEC + 1) * sizeof(int));
+      }
       const int nd = hstop[KSPEC];
       bool cut = false;     // stopped before the end of the batch -> device theta must be rewound
       for (int k = 0; k < nd; k++) {
