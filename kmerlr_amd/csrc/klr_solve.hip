@@ -55,6 +55,24 @@ __global__ __launch_bounds__(256) void k_gram_scale(const double* __restrict__ n
 // of q entries costs ~q steps instead of q^2/2 dependent load round trips (rows longer than 16 are chunked).
 // LDSACC: the d x d integer Gram is privatised in LDS (d*d*8 <= 128 KiB) and written out as one partial per
 // workgroup (summed by k_gram_reduce); otherwise global integer atomics.
+template <int O>
+__device__ __forceinline__ void dpp_pairs(bool ha, int ja, double wa, int jc_own, double vc_own, int d, unsigned long long* acc) {
+  if constexpr (O < 16) {
+    int jc; double vc;
+    if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
+    else {
+      constexpr int ctrl = 0x120 + O;                 // row_ror:O -> lane l receives lane (l + O) & 15 of its row
+      jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
+      vc = __hiloint2double(hi, lo);
+    }
+    // columns ascend inside a row: the pair is taken once, with ja < jc
+    if (ha && jc > ja) atomicAdd(&acc[ja * d + jc], (unsigned long long)__double2ll_rn(wa * vc));
+    dpp_pairs<O + 1>(ha, ja, wa, jc_own, vc_own, d, acc);
+  }
+}
+
 template <bool LDSACC>
 __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                        const double* __restrict__ val, const double* __restrict__ w,
@@ -81,14 +99,8 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
         const bool hc = c0 + lane < e;
         const int jc_own = hc ? (int)col[c0 + lane] : -1;
         const double vc_own = hc ? val[c0 + lane] : 0.0;
-#pragma unroll 4
-        for (int o = 0; o < 16; o++) {
-          const int src = (lane + o) & 15;
-          const int jc = __shfl(jc_own, src, 16);
-          const double vc = __shfl(vc_own, src, 16);
-          // columns ascend inside a row: the pair is taken once, with ja < jc
-          if (ha && jc > ja) atomicAdd(&acc[ja * d + jc], (unsigned long long)__double2ll_rn(wa * vc));
-        }
+        // the 16 lanes of a row are one DPP row: partner o arrives by a row rotation (VALU, no LDS round trip)
+        dpp_pairs<0>(ha, ja, wa, jc_own, vc_own, d, acc);
       }
     }
   }
@@ -99,12 +111,24 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
   }
 }
 
+// 64 cells x 4 partial lanes per block, 8 loads in flight per lane (one lane walking all 256 partials of a cell
+// took 66 us for 21 MB)
 __global__ __launch_bounds__(256) void k_gram_reduce(unsigned long long* __restrict__ Gi, int dd, int nblk) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= dd) return;
+  __shared__ unsigned long long sh[4][64];
+  const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + cx;
   unsigned long long v = 0ull;
-  for (int b = 1; b <= nblk; b++) v += Gi[(size_t)b * dd + t];
-  Gi[t] = v;
+  if (t < dd) {
+    for (int b = 1 + ly; b <= nblk; b += 32) {
+      unsigned long long x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = (b + 4 * u <= nblk) ? Gi[(size_t)(b + 4 * u) * dd + t] : 0ull;
+      v += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    }
+  }
+  sh[ly][cx] = v;
+  __syncthreads();
+  if (ly == 0 && t < dd) Gi[t] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
 }
 
 // G from its parts: row/column 0 and the diagonal from the column sweeps, the rest from the integers
@@ -497,7 +521,11 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&z));
   KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * 8, (void**)&wz));
   // LDS-privatised Gram build: one partial per workgroup after the result slot
-  const bool gram_lds = (size_t)d * d * 8 <= 128 * 1024;
+  // ... unless the rows are so short that there are few pairs in all (k-mer data: 2-3 stored entries per reduced
+  // row): then zeroing, writing and re-reading one 80 KiB partial per workgroup is the whole cost (150 us per
+  // re-weighting at configs[2]) and plain global integer atomics are the cheaper build
+  const double est_pairs = (double)n * std::max(0.0, red->avg_row - 1.0) * std::max(0.0, red->avg_row - 2.0) * 0.5 + (double)n;
+  const bool gram_lds = (size_t)d * d * 8 <= 128 * 1024 && est_pairs > 4e6;
   const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
   KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)(2 + gram_blocks) * d * d * 8, (void**)&G));
   Gi = (i64*)(G + (size_t)d * d);
@@ -542,7 +570,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (gram_lds) {
         hipLaunchKernelGGL(k_gram_offdiag<true>, dim3(gram_blocks), dim3(1024), (size_t)d * d * 8, st, red->rowptr, red->col,
                            (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
-        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, (unsigned long long*)Gi,
+        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
                            d * d, (int)gram_blocks);
       } else {
         const unsigned gb = (unsigned)std::max<i64>(1, std::min<i64>(4 * ctx->n_cu, ceil_div(n * 16, 1024)));
