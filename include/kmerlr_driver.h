@@ -120,6 +120,19 @@ int  klr_save_crossvalidation(const char* filename, const double* predictions, c
                               const int32_t* groups, int64_t n, int k_fold);
 int  klr_save_crossvalidation_loss(const char* filename, const double* loss_train, const double* loss_test, int k_fold);
 
+/* Ensembles (estimate_ensemble, kmerLr_estimator_ensemble.go:74-96 / scoresLr_estimator_ensemble.go:74-96): member k
+ * of `ensemble_size` >= 2 is trained by a fresh estimator on the rows whose group (klr_cv_groups with
+ * k_fold = ensemble_size) is NOT k -- a row mask on the resident matrix -- for every lambda_auto, all members with
+ * the same transform.  Classifiers are kept member-major (member k, lambda_auto j at k*n_lambda_auto + j). */
+int  klr_estimator_estimate_ensemble(klr_estimator* est, klr_mat* data, int64_t row0, int64_t n_all, int ensemble_size,
+                                     int64_t seed, const int64_t* lambda_auto, int64_t n_lambda_auto, const double* scale,
+                                     const double* offset);
+/* One model file for lambda_auto j of such an ensemble ({Kmer,Scores}LrEnsemble.AddKmerLr + ExportConfig,
+ * kmerLr_classifier_ensemble.go:253-353,416-433): the union of the members' features (zero coefficients dropped),
+ * one coefficient vector per member over that union, the shared transform; Name = "<type> [<summary>]". */
+int  klr_estimator_save_ensemble(const klr_estimator* est, int64_t j, int ensemble_size, int64_t n_lambda_auto,
+                                 const char* filename, const char* type_name, const char* const* names, const char* summary);
+
 /* Co-occurrence set-up ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:98-117,
  * scoresLr_estimator_ensemble.go:98-117).  With cfg.copreselection = q > 0 a first estimate_loop with lambda_auto = q
  * and WITHOUT co-occurrence runs on `data` (transform pre_scale / pre_offset, nullable), the data are restricted to

@@ -60,6 +60,10 @@ def bind_driver(L):
     L.klr_estimator_save_model.argtypes = [vp, i64, C.c_char_p, C.c_char_p, vp]
     L.klr_estimator_save_model_pairs.restype = C.c_int
     L.klr_estimator_save_model_pairs.argtypes = [vp, i64, C.c_char_p, C.c_char_p, vp, vp]
+    L.klr_estimator_estimate_ensemble.restype = C.c_int
+    L.klr_estimator_estimate_ensemble.argtypes = [vp, vp, i64, i64, C.c_int, i64, vp, i64, vp, vp]
+    L.klr_estimator_save_ensemble.restype = C.c_int
+    L.klr_estimator_save_ensemble.argtypes = [vp, i64, C.c_int, i64, C.c_char_p, C.c_char_p, vp, C.c_char_p]
     L.klr_cooccurrence_prepare.restype = C.c_int
     L.klr_cooccurrence_prepare.argtypes = [C.POINTER(Backend), C.POINTER(Config), vp, vp, vp, C.POINTER(vp), vp, C.POINTER(i64),
                                            C.c_char_p, i64]
@@ -148,6 +152,23 @@ class Estimator:
             None if scale is None else scale.ctypes.data, None if offset is None else offset.ctypes.data,
             pred.ctypes.data, groups.ctypes.data, lt.ctypes.data, ls.ctypes.data))
         return dict(predictions=pred, groups=groups, loss_train=lt, loss_test=ls, classifiers=self.classifiers())
+
+    def estimate_ensemble(self, mat_handle, n_local, ensemble_size, lambda_auto, seed=1, row0=0, n_all=0, scale=None, offset=None):
+        """Member-major list of classifiers (member k, lambda_auto j at k*len(lambda_auto) + j)."""
+        la = np.ascontiguousarray(list(lambda_auto), dtype=np.int64)
+        scale = None if scale is None else np.ascontiguousarray(scale, dtype=np.float64)
+        offset = None if offset is None else np.ascontiguousarray(offset, dtype=np.float64)
+        self._check(self.L.klr_estimator_estimate_ensemble(
+            self._h, mat_handle, row0, n_all or n_local, ensemble_size, seed, la.ctypes.data, len(la),
+            None if scale is None else scale.ctypes.data, None if offset is None else offset.ctypes.data))
+        return self.classifiers()
+
+    def save_ensemble(self, j, ensemble_size, n_lambda_auto, filename, type_name="scoresLr", names=None, summary="mean"):
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+        self._check(self.L.klr_estimator_save_ensemble(self._h, j, ensemble_size, n_lambda_auto, filename.encode(), type_name.encode(),
+                                                       None if arr is None else C.cast(arr, C.c_void_p), summary.encode()))
 
     def classifiers(self):
         out = []

@@ -190,13 +190,43 @@ static std::vector<double> json_numbers_after(const std::string& s, const std::s
 // The data restricted to a model's features, transform applied (SelectData, kmerLr_classifier.go:125-147): plain
 // models select the Index columns; co-occurrence models (Cooccurrence = true) select them, write out the pair matrix
 // of that restriction and pick the columns of the Features pairs.  theta is permuted along if the columns need sorting.
-static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& js, std::vector<double>& theta) {
+// Summarize ({Kmer,Scores}LrEnsemble.Summarize, kmerLr_classifier_ensemble.go:64-104)
+static double summarize(const std::string& summary, const std::vector<double>& x) {
+  if (x.empty()) return NAN;
+  if (x.size() == 1 && summary.empty()) return x[0];
+  double r;
+  if (summary == "product") { r = 1.0; for (double v : x) r *= v; }
+  else if (summary == "min") { r = x[0]; for (double v : x) if (r > v) r = v; }
+  else if (summary == "max") { r = x[0]; for (double v : x) if (r < v) r = v; }
+  else if (summary == "mean") { r = 0.0; for (double v : x) r += v; r /= (double)x.size(); }
+  else die("no summary given for ensemble classifier");
+  return r;
+}
+
+// members: one coefficient vector per ensemble member (a single one for plain models); summary from "Name [summary]"
+static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& js, std::vector<std::vector<double>>& members,
+                           std::string& summary) {
   size_t pos = 0;
   std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
   const size_t dpos = js.find("\"Distributions\"");
-  theta = json_numbers_after(js, "Parameters", dpos, &pos);
-  std::vector<double> offset = json_numbers_after(js, "Offset", pos, nullptr);
-  std::vector<double> scale = json_numbers_after(js, "Scale", pos, nullptr);
+  members.clear();
+  summary.clear();
+  {
+    // top-level Name: "kmerLr" or "kmerLr [summary]" (kmerLr_classifier_ensemble.go:380,426-430)
+    const size_t np = js.find("\"Name\"");
+    const size_t q0 = js.find('"', js.find(':', np)), q1 = js.find('"', q0 + 1);
+    const std::string name = js.substr(q0 + 1, q1 - q0 - 1);
+    const size_t lb = name.find('['), rb = name.find(']');
+    if (lb != std::string::npos && rb != std::string::npos && rb > lb) summary = name.substr(lb + 1, rb - lb - 1);
+  }
+  const size_t tpos = js.find("\"transform\"", dpos);
+  for (size_t p = js.find("vector:logistic regression", dpos); p != std::string::npos && p < tpos; p = js.find("vector:logistic regression", pos)) {
+    members.push_back(json_numbers_after(js, "Parameters", p, &pos));
+  }
+  if (members.empty()) die("invalid config file");
+  std::vector<double>& theta = members[0];
+  std::vector<double> offset = json_numbers_after(js, "Offset", tpos, nullptr);
+  std::vector<double> scale = json_numbers_after(js, "Scale", tpos, nullptr);
   const size_t cp = js.find("\"Cooccurrence\"");
   const bool co = cp != std::string::npos && js.compare(js.find(':', cp) + 1, 5, " true") == 0;
   std::vector<int64_t> cols{0};
@@ -235,6 +265,7 @@ static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& 
   if (klr_mat_select_columns(ctx, ex, ecols.data(), (int64_t)ecols.size(), sc.empty() ? nullptr : sc.data(), of.empty() ? nullptr : of.data(), &red) != KLR_OK)
     die("%s", klr_last_error(ctx));
   klr_mat_destroy(ex); klr_mat_destroy(base);
+  if (members.size() != 1) die("co-occurrence ensembles are not part of this build");
   theta = th;
   return red;
 }
@@ -307,8 +338,12 @@ int main(int argc, char** argv) {
     const int kfold = atoi(opt(o, "k-fold-cv", "1").c_str());
     const long long seed = atoll(opt(o, "seed", g_seed.c_str()).c_str());
     if (kfold < 1) die("invalid --k-fold-cv");
-    if (atoi(opt(o, "ensemble-size", "1").c_str()) != 1)
-      die("--ensemble-size is not part of this build (DESIGN.md, out of scope)");
+    const int ensemble = atoi(opt(o, "ensemble-size", "1").c_str());
+    const std::string summary = opt(o, "ensemble-summary", "mean");
+    if (ensemble < 1) die("invalid --ensemble-size");
+    if (summary != "mean" && summary != "product" && summary != "min" && summary != "max") die("invalid --ensemble-summary");
+    if (ensemble > 1 && kfold > 1) die("--ensemble-size together with --k-fold-cv is not part of this build");
+    if (ensemble > 1 && !std::isnan(cfg.lambda)) die("--ensemble-size needs --lambda-auto in this build");
     cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;
     cfg.copreselection = atoll(opt(o, "co-preselection", "0").c_str());
     if (cfg.copreselection != 0 && !cfg.cooccurrence) die("--co-preselection needs --co-occurrence");
@@ -419,8 +454,13 @@ int main(int argc, char** argv) {
       klr_ctx_destroy(ctx);
       return 0;
     }
-    if (klr_estimator_estimate(est, mat, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
-                               offset.empty() ? nullptr : offset.data()) != KLR_OK)
+    if (ensemble > 1) {
+      if (cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
+      if (klr_estimator_estimate_ensemble(est, mat, 0, n, ensemble, seed, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
+                                          offset.empty() ? nullptr : offset.data()) != KLR_OK)
+        die("%s", klr_estimator_error(est));
+    } else if (klr_estimator_estimate(est, mat, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
+                                      offset.empty() ? nullptr : offset.data()) != KLR_OK)
       die("%s", klr_estimator_error(est));
     if (cfg.save_trace) {
       const std::string fn = base + ".trace";
@@ -434,13 +474,16 @@ int main(int argc, char** argv) {
       if (klr_estimator_save_path(est, fn.c_str()) != KLR_OK) die("failed");
       say(1, "done\n");
     }
-    const int64_t nc = klr_estimator_n_classifiers(est);
+    const int64_t nc = ensemble > 1 ? (int64_t)la.size() : klr_estimator_n_classifiers(est);
     for (int64_t i = 0; i < nc; i++) {                                    // kmerLr_learn.go:60-66
       char fn[4096];
       if (nc == 1) snprintf(fn, sizeof(fn), "%s.json", base.c_str());
       else snprintf(fn, sizeof(fn), "%s_%lld.json", base.c_str(), (long long)la[(size_t)i]);
       say(1, "Exporting model to `%s'... ", fn);
-      if (save_model(est, i, fn, names) != KLR_OK) die("failed");
+      if (ensemble > 1) {
+        if (klr_estimator_save_ensemble(est, i, ensemble, nc, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
+                                        summary.c_str()) != KLR_OK) die("failed");
+      } else if (save_model(est, i, fn, names) != KLR_OK) die("failed");
       say(1, "done\n");
     }
     klr_estimator_destroy(est);
@@ -452,7 +495,6 @@ int main(int argc, char** argv) {
     if (!jf) die("cannot open `%s'", o.pos[0].c_str());
     std::stringstream buf; buf << jf.rdbuf();
     const std::string js = buf.str();
-    std::vector<double> theta;
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
     if (scores) {
@@ -467,11 +509,16 @@ int main(int argc, char** argv) {
       read_fasta(o.pos[1], 1, sq); read_fasta(o.pos[2], 0, sq);
       mat = count_kmers(ctx, sq, ks);
     }
-    red = model_data(ctx, mat, js, theta);
+    std::vector<std::vector<double>> members; std::string summary;
+    red = model_data(ctx, mat, js, members, summary);
     const double cw[2] = {1.0, 1.0};
-    double out = 0.0;
-    if (klr_loss(ctx, red, theta.data(), cw, strtod(opt(o, "lambda", "NaN").c_str(), nullptr), &out) != KLR_OK) die("%s", klr_last_error(ctx));
-    printf("%15e\n", out);                                              // saveLoss, kmerLr_loss.go:48
+    std::vector<double> lv;                                             // {Kmer,Scores}LrEnsemble.Loss: summary of the members' losses
+    for (auto& th : members) {
+      double out = 0.0;
+      if (klr_loss(ctx, red, th.data(), cw, strtod(opt(o, "lambda", "NaN").c_str(), nullptr), &out) != KLR_OK) die("%s", klr_last_error(ctx));
+      lv.push_back(out);
+    }
+    printf("%15e\n", summarize(summary, lv));                            // saveLoss, kmerLr_loss.go:48
     klr_mat_destroy(red); klr_mat_destroy(mat);
   } else if (cmd == "predict") {
     // predict_ / predict_scores_ (kmerLr_predict.go:125-139, scoresLr_predict.go:28-37): log sigma(x . theta) per row
@@ -480,7 +527,6 @@ int main(int argc, char** argv) {
     if (!jf) die("cannot open `%s'", o.pos[0].c_str());
     std::stringstream buf; buf << jf.rdbuf();
     const std::string js = buf.str();
-    std::vector<double> theta;
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
     int64_t n = 0;
@@ -498,9 +544,17 @@ int main(int argc, char** argv) {
       n = (int64_t)sq.labels.size();
       mat = count_kmers(ctx, sq, ks);
     }
-    red = model_data(ctx, mat, js, theta);
+    std::vector<std::vector<double>> members; std::string summary;
+    red = model_data(ctx, mat, js, members, summary);
     std::vector<double> out((size_t)std::max<int64_t>(n, 1));
-    if (klr_log_pdf(ctx, red, theta.data(), out.data()) != KLR_OK) die("%s", klr_last_error(ctx));
+    {
+      // {Kmer,Scores}LrEnsemble.Predict (kmerLr_classifier_ensemble.go:124-137): summary of the members' LogPdf per row
+      std::vector<std::vector<double>> lp(members.size(), std::vector<double>((size_t)std::max<int64_t>(n, 1)));
+      for (size_t k = 0; k < members.size(); k++)
+        if (klr_log_pdf(ctx, red, members[k].data(), lp[k].data()) != KLR_OK) die("%s", klr_last_error(ctx));
+      std::vector<double> t(members.size());
+      for (int64_t i = 0; i < n; i++) { for (size_t k = 0; k < members.size(); k++) t[k] = lp[k][(size_t)i]; out[(size_t)i] = summarize(summary, t); }
+    }
     FILE* f = o.pos.size() == 3 ? fopen(o.pos[2].c_str(), "w") : stdout;
     if (!f) die("cannot write `%s'", o.pos[2].c_str());
     fprintf(f, "%15s\n", "prediction");                                  // savePredictions, kmerLr_predict.go:81-84

@@ -577,3 +577,92 @@ extern "C" int klr_estimator_save_model_pairs(const klr_estimator* e, int64_t i,
   fclose(f);
   return KLR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// ensembles
+// ---------------------------------------------------------------------------------------------------
+extern "C" int klr_estimator_estimate_ensemble(klr_estimator* e, klr_mat* data, int64_t row0, int64_t n_all, int ensemble_size,
+                                               int64_t seed, const int64_t* lambda_auto, int64_t nla, const double* scale,
+                                               const double* offset) {
+  if (!e) return KLR_EINVAL;
+  if (!data || ensemble_size < 2 || !lambda_auto || nla < 1) return fail(e, KLR_EINVAL, "estimate_ensemble: invalid argument");
+  if (!e->be.set_active_rows) return fail(e, KLR_EINVAL, "backend lacks set_active_rows");
+  int64_t n = 0, dim = 0;
+  if (e->be.mat_shape(data, &n, &dim, nullptr, nullptr) != KLR_OK) return fail(e, KLR_EINVAL, "bad data matrix");
+  if (n_all < ensemble_size) return fail(e, KLR_EINVAL, "not enough training samples (%lld) for an ensemble of %d", (long long)n_all, ensemble_size);
+  std::vector<int32_t> all((size_t)n_all);
+  klr_cv_groups(n_all, ensemble_size, seed, 0, n_all, all.data());                // getCvGroups(len, EnsembleSize, ..., Seed) :75
+  std::vector<int64_t> size((size_t)ensemble_size, 0);
+  for (int32_t g : all) size[(size_t)g]++;
+  const int32_t* grp = all.data() + row0;
+  std::vector<uint8_t> mask((size_t)std::max<int64_t>(n, 1));
+  std::vector<Classifier> all_cls;
+  int rc = KLR_OK;
+  e->out.clear();
+  for (int k = 0; k < ensemble_size && rc == KLR_OK; k++) {
+    for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] != k;                 // filterCvGroup(data_train, groups, nil, k) :84
+    if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_all - size[(size_t)k]) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+    klr_estimator* me = nullptr;
+    if (klr_estimator_create(&e->be, &e->cfg, &me) != KLR_OK) { rc = fail(e, KLR_EINVAL, "cannot create member estimator"); break; }
+    rc = klr_estimator_estimate(me, data, lambda_auto, nla, scale, offset);
+    if (rc != KLR_OK) { e->err = me->err; klr_estimator_destroy(me); break; }
+    for (auto& r : me->trace) e->trace.push_back(r);                               // GetTrace :56-62
+    for (int64_t j = 0; j < nla; j++) all_cls.push_back(me->out[(size_t)j]);
+    klr_estimator_destroy(me);
+  }
+  e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
+  if (rc == KLR_OK) e->out.swap(all_cls);
+  return rc;
+}
+
+extern "C" int klr_estimator_save_ensemble(const klr_estimator* e, int64_t j, int ensemble_size, int64_t nla, const char* filename,
+                                           const char* type_name, const char* const* names, const char* summary) {
+  if (!e || !filename || ensemble_size < 1 || nla < 1 || j < 0 || j >= nla || (int64_t)e->out.size() < (int64_t)ensemble_size * nla)
+    return KLR_EINVAL;
+  // union of the members' features with a non-zero coefficient (AddKmerLr :277-286), ascending
+  std::vector<int64_t> uni;
+  for (int k = 0; k < ensemble_size; k++) {
+    const Classifier& c = e->out[(size_t)(k * nla + j)];
+    for (size_t p = 1; p < c.cols.size(); p++) if (c.theta[p] != 0.0) uni.push_back(c.cols[p]);
+  }
+  std::sort(uni.begin(), uni.end());
+  uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+  const size_t nf = uni.size();
+  std::vector<double> scale(nf + 1, 1.0), offset(nf + 1, 0.0);
+  bool has_scale = false, has_offset = false;
+  FILE* f = fopen(filename, "w");
+  if (!f) return KLR_EINVAL;
+  std::string name = type_name ? type_name : "scoresLr";
+  if (summary && *summary) name += std::string(" [") + summary + "]";
+  fprintf(f, "{\n  \"Name\": ");
+  json_str(f, name.c_str());
+  fprintf(f, ",\n  \"Parameters\": {\n    \"Cooccurrence\": false,\n    \"Features\": [");
+  for (size_t k = 0; k < nf; k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", k, k);
+  fprintf(f, "],\n    \"Index\": [");
+  for (size_t k = 0; k < nf; k++) fprintf(f, "%s%lld", k ? "," : "", (long long)(uni[k] - 1));
+  fprintf(f, "],\n    \"Names\": [");
+  if (names) for (size_t k = 0; k < nf; k++) { if (k) fputc(',', f); json_str(f, names[uni[k] - 1]); }
+  fprintf(f, "]\n  },\n  \"Distributions\": [\n");
+  for (int k = 0; k < ensemble_size; k++) {
+    const Classifier& c = e->out[(size_t)(k * nla + j)];
+    std::vector<double> th(nf + 1, 0.0);
+    th[0] = c.theta[0];
+    for (size_t p = 1; p < c.cols.size(); p++) {
+      if (c.theta[p] == 0.0) continue;
+      const size_t u = (size_t)(std::lower_bound(uni.begin(), uni.end(), c.cols[p]) - uni.begin());
+      th[u + 1] = c.theta[p];
+      if (!c.scale.empty()) { scale[u + 1] = c.scale[p]; has_scale = true; }
+      if (!c.offset.empty()) { offset[u + 1] = c.offset[p]; has_offset = true; }
+    }
+    fprintf(f, "    {\"Name\": \"vector:logistic regression\", \"Parameters\": [");
+    for (size_t q = 0; q < th.size(); q++) fprintf(f, "%s%.17g", q ? "," : "", th[q]);
+    fprintf(f, "], \"Distributions\": null},\n");
+  }
+  fprintf(f, "    {\"Name\": \"transform\", \"Parameters\": {\"Offset\": [");
+  if (has_offset) for (size_t q = 0; q < offset.size(); q++) fprintf(f, "%s%.17g", q ? "," : "", offset[q]);
+  fprintf(f, "], \"Scale\": [");
+  if (has_scale) for (size_t q = 0; q < scale.size(); q++) fprintf(f, "%s%.17g", q ? "," : "", scale[q]);
+  fprintf(f, "]}, \"Distributions\": null}\n  ]\n}\n");
+  fclose(f);
+  return KLR_OK;
+}

@@ -240,3 +240,42 @@ def test_scores3_copreselection_selectdata(golden_dir):
         want = dense[:, f1] if f1 == f2 else dense[:, f1] * dense[:, f2]
         np.testing.assert_allclose(sel[:, j + 1], want, atol=1e-10)
     OD.free_matrix(exp_h); OD.free_matrix(h)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ensembles (estimate_ensemble, kmerLr_estimator_ensemble.go:74-96)
+# ---------------------------------------------------------------------------------------------------
+def test_ensemble_members_train_on_the_other_groups(tmp_path):
+    x, labels = O.synth_csr(11, 0, 400, 400, 64, 30, 8)
+    h = OD.matrix(x, labels)
+    E, la = 3, [4, 8]
+    est = OD.estimator()
+    cls = est.estimate_ensemble(h, x.n, E, la, seed=7)
+    assert len(cls) == E * len(la)
+    groups = np.zeros(x.n, dtype=np.int32)
+    OD.lib().klr_cv_groups(x.n, E, 7, 0, x.n, groups.ctypes.data)
+    dense = x.to_dense()
+    for k in range(E):
+        keep = np.nonzero(groups != k)[0]
+        sub = O.Csr.from_dense(dense[keep][:, 1:])
+        hs = OD.matrix(sub, labels[keep])
+        ref = OD.estimator().estimate(hs, la)
+        for j in range(len(la)):
+            c = cls[k * len(la) + j]
+            np.testing.assert_array_equal(c["cols"], ref[j]["cols"])
+            np.testing.assert_allclose(c["theta"], ref[j]["theta"], rtol=1e-9, atol=1e-12)
+        OD.free_matrix(hs)
+    # one model file per lambda_auto: union of the members' features, one coefficient vector per member
+    est.save_ensemble(1, E, len(la), str(tmp_path / "ens.json"), summary="mean")
+    m = json.load(open(tmp_path / "ens.json"))
+    assert m["Name"] == "scoresLr [mean]"
+    lr = [dct for dct in m["Distributions"] if dct["Name"] == "vector:logistic regression"]
+    assert len(lr) == E and m["Distributions"][-1]["Name"] == "transform"
+    uni = sorted(set(int(cc) - 1 for k in range(E) for cc, t in zip(cls[k * 2 + 1]["cols"][1:], cls[k * 2 + 1]["theta"][1:]) if t != 0.0))
+    assert m["Parameters"]["Index"] == uni
+    for k in range(E):
+        c = cls[k * 2 + 1]
+        th = dict((int(cc) - 1, t) for cc, t in zip(c["cols"][1:], c["theta"][1:]))
+        want = [c["theta"][0]] + [th.get(u, 0.0) for u in uni]
+        np.testing.assert_allclose(lr[k]["Parameters"], want)
+    OD.free_matrix(h)

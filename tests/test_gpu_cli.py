@@ -192,3 +192,34 @@ def test_scores3_copreselection_cli(tmp_path):
     assert set(idx) <= set(int(v) - 1 for v in base_cols[1:])
     np.testing.assert_allclose(m["Distributions"][0]["Parameters"], c["theta"], rtol=1e-6, atol=1e-9)
     OD.free_matrix(exp_h); OD.free_matrix(h)
+
+
+def test_ensemble_cli(tmp_path):
+    # learn --ensemble-size=3 (kmerLr_learn.go:129-130, estimate_ensemble): one model with 3 coefficient vectors;
+    # predict / loss summarise the members (Summarize, kmerLr_classifier_ensemble.go:64-104)
+    fg, bg = os.path.join(GOLDEN, "scoresLr_test_fg.table"), os.path.join(GOLDEN, "scoresLr_test_bg.table")
+    run(["--type=scoresLr", "learn", "--lambda-auto=2", "--ensemble-size=3", "--ensemble-summary=mean", "--seed=5", fg, bg, "ens"], tmp_path)
+    m = json.load(open(tmp_path / "ens.json"))
+    assert m["Name"] == "scoresLr [mean]"
+    lr = [d for d in m["Distributions"] if d["Name"] == "vector:logistic regression"]
+    assert len(lr) == 3
+    _, xf = O.read_scores_table(fg); _, xb = O.read_scores_table(bg)
+    dense = np.concatenate([xf, xb]); labels = np.array([1] * 8 + [0] * 8, dtype=np.uint8)
+    x = O.Csr.from_dense(dense)
+    # the same ensemble from the oracle-served driver
+    h = OD.matrix(x, labels)
+    cls = OD.estimator().estimate_ensemble(h, x.n, 3, [2], seed=5)
+    uni = sorted(set(int(cc) - 1 for c in cls for cc, t in zip(c["cols"][1:], c["theta"][1:]) if t != 0.0))
+    assert m["Parameters"]["Index"] == uni
+    for k in range(3):
+        th = dict((int(cc) - 1, t) for cc, t in zip(cls[k]["cols"][1:], cls[k]["theta"][1:]))
+        want = [cls[k]["theta"][0]] + [th.get(u, 0.0) for u in uni]
+        np.testing.assert_allclose(lr[k]["Parameters"], want, rtol=1e-6, atol=1e-9)
+    OD.free_matrix(h)
+    red = O.select_columns(x, [0] + [u + 1 for u in uni])
+    pred = run(["--type=scoresLr", "predict", "ens.json", fg], tmp_path).stdout.split()[1:]
+    want = [np.mean([O.class_log_pdf(red, i, d["Parameters"], y=1) for d in lr]) for i in range(8)]
+    np.testing.assert_allclose([float(v) for v in pred], want, rtol=1e-6)
+    out = run(["--type=scoresLr", "loss", "ens.json", fg, bg], tmp_path).stdout
+    ref = np.mean([O.loss(red, labels, d["Parameters"]) for d in lr])
+    assert abs(float(out) - ref) < 1e-6 * ref
