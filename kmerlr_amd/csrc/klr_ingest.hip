@@ -322,6 +322,7 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
     KLR_TRY(d2h_sync(ctx, h_tot, d_tot, 16));
     u24 = 3ull * h_tot[0] <= 4ull * h_tot[1];
     if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
+    if (h_tot[0] >= (1ull << 31)) u24 = false;        // unit entries only while the stream stays below 6 GiB
   }
   u32 *tkey, *ne, *tile_ne, *tile_q4, *skey, *sne;
   KLR_TRY(tmp.get(ctx, &tkey, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &ne, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &skey, (size_t)nnz));
@@ -361,6 +362,26 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   for (i64 t = 0; t <= ntile; t++) toff4[(size_t)t] = (u64)h_tq[(size_t)t];
   m->stored_entries = h_stored;
   return build_pieces_and_upload(ctx, m, toff4, nrt, nct, rt_major);
+}
+
+// row id of every stored entry (one wavefront per row)
+__global__ __launch_bounds__(256) void k_row_ids(const i64* __restrict__ rowptr, i64 n, u32* __restrict__ erow) {
+  const i64 i = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  for (i64 a = rowptr[i] + (threadIdx.x & 63); a < rowptr[i + 1]; a += 64) erow[a] = (u32)i;
+}
+
+// CSC, tiles and host metadata of a count matrix whose narrow CSR (rowptr, u32 col, f32 val) and labels are already
+// on the device: klr_mat_from_csr's route for large count data
+int device_finish_csr(klr_ctx* ctx, klr_mat* m) {
+  TmpPool tmp;
+  u32* erow;
+  KLR_TRY(tmp.get(ctx, &erow, (size_t)std::max<i64>(m->nnz, 1)));
+  if (m->n) hipLaunchKernelGGL(k_row_ids, dim3((unsigned)ceil_div(m->n, 4)), dim3(256), 0, ctx->stream, m->rowptr, m->n, erow);
+  KLR_HIP(ctx, hipGetLastError());
+  KLR_TRY(finish_from_device_csr(ctx, m, erow, tmp));
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KLR_OK;
 }
 
 extern "C" int klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int64_t* seq_off, int64_t n, int M, int N,

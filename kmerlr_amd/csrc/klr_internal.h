@@ -219,3 +219,5 @@ static const u32 TILE_BITS = 12;
 static const u32 TILE_DIM = 1u << TILE_BITS;   // at most 4096 rows x 4096 columns per tile: 32 KiB of s + 32 KiB of g in LDS
 // rows / columns per tile and the tile grid for an n x dim shard swept by nwg workgroups
 void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt, i64* nct);
+// klr_ingest.hip: CSC + tiles + host metadata from a narrow count CSR already on the device
+int device_finish_csr(klr_ctx* ctx, klr_mat* m);

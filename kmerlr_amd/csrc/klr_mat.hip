@@ -274,6 +274,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   for (i64 t = 0; t < ntile; t++) { tot4 += tlen[(size_t)t]; tot1 += tlen1[(size_t)t]; }
   bool u24 = 3 * tot1 <= 4 * tot4;
   if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
+  if (tot1 >= ((u64)1 << 31)) u24 = false;            // unit entries only while the stream stays below 6 GiB
   if (u24) tlen.swap(tlen1);
   std::vector<u64> toff4((size_t)ntile + 1);
   u64 run = 0, stored = 0;
@@ -338,8 +339,13 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
                              std::max<i64>(1, n / 4096));
   std::vector<std::vector<u32>> cnt(T, std::vector<u32>((size_t)dim, 0u));
   std::vector<std::vector<u32>> cnz(T, std::vector<u32>((size_t)dim, 0u));
-  std::vector<int> bad(T, 0), notf32(T, 0);
+  std::vector<int> bad(T, 0), notf32(T, 0), notcount(T, 0);
   std::vector<i64> n1(T, 0);
+  // large inputs also get their narrow copy (u32 column, f32 value) in this pass: if they turn out to be count data,
+  // the device builds CSC and tiles from it (KLR_HOST_INGEST=1 keeps everything on the host)
+  const bool maybe_device = n >= 2048 && nnz >= (1 << 20) && !getenv("KLR_HOST_INGEST");
+  std::vector<u32> n_col(maybe_device ? (size_t)nnz : 0);
+  std::vector<float> n_val(maybe_device ? (size_t)nnz : 0);
   auto rows_of = [&](int t, i64& r0, i64& r1) { r0 = n * t / T; r1 = n * (t + 1) / T; };
   {
     std::vector<std::thread> th;
@@ -359,6 +365,8 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
           const double v = val[a];
           if (v != 0.0) cnz[t][c]++;
           if ((double)(float)v != v) notf32[t] = 1;
+          if (!(v >= 1.0 && v <= 16777216.0 && v == (double)(u32)v)) notcount[t] = 1;
+          if (maybe_device) { n_col[(size_t)a] = (u32)c; n_val[(size_t)a] = (float)v; }
         }
       }
     });
@@ -372,8 +380,28 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
   m->ctx = ctx; m->device = ctx->device; m->n = n; m->dim = dim; m->nnz = nnz; m->n_total = n_total;
   m->n_total_all = n_total; m->h_labels.assign(labels, labels + n);
   m->val_f64 = false;
-  for (int t = 0; t < T; t++) { if (notf32[t]) m->val_f64 = true; m->n1_local += n1[t]; }
+  bool counts = true;
+  for (int t = 0; t < T; t++) { if (notf32[t]) m->val_f64 = true; if (notcount[t]) counts = false; m->n1_local += n1[t]; }
   m->avg_row = n ? (double)nnz / (double)n : 0.0;
+  if (maybe_device && counts) {
+    // ---- device route: upload the narrow CSR, everything else is built there (klr_ingest.hip) -------------------
+    int rc = KLR_OK;
+    do {
+      if ((rc = dev_alloc(ctx, (void**)&m->rowptr, (size_t)(n + 1) * sizeof(i64)))) break;
+      if ((rc = dev_alloc(ctx, (void**)&m->col, (size_t)nnz * sizeof(u32)))) break;
+      if ((rc = dev_alloc(ctx, &m->val, (size_t)nnz * 4))) break;
+      if ((rc = dev_alloc(ctx, (void**)&m->labels, (size_t)n))) break;
+      hipError_t e = hipMemcpy(m->rowptr, rowptr, (size_t)(n + 1) * sizeof(i64), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(m->col, n_col.data(), (size_t)nnz * sizeof(u32), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(m->val, n_val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(m->labels, labels, (size_t)n, hipMemcpyHostToDevice);
+      if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "matrix upload failed: %s", hipGetErrorString(e)); break; }
+      rc = device_finish_csr(ctx, m);
+    } while (0);
+    if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(m); ctx->err = keep; return rc; }
+    *out = m;
+    return KLR_OK;
+  }
   m->h_colptr.assign((size_t)dim + 1, 0);
   m->h_collen.assign((size_t)dim, 0);
   m->h_colnz.assign((size_t)dim, 0);

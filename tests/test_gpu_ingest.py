@@ -102,7 +102,34 @@ def test_ambiguous_characters_and_short_sequences(ctx):
         np.testing.assert_array_equal(rp, x.rowptr); np.testing.assert_array_equal(col, x.col); np.testing.assert_array_equal(val, x.val)
 
 
-def test_large_device_ingest_equals_host_ingest(ctx):
+@pytest.fixture()
+def host_ingest(monkeypatch):
+    # klr_mat_from_csr builds large count matrices on the device too; KLR_HOST_INGEST=1 selects the host builder
+    monkeypatch.setenv("KLR_HOST_INGEST", "1")
+
+
+def test_from_csr_device_route_equals_host_route(ctx, monkeypatch):
+    from oracle import oracle as O
+    x, labels = O.synth_csr(77, 0, 9000, 9000, 5000, 200, 8)
+    v = x.val.copy(); v[5::31] = 300.0; v[x.rowptr[:-1]] = 1.0          # some counts above 255
+    md = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, v, labels)
+    monkeypatch.setenv("KLR_HOST_INGEST", "1")
+    mh = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, v, labels)
+    monkeypatch.delenv("KLR_HOST_INGEST")
+    assert md.layout() == mh.layout() and md.layout()["tiled"]
+    for a, b in zip(md.to_csr(), mh.to_csr()):
+        np.testing.assert_array_equal(a, b)
+    cw = md.class_weights()
+    rd = K.sweep_select(ctx, md, None, None, np.zeros(1), cw, 20, want_g=True)
+    rh = K.sweep_select(ctx, mh, None, None, np.zeros(1), cw, 20, want_g=True)
+    np.testing.assert_array_equal(rd["g"], rh["g"])
+    cols = np.nonzero(rd["b"])[0]
+    for a, b in zip(md.select_columns(cols).to_csr(), mh.select_columns(cols).to_csr()):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(K.transform_fit(ctx, md, "variance-scaler")[0], K.transform_fit(ctx, mh, "variance-scaler")[0])
+
+
+def test_large_device_ingest_equals_host_ingest(ctx, host_ingest):
     """Tiled layout built on the device: bit-identical gradient, selection and solve to the host-ingested matrix."""
     rng = np.random.default_rng(5)
     n, L = 6000, 400
