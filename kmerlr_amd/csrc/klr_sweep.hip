@@ -353,7 +353,7 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
                                                        const uint4* __restrict__ wgrec, const u32* __restrict__ tileq,
                                                        u32 nrt, u32 nct_or0, u32 RT, i64 n, const i64* __restrict__ S,
                                                        i64* __restrict__ part) {
-  static_assert(!U24 || UNROLL == 1, "unit entries: one quad per lane and trip");
+  static_assert(!U24 || UNROLL <= 2, "unit entries: one quad per lane and trip (UNROLL 2 = ping-pong prefetch)");
   extern __shared__ unsigned long long coo_lds[];
   i64* sS = (i64*)coo_lds;
   unsigned long long* sG = coo_lds + TILE_DIM;
@@ -396,7 +396,43 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
         cur_rt = rt;
       }
       __syncthreads();                                  // s tile (and the zeroed accumulators) visible
-      if (U24) {
+      if (U24 && UNROLL == 2 && ABL == 0) {
+        // ping-pong prefetch: the next 12 bytes are requested before the current quad goes through LDS.  Two register
+        // sets alternate (no copies of in-flight values), the loads are branch free (clamped to the tile's last
+        // quad) and the trip count is uniform (lanes past the end consume null entries spread over the columns), so
+        // the compiler counts its waits (vmcnt(1)) instead of draining before every use.  The kernel is a closed
+        // loop between HBM latency and the LDS atomic unit (~14 clocks per ds_add_u64 instruction whatever its lanes
+        // do, tools/lds_probe.hip); overlapping the two is worth 3-4 %.
+        const u32 nit = (q1 - q0 + THREADS - 1) / THREADS, qend = q1 - 1;
+        const u32 nul = ((tid & (TILE_DIM - 1)) << TILE_BITS) | (TILE_DIM - 1);     // row 4095 (s = 0), a column of its own
+        const u32 n0 = nul | (nul << 24), n1 = (nul >> 8) | (nul << 16), n2 = (nul >> 16) | (nul << 8);
+        u32 q = q0 + tid;
+        u32 A0, A1, A2, B0, B1, B2;
+#define LD3(X0, X1, X2, QQ) { const u32* s_ = ent + 3ull * min((QQ), qend); X0 = __builtin_nontemporal_load(s_); X1 = __builtin_nontemporal_load(s_ + 1); X2 = __builtin_nontemporal_load(s_ + 2); }
+#define EAT3(X0, X1, X2, OK) {                                                                                      \
+          const bool ok_ = (OK);                                                                                     \
+          const u32 x0_ = ok_ ? X0 : n0, x1_ = ok_ ? X1 : n1, x2_ = ok_ ? X2 : n2;                                   \
+          const u32 e0_ = x0_ & 0xFFFFFFu, e1_ = __builtin_amdgcn_alignbit(x1_, x0_, 24) & 0xFFFFFFu;                \
+          const u32 e2_ = __builtin_amdgcn_alignbit(x2_, x1_, 16) & 0xFFFFFFu, e3_ = x2_ >> 8;                       \
+          const unsigned long long s0_ = (unsigned long long)sS[e0_ & (TILE_DIM - 1)], s1_ = (unsigned long long)sS[e1_ & (TILE_DIM - 1)]; \
+          const unsigned long long s2_ = (unsigned long long)sS[e2_ & (TILE_DIM - 1)], s3_ = (unsigned long long)sS[e3_ & (TILE_DIM - 1)]; \
+          atomicAdd(&sG[e0_ >> TILE_BITS], s0_); atomicAdd(&sG[e1_ >> TILE_BITS], s1_);                              \
+          atomicAdd(&sG[e2_ >> TILE_BITS], s2_); atomicAdd(&sG[e3_ >> TILE_BITS], s3_); }
+        LD3(A0, A1, A2, q);
+        for (u32 it = 0; it < nit; it += 2) {
+          LD3(B0, B1, B2, q + THREADS);
+          __builtin_amdgcn_sched_barrier(0);              // keep the order: request, then consume the other set
+          EAT3(A0, A1, A2, q < q1);
+          __builtin_amdgcn_sched_barrier(0);
+          LD3(A0, A1, A2, q + 2 * THREADS);
+          __builtin_amdgcn_sched_barrier(0);
+          EAT3(B0, B1, B2, q + THREADS < q1);
+          __builtin_amdgcn_sched_barrier(0);
+          q += 2 * THREADS;
+        }
+#undef LD3
+#undef EAT3
+      } else if (U24) {
         for (u32 q = q0 + tid; q < q1; q += THREADS) {
           const u32* src = ent + 3ull * q;
           u32 a0, a1, a2;
@@ -472,7 +508,8 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
       case 26: return launch_sweep_coo<1024, 1, true, 3, true>(ctx, mat, S, part, e0, e1);   // stream only
       case 14: return launch_sweep_coo<1024, 1, false, 0, true>(ctx, mat, S, part, e0, e1);
       case 13: return launch_sweep_coo<512, 1, true, 0, true>(ctx, mat, S, part, e0, e1);
-      default: return launch_sweep_coo<1024, 1, true, 0, true>(ctx, mat, S, part, e0, e1);   // shipped: 32 waves/CU, nt loads
+      case 12: return launch_sweep_coo<1024, 1, true, 0, true>(ctx, mat, S, part, e0, e1);   // one load per trip, no prefetch
+      default: return launch_sweep_coo<1024, 2, true, 0, true>(ctx, mat, S, part, e0, e1);   // shipped: 32 waves/CU, nt loads, ping-pong prefetch
     }
   }
   switch (g_coo_variant) {
