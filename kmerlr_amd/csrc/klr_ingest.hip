@@ -227,6 +227,70 @@ __global__ __launch_bounds__(256) void k_entry_totals(const u32* __restrict__ co
   if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], t1); atomicAdd(&out[1], t4); }
 }
 
+// ---- r64 quads: one thread per row walks the row's (column-sorted) entries twice -------------------------------------
+// pass 1: quads of every (row, column tile) run -> rq[tile * RT + row in tile]
+__global__ __launch_bounds__(256) void k_r64_count(const i64* __restrict__ rowptr, const u32* __restrict__ col, const float* __restrict__ val,
+                                                   i64 n, u32 RT, u32 CT, u32 nrt, u32 nct, int rt_major, u32* __restrict__ rq) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u32 rt = (u32)(i / RT), ri = (u32)(i - (i64)rt * RT);
+  u32 cur_ct = 0xFFFFFFFFu, run = 0;
+  for (i64 a = rowptr[i] + 1; a < rowptr[i + 1]; a++) {                    // entry 0 is the bias
+    const u32 ct = col[a] / CT;
+    if (ct != cur_ct) {
+      if (cur_ct != 0xFFFFFFFFu) rq[(size_t)(rt_major ? rt * nct + cur_ct : cur_ct * nrt + rt) * RT + ri] = (run + 3u) / 4u;
+      cur_ct = ct; run = 0;
+    }
+    run += (u32)val[a];
+  }
+  if (cur_ct != 0xFFFFFFFFu) rq[(size_t)(rt_major ? rt * nct + cur_ct : cur_ct * nrt + rt) * RT + ri] = (run + 3u) / 4u;
+}
+
+// quads per tile -> 16-byte load units (two quads)
+__global__ __launch_bounds__(256) void k_r64_tile_units(const i64* __restrict__ rq_prefix, u32 RT, u32 ntile, u32* __restrict__ units) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t < ntile) units[t] = (u32)((rq_prefix[(size_t)(t + 1) * RT] - rq_prefix[(size_t)t * RT] + 1) / 2);
+}
+
+// pass 2: the quads themselves; every quad is written by exactly one thread
+__global__ __launch_bounds__(256) void k_r64_fill(const i64* __restrict__ rowptr, const u32* __restrict__ col, const float* __restrict__ val,
+                                                  i64 n, u32 RT, u32 CT, u32 nrt, u32 nct, int rt_major, const i64* __restrict__ rq_prefix,
+                                                  const i64* __restrict__ tile_unit, unsigned long long* __restrict__ ent) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u32 rt = (u32)(i / RT), ri = (u32)(i - (i64)rt * RT);
+  u32 cur_ct = 0xFFFFFFFFu, p = 0;
+  i64 qpos = 0;
+  unsigned long long w = 0;
+  for (i64 a = rowptr[i] + 1; a < rowptr[i + 1]; a++) {
+    const u32 c = col[a];
+    const u32 ct = c / CT;
+    if (ct != cur_ct) {
+      if (cur_ct != 0xFFFFFFFFu && (p & 3u)) ent[qpos++] = w;
+      const size_t t = (size_t)(rt_major ? rt * nct + ct : ct * nrt + rt);
+      qpos = tile_unit[t] * 2 + (rq_prefix[t * RT + ri] - rq_prefix[t * RT]);
+      cur_ct = ct; p = 0;
+    }
+    const unsigned long long cl = (unsigned long long)(c - ct * CT);
+    for (u32 v = (u32)val[a]; v > 0u; v--) {
+      if ((p & 3u) == 0u) w = r64_null_quad(ri, (u32)qpos);
+      const int sh = 12 * (int)(p & 3u);
+      w = (w & ~(0xFFFull << sh)) | (cl << sh);
+      if ((++p & 3u) == 0u) ent[qpos++] = w;
+    }
+  }
+  if (cur_ct != 0xFFFFFFFFu && (p & 3u)) ent[qpos++] = w;
+}
+
+// tiles with an odd number of quads end in a null quad (row 4095: s = 0)
+__global__ __launch_bounds__(256) void k_r64_pad(const i64* __restrict__ rq_prefix, const i64* __restrict__ tile_unit, u32 RT, u32 ntile,
+                                                 unsigned long long* __restrict__ ent) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntile) return;
+  const i64 quads = rq_prefix[(size_t)(t + 1) * RT] - rq_prefix[(size_t)t * RT];
+  if (quads & 1) { const i64 qp = tile_unit[t] * 2 + quads; ent[qp] = r64_null_quad(4095u, (u32)qp); }
+}
+
 // the stream pre-filled with null unit entries (row 4095, column 0): bytes FF 0F 00 repeating
 __global__ __launch_bounds__(256) void k_fill_u24_null(u32* __restrict__ w, i64 nwords) {
   const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -323,6 +387,40 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
     u24 = 3ull * h_tot[0] <= 4ull * h_tot[1];
     if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
     if (h_tot[0] >= (1ull << 31)) u24 = false;        // unit entries only while the stream stays below 6 GiB
+    // r64 (8-byte quads row:12 | 4 x col:12, every (row, tile) run padded to 4 columns): needs no sort at all
+    const char* ef = getenv("KLR_ENTRY_FORMAT");
+    const bool forced_other = ef && (!strcmp(ef, "u24") || !strcmp(ef, "u32"));
+    if (h_tot[0] < (1ull << 31) && !forced_other && (u64)ntile * m->tile_r < ((u64)1 << 31)) {
+      const u32 RT = m->tile_r;
+      u32 *rq, *tunits; i64 *rq_prefix, *tile_unit;
+      KLR_TRY(tmp.get(ctx, &rq, (size_t)ntile * RT + 1)); KLR_TRY(tmp.get(ctx, &rq_prefix, (size_t)ntile * RT + 2));
+      KLR_TRY(tmp.get(ctx, &tunits, (size_t)ntile + 1)); KLR_TRY(tmp.get(ctx, &tile_unit, (size_t)ntile + 2));
+      KLR_HIP(ctx, hipMemsetAsync(rq, 0, ((size_t)ntile * RT + 1) * 4, st));
+      hipLaunchKernelGGL(k_r64_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, RT, m->tile_c, (u32)nrt,
+                         (u32)nct, rt_major ? 1 : 0, rq);
+      KLR_TRY(exscan64(ctx, rq, (i64)ntile * RT, rq_prefix));
+      hipLaunchKernelGGL(k_r64_tile_units, dim3((unsigned)ceil_div(ntile, 256)), dim3(256), 0, st, rq_prefix, RT, (u32)ntile, tunits);
+      KLR_TRY(exscan64(ctx, tunits, ntile, tile_unit));
+      std::vector<i64> h_tu((size_t)ntile + 1);
+      KLR_TRY(d2h_sync(ctx, h_tu.data(), tile_unit, (size_t)(ntile + 1) * 8));
+      const u64 units_r = (u64)h_tu[(size_t)ntile];
+      const u64 bytes_r = 16 * units_r, bytes_other = u24 ? 12 * ((h_tot[0] + 3) / 4) : 16 * ((h_tot[1] + 3) / 4);   // (per-tile padding of the others ignored)
+      const bool force_r = ef && !strcmp(ef, "r64");
+      if (units_r > 0 && units_r < 0xFFFFFFF0ull && (bytes_r <= bytes_other || force_r)) {
+        KLR_TRY(dalloc(ctx, &m->t_ent, (size_t)units_r * 4));
+        unsigned long long* ent64 = reinterpret_cast<unsigned long long*>(m->t_ent);
+        hipLaunchKernelGGL(k_r64_fill, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, RT, m->tile_c, (u32)nrt,
+                           (u32)nct, rt_major ? 1 : 0, rq_prefix, tile_unit, ent64);
+        hipLaunchKernelGGL(k_r64_pad, dim3((unsigned)ceil_div(ntile, 256)), dim3(256), 0, st, rq_prefix, tile_unit, RT, (u32)ntile, ent64);
+        KLR_HIP(ctx, hipGetLastError());
+        KLR_HIP(ctx, hipStreamSynchronize(st));
+        m->fmt = FMT_R64;
+        m->stored_entries = (i64)h_tot[0];
+        std::vector<u64> toff4((size_t)ntile + 1);
+        for (i64 t = 0; t <= ntile; t++) toff4[(size_t)t] = (u64)h_tu[(size_t)t];
+        return build_pieces_and_upload(ctx, m, toff4, nrt, nct, rt_major);
+      }
+    }
   }
   u32 *tkey, *ne, *tile_ne, *tile_q4, *skey, *sne;
   KLR_TRY(tmp.get(ctx, &tkey, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &ne, (size_t)nnz)); KLR_TRY(tmp.get(ctx, &skey, (size_t)nnz));
@@ -353,7 +451,7 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   KLR_TRY(dalloc(ctx, &m->t_ent, (size_t)total4 * 4));                 // 16 bytes per quad (12 used by unit entries)
   if (u24) hipLaunchKernelGGL(k_fill_u24_null, dim3((unsigned)ceil_div(total4 * 3, 256)), dim3(256), 0, st, m->t_ent, total4 * 3);
   else KLR_HIP(ctx, hipMemsetAsync(m->t_ent, 0, (size_t)total4 * 16, st));
-  m->u24 = u24;
+  m->fmt = u24 ? FMT_U24 : FMT_U32;
   hipLaunchKernelGGL(k_tile_scatter, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, skey, vout, nnz, (u32)ntile, ne_prefix,
                      tile_first, tile_q, m->col, val, erow, m->tile_r, m->tile_c, u24 ? 1 : 0, m->t_ent);
   KLR_HIP(ctx, hipGetLastError());

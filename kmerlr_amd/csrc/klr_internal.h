@@ -104,7 +104,8 @@ struct klr_mat {
   u32* t_piece = nullptr;        // npiece * 4: {column tile, quad begin, quad end, first tile index}
   u32* t_tileq = nullptr;        // ntile+1 quad offsets of the tiles (column-tile major: tile = ct*nrt + rt)
   u32* t_wgpiece = nullptr;      // 8 u32 per workgroup: its pieces and everything its first tile needs
-  bool u24 = false;              // entries are 3-byte unit entries (row:12|col:12) instead of 4-byte (count:8|col:12|row:12)
+  int  fmt = 0;                  // FMT_U32: 4-byte entries (count:8|col:12|row:12); FMT_U24: 3-byte unit entries (col:12|row:12);
+                                 // FMT_R64: 8-byte quads (row:12 | 4 x col:12), a row's run padded to 4 columns: 2 bytes per unit entry
   u32 tile_r = 4096, tile_c = 4096;   // rows / columns per tile (<= TILE_DIM), chosen at ingest (tile_geometry)
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile
@@ -215,7 +216,14 @@ int   build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, 
 static inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
 
 // 2-D tiled packed COO (klr_mat.hip build_tiled, klr_sweep.hip k_sweep_coo)
+enum { FMT_U32 = 0, FMT_U24 = 1, FMT_R64 = 2 };
 static const u32 TILE_BITS = 12;
+// an r64 quad with all four columns padding: the quad's position spreads them over the 64 spare slots
+static inline __host__ __device__ unsigned long long r64_null_quad(unsigned row, unsigned pos) {
+  const unsigned long long d = 4032u + (pos & 63u);
+  return ((unsigned long long)row << 48) | (d << 36) | (d << 24) | (d << 12) | d;
+}
+static const u32 R64_DUMP = 4032;          // accumulator slots 4032..4095 take the padding columns of r64 quads (tiles are at most 4032 wide)
 static const u32 TILE_DIM = 1u << TILE_BITS;   // at most 4096 rows x 4096 columns per tile: 32 KiB of s + 32 KiB of g in LDS
 // rows / columns per tile and the tile grid for an n x dim shard swept by nwg workgroups
 void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt, i64* nct);

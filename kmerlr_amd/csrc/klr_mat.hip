@@ -48,9 +48,10 @@ extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows
   if (tiled) *tiled = mat->tiled ? 1 : 0;
   if (tile_rows) *tile_rows = mat->tiled ? (int64_t)mat->tile_r : mat->n;
   if (nseg) *nseg = mat->tiled ? (int64_t)mat->npiece : mat->nchunks;
-  if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * 4 : mat->nnz_pad;
+  if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * (mat->fmt == FMT_R64 ? 8 : 4) : mat->nnz_pad;
   if (lanes_per_segment) *lanes_per_segment = mat->tiled ? 0 : mat->group;
-  if (value_bytes) *value_bytes = mat->tiled ? (mat->u24 ? 0 : 1) : (mat->val_f64 ? 8 : 4);   // + 3 bytes of row/col per tiled entry
+  // tiled: bytes per padded entry = 3 + value_bytes (u32: 1, u24: 0, r64: -1 -- four columns share one row field)
+  if (value_bytes) *value_bytes = mat->tiled ? (mat->fmt == FMT_U32 ? 1 : (mat->fmt == FMT_U24 ? 0 : -1)) : (mat->val_f64 ? 8 : 4);
   return KLR_OK;
 }
 
@@ -199,13 +200,14 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
 //   pieces = the entry stream cut into nwg equal parts (one per workgroup), each part cut where the
 //            column tile changes; a piece produces one 4096-wide int64 partial column-sum vector
 // =================================================================================================
-// Tile geometry.  A tile is at most 4094 x 4096 (12-bit offsets in an entry, 32 KiB + 32 KiB of LDS).  Columns:
+// Tile geometry.  A tile is at most 4094 x 4032 (12-bit offsets in an entry, 32 KiB + 32 KiB of LDS; row slot 4095 is the
+// null entry's zero, column slots 4032..4095 take the padding columns of r64 quads).  Columns:
 // the fewest strips that cover dim, equally wide.  Rows: if the matrix is small enough for one tile per
 // workgroup (nrt_min * nct <= nwg), as many equally tall row tiles as give one tile per workgroup -- then a
 // workgroup starts and ends on tile boundaries and streams its whole part without boundary work in between
 // (configs[2]: 30 x 17 tiles of 3334 x 3856 for 512 workgroups); otherwise the tallest tiles.
 void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt_out, i64* nct_out) {
-  i64 nct = std::max<i64>(1, ceil_div(dim, (i64)TILE_DIM));
+  i64 nct = std::max<i64>(1, ceil_div(dim, (i64)R64_DUMP));       // at most 4032 columns: 64 spare accumulator slots
   const i64 CT = std::max<i64>(1, ceil_div(dim, nct));
   nct = ceil_div(dim, CT);
   const i64 RT_MAX = TILE_DIM - 2;                           // slot 4095 of the s tile is the null entry's zero
@@ -242,6 +244,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   std::vector<int> bad(T, 0);
   std::vector<u64> tlen((size_t)ntile, 0);           // 4-byte entries per tile (counts > 255 split)
   std::vector<u64> tlen1((size_t)ntile, 0);          // unit entries per tile (sum of the counts)
+  std::vector<u64> tlenr((size_t)ntile, 0);          // r64: quads per tile (every (row, tile) run padded to 4 columns)
   std::vector<std::vector<double>> colsum(T, std::vector<double>((size_t)dim, 0.0));
   {
     std::vector<std::thread> th;
@@ -249,16 +252,24 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
       for (i64 rt = t; rt < nrt; rt += T) {
         u64* l = tlen.data();
         u64* l1 = tlen1.data();
+        u64* lr = tlenr.data();
         const i64 r0 = rt * RT, r1 = std::min<i64>(n, r0 + RT);
-        for (i64 a = rowptr[r0]; a < rowptr[r1]; a++) {
-          const double v = val[a];
-          if (!(v >= 0.0 && v <= 16777216.0 && v == (double)(u32)v)) { bad[t] = 1; return; }
-          const i64 c = col[a];
-          if (c == 0) continue;
-          const u32 iv = (u32)v;
-          l[(size_t)tix(rt, c / CT)] += (iv + 254u) / 255u;               // 0 -> no entry
-          l1[(size_t)tix(rt, c / CT)] += iv;
-          colsum[t][(size_t)c] += v;
+        for (i64 i = r0; i < r1; i++) {
+          i64 cur_ct = -1; u64 run = 0;
+          for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
+            const double v = val[a];
+            if (!(v >= 0.0 && v <= 16777216.0 && v == (double)(u32)v)) { bad[t] = 1; return; }
+            const i64 c = col[a];
+            if (c == 0) continue;
+            const u32 iv = (u32)v;
+            const i64 ct = c / CT;
+            if (ct != cur_ct) { if (cur_ct >= 0) lr[(size_t)tix(rt, cur_ct)] += (run + 3) / 4; cur_ct = ct; run = 0; }
+            run += iv;
+            l[(size_t)tix(rt, ct)] += (iv + 254u) / 255u;               // 0 -> no entry
+            l1[(size_t)tix(rt, ct)] += iv;
+            colsum[t][(size_t)c] += v;
+          }
+          if (cur_ct >= 0) lr[(size_t)tix(rt, cur_ct)] += (run + 3) / 4;
         }
       }
     });
@@ -268,31 +279,73 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   double amax = 0.0;
   for (i64 j = 1; j < dim; j++) { double sj = 0.0; for (int t = 0; t < T; t++) sj += colsum[t][(size_t)j]; amax = std::max(amax, sj); }
   colsum.clear();
-  // entry format: 3-byte unit entries when that is fewer bytes (k-mer counts: a row's counts sum to its number
-  // of windows, so it almost always is), else 4-byte entries with an 8-bit count.  KLR_ENTRY_FORMAT=u24|u32 overrides.
-  u64 tot4 = 0, tot1 = 0;
-  for (i64 t = 0; t < ntile; t++) { tot4 += tlen[(size_t)t]; tot1 += tlen1[(size_t)t]; }
-  bool u24 = 3 * tot1 <= 4 * tot4;
-  if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
-  if (tot1 >= ((u64)1 << 31)) u24 = false;            // unit entries only while the stream stays below 6 GiB
-  if (u24) tlen.swap(tlen1);
+  // entry format, whichever is fewer bytes (KLR_ENTRY_FORMAT=u32|u24|r64 overrides), all row-major inside a tile:
+  //   u32  4-byte entries with an 8-bit count (counts > 255 split)
+  //   u24  3-byte unit entries (a k-mer count row sums to its number of windows, so unit entries cost at most
+  //        windows / distinct more entries)
+  //   r64  unit entries with every (row, tile) run padded to 4 columns: an 8-byte quad = row:12 << 48 | 4 x col:12, i.e.
+  //        2 bytes per unit entry, one s read per quad; padding columns point at the spare accumulator slots 4032..4095
+  u64 tot4 = 0, tot1 = 0, totr = 0, units1 = 0;
+  for (i64 t = 0; t < ntile; t++) {
+    tot4 += (tlen[(size_t)t] + 3) / 4; tot1 += (tlen1[(size_t)t] + 3) / 4; totr += (tlenr[(size_t)t] + 1) / 2; units1 += tlen1[(size_t)t];
+  }
+  int fmt = FMT_U32;
+  u64 best = 16 * tot4;
+  if (units1 < ((u64)1 << 31)) {                     // unit entries only while the stream stays small
+    if (12 * tot1 <= best) { fmt = FMT_U24; best = 12 * tot1; }
+    if (16 * totr <= best) { fmt = FMT_R64; best = 16 * totr; }
+    if (const char* ef = getenv("KLR_ENTRY_FORMAT")) {
+      if (!strcmp(ef, "u24")) fmt = FMT_U24; else if (!strcmp(ef, "u32")) fmt = FMT_U32; else if (!strcmp(ef, "r64")) fmt = FMT_R64;
+    }
+  }
+  u64 stored = 0;
+  for (i64 t = 0; t < ntile; t++) stored += fmt == FMT_U32 ? tlen[(size_t)t] : tlen1[(size_t)t];
   std::vector<u64> toff4((size_t)ntile + 1);
-  u64 run = 0, stored = 0;
-  for (i64 t = 0; t < ntile; t++) { toff4[(size_t)t] = run; run += (tlen[(size_t)t] + 3) / 4; stored += tlen[(size_t)t]; }
+  u64 run = 0;
+  for (i64 t = 0; t < ntile; t++) {
+    toff4[(size_t)t] = run;
+    run += fmt == FMT_R64 ? (tlenr[(size_t)t] + 1) / 2 : ((fmt == FMT_U24 ? tlen1[(size_t)t] : tlen[(size_t)t]) + 3) / 4;
+  }
   toff4[(size_t)ntile] = run;
   if (run >= 0xFFFFFFF0ull || run == 0) return KLR_OK;
   const i64 total4 = (i64)run;
-  const size_t qbytes = u24 ? 12 : 16;                // a quad = 4 entries
+  const size_t qbytes = fmt == FMT_U24 ? 12 : 16;     // bytes per load unit: 4 entries (u32, u24) or 2 quads = 8 entries (r64)
   std::vector<unsigned char> ent((size_t)total4 * qbytes, 0);
-  if (u24) for (size_t e = 0; e < (size_t)total4 * 4; e++) { ent[e * 3] = 0xFF; ent[e * 3 + 1] = 0x0F; }   // null entries: row 4095, column 0
+  if (fmt == FMT_U24) for (size_t e = 0; e < (size_t)total4 * 4; e++) { ent[e * 3] = 0xFF; ent[e * 3 + 1] = 0x0F; }   // null entries: row 4095, column 0
+  if (fmt == FMT_R64) {                               // null quads: row 4095 (s = 0), spread padding columns
+    u64* w = reinterpret_cast<u64*>(ent.data());
+    for (size_t e = 0; e < (size_t)total4 * 2; e++) w[e] = r64_null_quad(4095u, (u32)e);
+  }
   {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
       std::vector<u64> cur((size_t)nct);
       u32* ent32 = reinterpret_cast<u32*>(ent.data());
+      u64* ent64 = reinterpret_cast<u64*>(ent.data());
       for (i64 rt = t; rt < nrt; rt += T) {
-        for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)tix(rt, ct)] * 4;
         const i64 r0 = rt * RT, r1 = std::min<i64>(n, r0 + RT);
+        if (fmt == FMT_R64) {
+          for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)tix(rt, ct)] * 2;      // in quads
+          for (i64 i = r0; i < r1; i++) {
+            i64 cur_ct = -1; u32 p = 0; u64 w = 0;
+            auto flush = [&]() { if (cur_ct >= 0 && p % 4 != 0) ent64[cur[(size_t)cur_ct]++] = w; };
+            for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
+              const i64 c = col[a];
+              if (c == 0) continue;
+              const i64 ct = c / CT;
+              if (ct != cur_ct) { flush(); cur_ct = ct; p = 0; }
+              for (u32 iv = (u32)val[a]; iv > 0; iv--) {
+                if (p % 4 == 0) w = r64_null_quad((u32)(i - r0), (u32)cur[(size_t)ct]);
+                const int sh = 12 * (int)(p % 4);
+                w = (w & ~(0xFFFull << sh)) | ((u64)(c - ct * CT) << sh);
+                if (++p % 4 == 0) ent64[cur[(size_t)ct]++] = w;
+              }
+            }
+            flush();
+          }
+          continue;
+        }
+        for (i64 ct = 0; ct < nct; ct++) cur[(size_t)ct] = toff4[(size_t)tix(rt, ct)] * 4;
         for (i64 i = r0; i < r1; i++)
           for (i64 a = rowptr[i]; a < rowptr[i + 1]; a++) {
             const i64 c = col[a];
@@ -301,7 +354,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
             const i64 ct = c / CT;
             const u32 base = ((u32)(c - ct * CT) << TILE_BITS) | (u32)(i - r0);
             u64& cu = cur[(size_t)ct];
-            if (u24) {
+            if (fmt == FMT_U24) {
               for (; iv > 0; iv--, cu++) { unsigned char* b = &ent[cu * 3]; b[0] = (unsigned char)base; b[1] = (unsigned char)(base >> 8); b[2] = (unsigned char)(base >> 16); }
             } else {
               while (iv > 0) { const u32 q = std::min(iv, 255u); ent32[cu++] = (q << 24) | base; iv -= q; }
@@ -313,7 +366,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   }
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ent, (size_t)total4 * qbytes));
   KLR_HIP(ctx, hipMemcpy(m->t_ent, ent.data(), (size_t)total4 * qbytes, hipMemcpyHostToDevice));
-  m->u24 = u24;
+  m->fmt = fmt;
   m->stored_entries = (i64)stored; m->col_abs_max = amax;
   KLR_TRY(build_pieces_and_upload(ctx, m, toff4, nrt, nct, rt_major));
   return KLR_OK;

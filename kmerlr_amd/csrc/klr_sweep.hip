@@ -348,12 +348,17 @@ __device__ __forceinline__ uint4 coo_load(const uint4* __restrict__ ent4, u32 q)
 //        tile_geometry never gives a tile more than 4094 rows), column 0.  k-mer count rows sum to the number of
 //        windows, so unit entries cost at most windows/distinct more entries (0.9 % at configs[2]) for 25 % fewer
 //        bytes each, and the product S*count disappears.
-template <int THREADS, int UNROLL, bool NT, int ABL, bool U24>
+//   r64: unit entries with every (row, tile) run padded to 4 columns: a quad is 8 bytes, row:12 << 48 | 4 x col:12, i.e.
+//        2 bytes per unit entry and ONE s read per four entries; a lane reads two quads (16 bytes) per trip.
+//        Padding columns point at the spare accumulator slots 4032..4095 (tiles are at most 4032 wide; the finishing
+//        kernel never reads them), spread by the quad's position; null quads carry row 4095.
+template <int THREADS, int UNROLL, bool NT, int ABL, int FMT>
 __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ ent, const uint4* __restrict__ piece,
                                                        const uint4* __restrict__ wgrec, const u32* __restrict__ tileq,
                                                        u32 nrt, u32 nct_or0, u32 RT, i64 n, const i64* __restrict__ S,
                                                        i64* __restrict__ part) {
-  static_assert(!U24 || UNROLL <= 2, "unit entries: one quad per lane and trip (UNROLL 2 = ping-pong prefetch)");
+  static_assert(FMT == FMT_U32 || UNROLL <= 2, "unit entries: one load per lane and trip (UNROLL 2 = ping-pong prefetch)");
+  constexpr bool U24 = FMT == FMT_U24;
   extern __shared__ unsigned long long coo_lds[];
   i64* sS = (i64*)coo_lds;
   unsigned long long* sG = coo_lds + TILE_DIM;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
   const u32 p0 = w0.x, p1 = w0.y;
   unsigned long long sink = 0ull;
   u32 cur_rt = 0xFFFFFFFFu;
-  if (U24 && tid == 0) sS[TILE_DIM - 1] = 0;            // the null entry's s slot; never overwritten (RT <= 4094)
+  if (FMT != FMT_U32 && tid == 0) sS[TILE_DIM - 1] = 0;   // the null entry's s slot; never overwritten (RT <= 4094)
   for (u32 p = p0; p < p1; p++) {
     uint4 d;                                            // {column tile, quad begin, quad end, first tile}
     if (p == p0) d = make_uint4(0u, w1.y, w1.z, w0.z); else d = piece[p];
@@ -396,7 +401,42 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
         cur_rt = rt;
       }
       __syncthreads();                                  // s tile (and the zeroed accumulators) visible
-      if (U24 && UNROLL == 2 && ABL == 0) {
+      if (FMT == FMT_R64) {
+        // two quads per lane and trip, ping-pong prefetch as in the u24 branch below
+        const uint4* ent4 = reinterpret_cast<const uint4*>(ent);
+        const u32 nit = (q1 - q0 + THREADS - 1) / THREADS, qend = q1 - 1;
+        const u32 dcol = R64_DUMP + (tid & 63u);
+        const u32 nlo = dcol | (dcol << 12) | (dcol << 24), nhi = (dcol >> 8) | (dcol << 4) | ((TILE_DIM - 1) << 16);
+        const uint4 nulq = make_uint4(nlo, nhi, nlo, nhi);            // row 4095 (s = 0), spare columns
+        u32 q = q0 + tid;
+        uint4 A, B;
+#define EATR(E0, OK) {                                                                                              \
+          const uint4 e_ = (OK) ? E0 : nulq;                                                                         \
+          if (ABL == 3) { sink += e_.x + e_.y + e_.z + e_.w; }                                                       \
+          else {                                                                                                     \
+            const unsigned long long sa_ = (unsigned long long)sS[(e_.y >> 16) & 0xFFFu], sb_ = (unsigned long long)sS[(e_.w >> 16) & 0xFFFu]; \
+            atomicAdd(&sG[e_.x & 0xFFFu], sa_); atomicAdd(&sG[(e_.x >> 12) & 0xFFFu], sa_);                          \
+            atomicAdd(&sG[__builtin_amdgcn_alignbit(e_.y, e_.x, 24) & 0xFFFu], sa_); atomicAdd(&sG[(e_.y >> 4) & 0xFFFu], sa_); \
+            atomicAdd(&sG[e_.z & 0xFFFu], sb_); atomicAdd(&sG[(e_.z >> 12) & 0xFFFu], sb_);                          \
+            atomicAdd(&sG[__builtin_amdgcn_alignbit(e_.w, e_.z, 24) & 0xFFFu], sb_); atomicAdd(&sG[(e_.w >> 4) & 0xFFFu], sb_); } }
+        if (UNROLL == 2) {
+          A = coo_load<NT>(ent4, min(q, qend));
+          for (u32 it = 0; it < nit; it += 2) {
+            B = coo_load<NT>(ent4, min(q + THREADS, qend));
+            __builtin_amdgcn_sched_barrier(0);
+            EATR(A, q < q1);
+            __builtin_amdgcn_sched_barrier(0);
+            A = coo_load<NT>(ent4, min(q + 2 * THREADS, qend));
+            __builtin_amdgcn_sched_barrier(0);
+            EATR(B, q + THREADS < q1);
+            __builtin_amdgcn_sched_barrier(0);
+            q += 2 * THREADS;
+          }
+        } else {
+          for (; q < q1; q += THREADS) { A = coo_load<NT>(ent4, q); EATR(A, true); }
+        }
+#undef EATR
+      } else if (U24 && UNROLL == 2 && ABL == 0) {
         // ping-pong prefetch: the next 12 bytes are requested before the current quad goes through LDS.  Two register
         // sets alternate (no copies of in-flight values), the loads are branch free (clamped to the tile's last
         // quad) and the trip count is uniform (lanes past the end consume null entries spread over the columns), so
@@ -483,17 +523,17 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
   }
 }
 
-template <int THREADS, int UNROLL, bool NT, int ABL = 0, bool U24 = false>
+template <int THREADS, int UNROLL, bool NT, int ABL = 0, int FMT = FMT_U32>
 static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds_bytes = (size_t)TILE_DIM * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL, U24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL, FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done = true;
   }
   // start / stop events ride on the dispatch packet itself (hipExtLaunchKernelGGL): recording them with
   // hipEventRecord puts two barrier packets around the kernel and costs ~15 us per step
-  hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL, U24>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+  hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL, FMT>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
                         (const u32*)mat->t_ent, (const uint4*)mat->t_piece, (const uint4*)mat->t_wgpiece, (const u32*)mat->t_tileq, mat->nrt,
                         mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->n, S, part);
   return KLR_OK;
@@ -503,13 +543,27 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
 static int g_coo_variant = -1;
 static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   if (g_coo_variant < 0) { const char* e = getenv("KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
-  if (mat->u24) {
+  if (mat->fmt == FMT_R64) {
     switch (g_coo_variant) {
-      case 26: return launch_sweep_coo<1024, 1, true, 3, true>(ctx, mat, S, part, e0, e1);   // stream only
-      case 14: return launch_sweep_coo<1024, 1, false, 0, true>(ctx, mat, S, part, e0, e1);
-      case 13: return launch_sweep_coo<512, 1, true, 0, true>(ctx, mat, S, part, e0, e1);
-      case 12: return launch_sweep_coo<1024, 1, true, 0, true>(ctx, mat, S, part, e0, e1);   // one load per trip, no prefetch
-      default: return launch_sweep_coo<1024, 2, true, 0, true>(ctx, mat, S, part, e0, e1);   // shipped: 32 waves/CU, nt loads, ping-pong prefetch
+      case 26: return launch_sweep_coo<1024, 2, true, 3, FMT_R64>(ctx, mat, S, part, e0, e1);   // stream only
+      case 14: return launch_sweep_coo<1024, 2, false, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+      case 13: return launch_sweep_coo<512, 2, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+      case 12: return launch_sweep_coo<1024, 1, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);   // no prefetch
+      default:
+        // shipped: 32 waves/CU, ping-pong prefetch.  A stream that fits the 256 MiB Infinity Cache together with the
+        // piece vectors is read with plain loads and stays resident from one sweep to the next (every leapfrog epoch
+        // sweeps the same matrix; measured 45.1 us against 48.7 us at configs[2]); larger ones stream non-temporally.
+        if ((size_t)mat->total4 * 16 <= ((size_t)220 << 20)) return launch_sweep_coo<1024, 2, false, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+        return launch_sweep_coo<1024, 2, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+    }
+  }
+  if (mat->fmt == FMT_U24) {
+    switch (g_coo_variant) {
+      case 26: return launch_sweep_coo<1024, 1, true, 3, FMT_U24>(ctx, mat, S, part, e0, e1);   // stream only
+      case 14: return launch_sweep_coo<1024, 1, false, 0, FMT_U24>(ctx, mat, S, part, e0, e1);
+      case 13: return launch_sweep_coo<512, 1, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);
+      case 12: return launch_sweep_coo<1024, 1, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);   // one load per trip, no prefetch
+      default: return launch_sweep_coo<1024, 2, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);   // shipped: 32 waves/CU, nt loads, ping-pong prefetch
     }
   }
   switch (g_coo_variant) {

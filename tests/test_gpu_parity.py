@@ -314,9 +314,9 @@ def synth_tiled():
     return x, labels
 
 
-@pytest.fixture(params=["u24", "u32"])
+@pytest.fixture(params=["r64", "u24", "u32"])
 def entry_format(request, monkeypatch):
-    # both packings of the tiled stream: 3-byte unit entries / 4-byte entries with an 8-bit count
+    # the packings of the tiled stream: 8-byte quads (row | 4 columns) / 3-byte unit entries / 4-byte entries with a count
     monkeypatch.setenv("KLR_ENTRY_FORMAT", request.param)
     return request.param
 
@@ -326,7 +326,7 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled, entry_format):
     m = upload(ctx, x, labels)
     lay = m.layout()
     assert lay["tiled"] and 0 < lay["tile_rows"] <= 4094 and lay["tile_rows"] % 2 == 0
-    assert lay["value_bytes"] == (0 if entry_format == "u24" else 1)
+    assert lay["value_bytes"] == {"r64": -1, "u24": 0, "u32": 1}[entry_format]
     cw = O.class_weights(labels)
     rng = np.random.default_rng(1)
     for k in (0, 40):
@@ -380,7 +380,7 @@ def test_full_size_properties(ctx):
     n, m, draws, N = 100000, 65536, 993, 100
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
     mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
-    assert mat.layout()["tiled"] and mat.layout()["value_bytes"] == 0      # k-mer counts: 3-byte unit entries
+    assert mat.layout()["tiled"] and mat.layout()["value_bytes"] == -1     # k-mer counts: 8-byte quads, 2 bytes per unit entry
     rows_fg = int(rowptr[n // 2])
     fg = np.bincount(col[:rows_fg], weights=val[:rows_fg], minlength=m + 1)
     bg = np.bincount(col[rows_fg:], weights=val[rows_fg:], minlength=m + 1)
