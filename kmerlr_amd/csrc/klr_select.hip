@@ -460,12 +460,14 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     hipStream_t st = ctx->stream;
     u64* keys; u32* hist; Cand* cand;
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
-    // WS_TMP0: [GCAND_CAP compacted candidates | 64 B: FastState (40 B) + caller scalar | K sorted candidates]
-    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + K) * sizeof(Cand) + 64, (void**)&cand));
-    char* stage = (char*)(cand + GCAND_CAP);
-    FastState* fs = (FastState*)stage;
-    double* extra_dst = (double*)(stage + 48);
-    Cand* out = (Cand*)(stage + 64);
+    // WS_TMP0: GCAND_CAP compacted candidates.  The result -- [FastState (40 B) + caller scalar | K sorted candidates],
+    // 3 KB -- is written by k_fast_finish straight into pinned host memory (device-visible, coherent): no copy kernel
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)GCAND_CAP * sizeof(Cand), (void**)&cand));
+    char* pin;
+    KLR_TRY(pin_get(ctx, 64 + (size_t)K * sizeof(Cand), (void**)&pin));
+    FastState* fs = (FastState*)pin;
+    double* extra_dst = (double*)(pin + 48);
+    Cand* out = (Cand*)(pin + 64);
     if (!keys_hist_ready) {
       const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
       hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
@@ -484,10 +486,6 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
                          cand, fs, out, extra_src, extra_dst);
     }
     KLR_HIP(ctx, hipGetLastError());
-    // ONE device->host copy: [state | scalar | K candidates] into pinned memory
-    char* pin;
-    KLR_TRY(pin_get(ctx, 64 + (size_t)K * sizeof(Cand), (void**)&pin));
-    KLR_HIP(ctx, hipMemcpyAsync(pin, stage, 64 + (size_t)K * sizeof(Cand), hipMemcpyDeviceToHost, st));
     KLR_HIP(ctx, hipStreamSynchronize(st));
     FastState hs;
     memcpy(&hs, pin, sizeof(hs));
