@@ -145,9 +145,10 @@ def main():
     # ---- roofline of the dominant kernel (column sweep k_xt_s), per launch ----------------------------
     lay = full.layout()
     if lay["tiled"]:
-        # single pass over the 2-D tiled packed stream: 3 B per unit entry (col:12|row:12; a count c is c entries)
-        # or 4 B per entry (count:8|col:12|row:12), whichever the ingest chose (value_bytes 0 / 1), padding
-        # included; one 32 KiB vector of int64 column sums written per (tile, workgroup) piece,
+        # single pass over the 2-D tiled packed stream: 2 B per unit entry (8-byte quads row:12 | 4 x col:12, a row's
+        # run padded to 4 columns), 3 B (col:12|row:12) or 4 B (count:8|col:12|row:12) per entry, whichever the
+        # ingest chose (value_bytes -1 / 0 / 1), padding included; one 32 KiB vector of int64 column sums written per
+        # (tile, workgroup) piece,
         # s read once (the per-piece s tiles are L2 hits and not counted)
         alg_bytes = (3.0 + lay["value_bytes"]) * lay["padded_entries"] + lay["nseg"] * 4096.0 * 8 + 8.0 * n_local
         kname = "k_sweep_coo"
@@ -169,7 +170,7 @@ def main():
     two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x1.994, calibrated for 12 B/lane loads as MI355X_MICROARCH.md prescribes)" if traffic else None,
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 for 16 B/lane loads per MI355X_MICROARCH.md; Infinity-Cache hits are counted)" if traffic else None,
                 "kernel": kname, "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "survey_two_pass_bytes": two_pass_bytes,
