@@ -553,6 +553,9 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
         // shipped: 32 waves/CU, ping-pong prefetch.  A stream that fits the 256 MiB Infinity Cache together with the
         // piece vectors is read with plain loads and stays resident from one sweep to the next (every leapfrog epoch
         // sweeps the same matrix; measured 45.1 us against 48.7 us at configs[2]); larger ones stream non-temporally.
+        // The prefetch loop runs a uniform, even number of trips per tile with masked lanes: only worth it for long
+        // tiles (a 1M-column shard has ~2.6 trips per tile: 116 us with it, 103 us without).
+        if (mat->total4 < (i64)8192 * mat->nrt * mat->nct) return launch_sweep_coo<1024, 1, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
         if ((size_t)mat->total4 * 16 <= ((size_t)220 << 20)) return launch_sweep_coo<1024, 2, false, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
         return launch_sweep_coo<1024, 2, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
     }
