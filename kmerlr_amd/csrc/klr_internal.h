@@ -56,6 +56,8 @@ struct klr_ctx {
   DevBuf       ws[WS_COUNT];
   // pinned host staging
   void*        pin = nullptr;
+  u64          sel_hint = 0;      // hinted compaction threshold (key) from the last selection, 0 = none
+  i64          sel_hint_K = 0, sel_hint_m = 0;
   size_t       pin_cap = 0;
   // profiling of the column sweep
   bool         prof_on = false;
@@ -181,8 +183,16 @@ int   sweep_all(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const doub
 // their coarse histogram (keys/hist from sel_prepare; may be NULL).
 int   sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double* scale_out, i64** S_out,
                       unsigned long long** acc_out);
+// selection candidates and the control block of the fast path (klr_select.hip)
+struct Cand { u64 key; u32 idx; u32 pad; };
+#define GCAND_CAP 32768
+struct FastCtl { u32 cursor, n, above, pad0; u64 low; u32 pad[10]; };
+// hinted compaction: while the keys are produced, everything at or above `tau` (a little below the K-th key of the
+// previous selection on this context) goes straight into the candidate list -- the selection then needs no pass
+// over the keys at all.  tau = 0: off.
+struct SelHint { u64 tau; Cand* cand; FastCtl* ctl; };
 int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
-                       const unsigned long long* rowblk, i64 nrowblk);
+                       const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint = nullptr);
 int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                           const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
                           const double* theta_host = nullptr, i64 theta_len = 0);
@@ -204,7 +214,8 @@ int   launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out);
 int   select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                          double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
                          int* ok_out, i64* picked_out, bool keys_hist_ready = false,
-                         const double* extra_src = nullptr, double* extra_out = nullptr);
+                         const double* extra_src = nullptr, double* extra_out = nullptr,
+                         u64 hint_tau = 0);
 
 // matrix construction helpers
 int   mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat);   // uses h_colptr/h_collen

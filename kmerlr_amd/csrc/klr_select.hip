@@ -109,7 +109,6 @@ __global__ __launch_bounds__(1024) void k_sel_scan(u32* bgt, u32* beq, i64 nb, S
   if (threadIdx.x == 0) st->n_gt = ca;
 }
 
-struct Cand { u64 key; u32 idx; u32 pad; };
 
 __global__ __launch_bounds__(CMP_BLOCK) void k_sel_compact(const u64* __restrict__ keys, i64 m, const SelState* __restrict__ st,
                                                           const u32* __restrict__ bgt, const u32* __restrict__ beq,
@@ -180,6 +179,7 @@ __global__ __launch_bounds__(256) void k_sel_wmax(const u64* __restrict__ keys, 
 }
 
 static inline double key_to_double(u64 k) { double d; memcpy(&d, &k, 8); return d; }
+static inline u64 abs_key_host(double v) { v = std::fabs(v); u64 k; memcpy(&k, &v, 8); return (v != v) ? 0ull : k; }
 
 // ---------------------------------------------------------------------------------------------------
 // fast path: ONE coarse histogram over the top 13 key bits (exponent + 2 mantissa bits) brackets the
@@ -233,8 +233,6 @@ __device__ __forceinline__ u32 block_suffix_sum_1024(u32 v, u32* wtot /* 16 */) 
 // control block + histograms of the fast path (all zero between calls: k_fast_finish re-zeroes what was used)
 #define FINE_BINS 4096
 #define FINE_SHIFT 38
-#define GCAND_CAP 32768
-struct FastCtl { u32 cursor, n, above, pad0; u64 low; u32 pad[10]; };
 
 // Fast path, first launch (many workgroups).  Every workgroup brackets the K-th largest key in the coarse
 // histogram (top 13 key bits), then compacts its slice of the keys at or above the bracketing bin into a global
@@ -397,6 +395,67 @@ __global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u3
   }
 }
 
+// Hinted selection: the candidate list was filled while the keys were produced (SelHint).  One workgroup sorts it;
+// if the hint was too high (fewer than K candidates) or far too low (more than FAST_CAP) it reports fallback = 2 and
+// leaves the histogram for the regular path.
+__global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ hist, FastCtl* __restrict__ ctl, u64 tau, u32 K, u32 Nth,
+                                                      const Cand* __restrict__ gcand, FastState* st, Cand* __restrict__ out,
+                                                      const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
+  extern __shared__ Cand sc[];                    // FAST_CAP candidates
+  __shared__ unsigned long long wbest;
+  const int t = threadIdx.x;
+  if (t == 0 && extra_src) *extra_dst = *extra_src;
+  const u32 n = ctl->cursor;
+  if (t == 0) wbest = 0ull;
+  __syncthreads();                                 // every lane has read the cursor
+  if (t == 0) ctl->cursor = 0u;
+  if (n < K || n > FAST_CAP) {
+    if (t == 0) { st->lowkey = tau; st->ncand = n; st->cursor = 0; st->fallback = 2; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) hist[t * 8 + i] = 0u;  // the coarse histogram is not needed
+  for (u32 i = t; i < n; i += 1024) sc[i] = gcand[i];
+  __syncthreads();
+  Cand* sorted = sc;
+  if (n <= 1024) {
+    sorted = sc + 1024;
+    if ((u32)t < n) {
+      const Cand my = sc[t];
+      u32 rank = 0;
+      for (u32 j = 0; j < n; j++) rank += cand_before(sc[j], my) ? 1u : 0u;
+      sorted[rank] = my;
+    }
+    __syncthreads();
+  } else {
+    u32 P = 2; while (P < n) P <<= 1;
+    for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
+    __syncthreads();
+    for (u32 size = 2; size <= P; size <<= 1) {
+      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+        for (u32 q = t; q < P / 2; q += 1024) {
+          const u32 lo = 2 * q - (q & (stride - 1));
+          const u32 hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          Cand a = sc[lo], b = sc[hi];
+          const bool swap = up ? cand_before(b, a) : cand_before(a, b);
+          if (swap) { sc[lo] = b; sc[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (u32 i = t; i < K; i += 1024) out[i] = sorted[i];
+  const u64 vkey = (Nth >= 1 && Nth <= n) ? sorted[Nth - 1].key : 0ull;
+  for (u32 i = t; i < n; i += 1024)
+    if (sorted[i].key < vkey && (i == 0 || sorted[i - 1].key >= vkey)) atomicMax(&wbest, (unsigned long long)sorted[i].key | (1ull << 63));
+  __syncthreads();
+  if (t == 0) {
+    st->lowkey = tau; st->ncand = n; st->cursor = n; st->fallback = 0;
+    st->vkey = vkey; st->wfound = (wbest >> 63) ? 1u : 0u; st->wkey = wbest & ~(1ull << 63);
+  }
+}
+
 static int select_exact_device(klr_ctx* ctx, const double* g_dev, u64* keys, bool keys_ready, i64 m, i64 K, i64 N,
                                std::vector<Cand>& hc, u64* vkey, u64* wkey) {
   hipStream_t st = ctx->stream;
@@ -450,7 +509,8 @@ int sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist) {
 
 int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                        double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
-                       int* ok_out, i64* picked_out, bool keys_hist_ready, const double* extra_src, double* extra_out) {
+                       int* ok_out, i64* picked_out, bool keys_hist_ready, const double* extra_src, double* extra_out,
+                       u64 hint_tau) {
   KLR_ARG(ctx, m >= 0 && N >= 0 && b != nullptr);
   if (extra_out) *extra_out = NAN;
   const i64 K = std::min<i64>(m, 2 * N);             // NLargestAbsFloat64(g_, 2N)
@@ -476,26 +536,43 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     if (!attr) {
       KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(FAST_CAP * sizeof(Cand))));
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_direct, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(FAST_CAP * sizeof(Cand))));
       attr = true;
     }
-    {
+    bool direct_ok = false;
+    if (hint_tau != 0 && keys_hist_ready) {
+      // the candidates are already in `cand` (SelHint): one sort kernel, no pass over the keys
+      FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+      hipLaunchKernelGGL(k_fast_direct, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, ctl, hint_tau, (u32)K, (u32)N, cand, fs, out,
+                         extra_src, extra_dst);
+      KLR_HIP(ctx, hipGetLastError());
+      KLR_HIP(ctx, hipStreamSynchronize(st));
+      direct_ok = fs->fallback != 2;
+    }
+    if (!direct_ok) {
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
       const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 256));
       hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m, (u32)K, cand);
       hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K, (u32)N,
                          cand, fs, out, extra_src, extra_dst);
+      KLR_HIP(ctx, hipGetLastError());
+      KLR_HIP(ctx, hipStreamSynchronize(st));
     }
-    KLR_HIP(ctx, hipGetLastError());
-    KLR_HIP(ctx, hipStreamSynchronize(st));
     FastState hs;
     memcpy(&hs, pin, sizeof(hs));
     if (extra_out) memcpy(extra_out, pin + 48, sizeof(double));
     memcpy(hc.data(), pin + 64, (size_t)K * sizeof(Cand));
     vkey = hs.vkey; wkey = hs.wkey;
     const bool need_w = !(N > K) && N >= 1;
+    ctx->sel_hint = 0;
     if (hs.fallback || (need_w && !hs.wfound)) {
       // exact 8-pass radix select (keys are already on the device)
       KLR_TRY(select_exact_device(ctx, g_dev, keys, true, m, K, N, hc, &vkey, &wkey));
+    } else if (hc[(size_t)K - 1].key != 0ull) {
+      // next time: compact everything above 0.9 x this call's K-th |g| while the keys are produced
+      ctx->sel_hint = abs_key_host(0.9 * key_to_double(hc[(size_t)K - 1].key));
+      ctx->sel_hint_K = K; ctx->sel_hint_m = m;
     }
   }
   if (K == 0 && extra_src && extra_out) KLR_TRY(d2h_sync(ctx, extra_out, extra_src, sizeof(double)));
@@ -588,18 +665,26 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     if (!theta_inline) KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
   }
   bool keys_ready = false;
+  u64 hint_tau = 0;
   if (full->tiled) {
     // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
     // all-reduce of [g | bias | loss]; conversion to f64 emits the selection keys + histogram
     double scale_fx; i64* S; unsigned long long* acc; u64* keys; u32* hist;
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
+    SelHint hint{0ull, nullptr, nullptr};
+    if (ctx->sel_hint != 0 && ctx->sel_hint_K == std::min<i64>(m, 2 * N) && ctx->sel_hint_m == m && !(scale || offset)) {
+      KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)GCAND_CAP * sizeof(Cand), (void**)&hint.cand));
+      hint.tau = ctx->sel_hint;
+      hint.ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+      hint_tau = hint.tau;
+    }
     KLR_TRY(sweep_fix_begin(ctx, full, cw, &scale_fx, &S, &acc));
     unsigned long long* rowblk; i64 nrowblk;
     (void)acc;
     KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale_fx, S,
                                 &rowblk, &nrowblk, theta_inline ? theta_red : nullptr, theta_inline ? c_plus_1 : 0));
     const bool tr = scale != nullptr || offset != nullptr;
-    KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk));
+    KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk, hint.tau ? &hint : nullptr));
     keys_ready = m > 0 && !tr;
   } else {
     // the row pass leaves the local loss partial in gbuf[dim]; [g | loss] in ONE f64 all-reduce
@@ -612,7 +697,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
 
   double loss_sum = NAN;
   KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready,
-                             gbuf + dim, &loss_sum));
+                             gbuf + dim, &loss_sum, hint_tau));
   KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out copy (select may not have synchronised)
   if (loss_out) *loss_out = full->n_total ? loss_sum / (double)full->n_total : 0.0;
   return KLR_OK;

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
                                                      const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
                                                      const i64* __restrict__ rowblk, i64 nrowblk, u32 CT,
                                                      double inv_scale, double* __restrict__ g, u64* __restrict__ keys,
-                                                     u32* __restrict__ hist) {
+                                                     u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
   __shared__ i64 sh[4][256];
   __shared__ u32 shh[FUSE ? FAST_BINS : 1];
   if (blockIdx.x == gridDim.x - 1) {
@@ -668,6 +668,10 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
         const u64 kk = abs_key(gv);
         keys[j - 1] = kk;
         atomicAdd(&shh[(u32)(kk >> FAST_SHIFT)], 1u);
+        if (tau != 0ull && kk >= tau) {                       // hinted compaction (SelHint)
+          const u32 pos = atomicAdd(cursor, 1u);
+          if (pos < GCAND_CAP) { cand[pos].key = kk; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
+        }
       }
     } else ibuf[j] = sum;
   }
@@ -717,7 +721,8 @@ __global__ __launch_bounds__(256) void k_fix_s(const double* __restrict__ s, con
 }
 
 __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, i64 dim, double inv_scale,
-                                                  double* __restrict__ g, u64* __restrict__ keys, u32* __restrict__ hist) {
+                                                  double* __restrict__ g, u64* __restrict__ keys, u32* __restrict__ hist,
+                                                  u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
   // grid-stride; the coarse key histogram is privatised in LDS (most keys share a few bins)
   __shared__ u32 sh[FAST_BINS];
   if (keys) {
@@ -734,6 +739,10 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
         const u64 k = abs_key(v);
         keys[j - 1] = k;
         atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+        if (tau != 0ull && k >= tau) {                          // hinted compaction (SelHint)
+          const u32 pos = atomicAdd(cursor, 1u);
+          if (pos < GCAND_CAP) { cand[pos].key = k; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
+        }
       }
     } else {
       // loss sum = (limb0 + limb1 * 2^-42) * 2^-20; NaN if any term was not finite
@@ -788,7 +797,10 @@ int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double
 
 // integer sweep over the packed stream, int64 all-reduce of [column sums | bias | loss], back to f64
 int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
-                     const unsigned long long* rowblk, i64 nrowblk) {
+                     const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint) {
+  const u64 tau = hint && keys ? hint->tau : 0ull;
+  Cand* hcand = hint ? hint->cand : nullptr;
+  u32* hcur = hint ? &hint->ctl->cursor : nullptr;
   const i64 n = mat->n, dim = mat->dim;
   hipStream_t st = ctx->stream;
   i64 *S, *part, *ibuf;
@@ -806,14 +818,14 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   if (!ctx->ar_fn) {
     // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
     hipLaunchKernelGGL(k_finish_coo<true>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist);
+                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
   } else {
     hipLaunchKernelGGL(k_finish_coo<false>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist);
+                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr);
     KLR_HIP(ctx, hipGetLastError());
     KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
     hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,
-                       keys, hist);
+                       keys, hist, tau, hcand, hcur);
   }
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;

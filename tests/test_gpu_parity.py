@@ -497,3 +497,35 @@ def test_cooccurrence_inherits_row_mask(ctx):
         # the masked gradient equals the gradient of the kept rows: compare through a re-upload of those rows
         d = xe.to_dense()[keep]
         assert_g_close(g, O.gradient(O.Csr.from_dense(d[:, 1:]), labels[keep], theta))
+
+
+def test_hinted_selection_sequence_matches_oracle(ctx, synth_tiled):
+    """Consecutive sweeps on one context reuse the previous K-th |g| as a compaction hint (SelHint): the selection
+    must stay exact when the hint fits, when the gradient collapses under it (too few candidates -> regular path),
+    when it is far too low, and when N changes."""
+    x, labels = synth_tiled
+    m = upload(ctx, x, labels)
+    cw = O.class_weights(labels)
+    rng = np.random.default_rng(11)
+    thetas = []
+    t = np.zeros(x.dim); t[0] = -0.1; thetas.append((t.copy(), 20))
+    t[1 + rng.choice(x.dim - 1, size=30, replace=False)] = rng.normal(size=30) * 0.05; thetas.append((t.copy(), 20))
+    thetas.append((t.copy(), 20))                                   # identical sweep: hint fits exactly
+    big = t.copy(); big[0] = 30.0; thetas.append((big, 20))          # saturated sigmoid: gradients collapse, hint too high
+    thetas.append((t.copy(), 20))                                   # back up: the tiny hint now admits nearly everything
+    thetas.append((t.copy(), 7)); thetas.append((t.copy(), 300))     # N changes: hint off, then re-armed
+    for th, N in thetas:
+        idx = np.nonzero(th)[0]
+        red = m.select_columns(idx if idx[0] == 0 else np.r_[0, idx])
+        cols = idx if idx[0] == 0 else np.r_[0, idx]
+        r = K.sweep_select(ctx, m, red, cols, th[cols], cw, N, want_g=True)
+        g = O.gradient(x, labels, th, cw=cw)
+        assert_g_close(r["g"], g)
+        b = np.zeros(x.dim, dtype=np.uint8); b[0] = 1
+        b[cols[1:][th[cols[1:]] != 0.0]] = 1
+        c_prev = int(b.sum()) - 1
+        # selection on OUR gradient (bitwise what the device saw) through the oracle's rule
+        ok, lam, c, b2 = O.select(r["g"][1:], b, c_prev, N)
+        assert (r["ok"], r["c"]) == (ok, c)
+        assert r["lam"] == lam
+        np.testing.assert_array_equal(r["b"], b2)
