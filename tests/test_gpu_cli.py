@@ -223,3 +223,34 @@ def test_ensemble_cli(tmp_path):
     out = run(["--type=scoresLr", "loss", "ens.json", fg, bg], tmp_path).stdout
     ref = np.mean([O.loss(red, labels, d["Parameters"]) for d in lr])
     assert abs(float(out) - ref) < 1e-6 * ref
+
+
+def test_kmers6_cooccurrence_fasta_cli(tmp_path):
+    # TestKmers6 (kmerLr_test.go:192-268): learn --lambda-auto=2 --binarize --revcomp --co-occurrence 2 6 on the co_*.fa
+    # files.  Every fg sequence carries both motifs, every bg sequence one of them twice: no single k-mer separates
+    # the classes, pairs of k-mers do.  Which of the many tied pairs is taken is the sort's tie rule (unpinned, the
+    # reference's sort is unstable); pinned here: two pair features, each present in every fg and no bg sequence, and
+    # the reference's predictions log sigma(+-0.1) for its theta (-0.1, 0.1, 0.1) through OUR predict command.
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_co_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_co_bg.fa")
+    run(["learn", "--lambda-auto=2", "--epsilon-loss=1e-8", "--binarize", "--revcomp", "--co-occurrence", "2", "6", fg, bg, "co"], tmp_path)
+    m = json.load(open(tmp_path / "co.json"))
+    assert m["Parameters"]["Cooccurrence"] is True
+    feats = m["Parameters"]["Features"]
+    assert len(feats) == 2 and all(a != b for a, b in feats)                # two pairs (kmerLr_test.go:204-205)
+    theta = m["Distributions"][0]["Parameters"]
+    assert len(theta) == 3 and theta[1] > 0 and theta[2] > 0
+    pf = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "co.json", fg], tmp_path).stdout.split()[1:]]
+    pb = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "co.json", bg], tmp_path).stdout.split()[1:]]
+    assert len(pf) == 10 and len(pb) == 10
+    # both pair features are present in every fg row and in no bg row: two prediction levels, theta0 + theta1 + theta2 / theta0
+    np.testing.assert_allclose(pf, [-np.log1p(np.exp(-(theta[0] + theta[1] + theta[2])))] * 10, rtol=1e-6)
+    np.testing.assert_allclose(pb, [-np.log1p(np.exp(-theta[0]))] * 10, rtol=1e-6)
+    # the reference's theta through our predict: its goldens (:226-262)
+    m["Distributions"][0]["Parameters"] = [-0.1000970529629098, 0.09995715710821684, 0.09995715710821684]
+    json.dump(m, open(tmp_path / "ref.json", "w"))
+    pf = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "ref.json", fg], tmp_path).stdout.split()[1:]]
+    pb = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "ref.json", bg], tmp_path).stdout.split()[1:]]
+    np.testing.assert_allclose(pf, [-0.6444834689451768] * 10, atol=1e-6)
+    np.testing.assert_allclose(pb, [-0.744447612033651] * 10, atol=1e-6)
+    out = run(["loss", "--m=2", "--n=6", "--binarize", "--revcomp", "ref.json", fg, bg], tmp_path).stdout
+    assert abs(float(out) - 0.644417014007959) < 1e-4                       # :223 (the reference's tolerance)
