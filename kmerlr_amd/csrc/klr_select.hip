@@ -230,6 +230,28 @@ __device__ __forceinline__ u32 block_suffix_sum_1024(u32 v, u32* wtot /* 16 */) 
   return x + add;
 }
 
+// rank sort of n <= 1024 candidates in LDS by (|g| desc, column asc): (key, column) pairs are distinct, so the ranks
+// are a permutation.  The comparisons of an element are split over 1024/n' lanes (n' = n rounded up to a power of
+// two), partial ranks meet in LDS.  src, dst, rk: LDS.  Ends with a barrier.
+__device__ __forceinline__ void rank_sort_1024(const Cand* src, Cand* dst, u32* rk, u32 n) {
+  const u32 t = threadIdx.x;
+  u32 np = 64; while (np < n) np <<= 1;            // 64..1024
+  const u32 parts = 1024u / np;                    // 16..1
+  const u32 e = t & (np - 1), part = t / np;
+  if (t < np) rk[t] = 0u;
+  __syncthreads();
+  if (e < n) {
+    const Cand my = src[e];
+    const u32 j0 = (u32)((unsigned long long)n * part / parts), j1 = (u32)((unsigned long long)n * (part + 1) / parts);
+    u32 r = 0;
+    for (u32 j = j0; j < j1; j++) r += cand_before(src[j], my) ? 1u : 0u;
+    if (parts == 1) rk[e] = r; else if (r) atomicAdd(&rk[e], r);
+  }
+  __syncthreads();
+  if (t < n) dst[rk[t]] = src[t];
+  __syncthreads();
+}
+
 // control block + histograms of the fast path (all zero between calls: k_fast_finish re-zeroes what was used)
 #define FINE_BINS 4096
 #define FINE_SHIFT 38
@@ -357,15 +379,8 @@ __global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u3
   __syncthreads();
   Cand* sorted = sc;
   if (nt <= 1024) {
-    // rank sort: (key, column) pairs are distinct, so the ranks are a permutation
     sorted = sc + 1024;
-    if ((u32)t < nt) {
-      const Cand my = sc[t];
-      u32 rank = 0;
-      for (u32 j = 0; j < nt; j++) rank += cand_before(sc[j], my) ? 1u : 0u;
-      sorted[rank] = my;
-    }
-    __syncthreads();
+    rank_sort_1024(sc, sorted, ssum, nt);
   } else {
     u32 P = 2; while (P < nt) P <<= 1;
     for (u32 i = nt + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
@@ -403,6 +418,7 @@ __global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ hist, Fa
                                                       const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
   extern __shared__ Cand sc[];                    // FAST_CAP candidates
   __shared__ unsigned long long wbest;
+  __shared__ u32 srk[1024];
   const int t = threadIdx.x;
   if (t == 0 && extra_src) *extra_dst = *extra_src;
   const u32 n = ctl->cursor;
@@ -420,13 +436,7 @@ __global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ hist, Fa
   Cand* sorted = sc;
   if (n <= 1024) {
     sorted = sc + 1024;
-    if ((u32)t < n) {
-      const Cand my = sc[t];
-      u32 rank = 0;
-      for (u32 j = 0; j < n; j++) rank += cand_before(sc[j], my) ? 1u : 0u;
-      sorted[rank] = my;
-    }
-    __syncthreads();
+    rank_sort_1024(sc, sorted, srk, n);
   } else {
     u32 P = 2; while (P < n) P <<= 1;
     for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
