@@ -529,3 +529,39 @@ def test_hinted_selection_sequence_matches_oracle(ctx, synth_tiled):
         assert (r["ok"], r["c"]) == (ok, c)
         assert r["lam"] == lam
         np.testing.assert_array_equal(r["b"], b2)
+
+
+def test_tiled_ragged_rows_and_empty_tiles(ctx, entry_format):
+    """Tiled stream corner cases: bias-only rows, a column present in every row, whole column tiles without entries,
+    counts that need several quads / split entries, a last row tile with a handful of rows."""
+    rng = np.random.default_rng(21)
+    n, m = 8200, 9000                                   # three column tiles, many row tiles, ragged last one
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        if i % 17 == 0:
+            k = np.array([], dtype=np.int64)            # bias-only row
+        else:
+            k = np.unique(rng.integers(1, 3000, size=int(rng.integers(1, 400))))      # only the first column tile is used...
+            if i % 5 == 0:
+                k = np.unique(np.r_[k, 8999])           # ...except one far column; tile 2 stays empty
+            k = np.unique(np.r_[k, 7])                  # column 7 in every non-empty row
+        v = rng.integers(1, 4, size=len(k)).astype(np.float64)
+        if len(k) and i % 11 == 0:
+            v[0] = 300.0                                # a count above 255
+        rows.append(len(k)); cols.append(k); vals.append(v)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    col = []; val = []
+    for i in range(n):
+        col.append(np.r_[0, cols[i]]); val.append(np.r_[1.0, vals[i]])
+        rowptr[i + 1] = rowptr[i] + 1 + rows[i]
+    x = O.Csr(n, m + 1, rowptr, np.concatenate(col).astype(np.int64), np.concatenate(val))
+    assert x.nnz >= (1 << 20)
+    labels = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+    mat = upload(ctx, x, labels)
+    assert mat.layout()["tiled"]
+    theta = np.zeros(x.dim); theta[0] = 0.3; theta[7] = -0.02; theta[8999] = 0.5
+    assert_g_close(K.gradient_dense(ctx, mat, theta), O.gradient(x, labels, theta))
+    r = K.sweep_select(ctx, mat, None, None, np.zeros(1), (1.0, 1.0), 5, want_g=True)
+    assert_g_close(r["g"], O.gradient(x, labels, np.zeros(x.dim)))
+    rp, cc, vv = mat.to_csr()
+    np.testing.assert_array_equal(rp, x.rowptr); np.testing.assert_array_equal(cc, x.col); np.testing.assert_array_equal(vv, x.val)
