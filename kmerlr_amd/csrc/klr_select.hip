@@ -198,6 +198,15 @@ struct FastState {
   u64 vkey, wkey;
 };
 
+__global__ __launch_bounds__(256) void k_hist_from_keys(const u64* __restrict__ keys, i64 m, u32* __restrict__ hist) {
+  __shared__ u32 sh[FAST_BINS];
+  for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (i64 j = (i64)blockIdx.x * 256 + threadIdx.x; j < m; j += (i64)gridDim.x * 256) atomicAdd(&sh[(u32)(keys[j] >> FAST_SHIFT)], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
 __global__ __launch_bounds__(256) void k_fast_keys_hist(const double* __restrict__ g, i64 m, u64* __restrict__ keys,
                                                         u32* __restrict__ hist) {
   __shared__ u32 sh[FAST_BINS];
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u3
 // Hinted selection: the candidate list was filled while the keys were produced (SelHint).  One workgroup sorts it;
 // if the hint was too high (fewer than K candidates) or far too low (more than FAST_CAP) it reports fallback = 2 and
 // leaves the histogram for the regular path.
-__global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ hist, FastCtl* __restrict__ ctl, u64 tau, u32 K, u32 Nth,
+__global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ /*hist: untouched (not built when hinted)*/, FastCtl* __restrict__ ctl, u64 tau, u32 K, u32 Nth,
                                                       const Cand* __restrict__ gcand, FastState* st, Cand* __restrict__ out,
                                                       const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
   extern __shared__ Cand sc[];                    // FAST_CAP candidates
@@ -429,8 +438,6 @@ __global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ hist, Fa
     if (t == 0) { st->lowkey = tau; st->ncand = n; st->cursor = 0; st->fallback = 2; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < 8; i++) hist[t * 8 + i] = 0u;  // the coarse histogram is not needed
   for (u32 i = t; i < n; i += 1024) sc[i] = gcand[i];
   __syncthreads();
   Cand* sorted = sc;
@@ -562,6 +569,10 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     }
     if (!direct_ok) {
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+      if (hint_tau != 0 && keys_hist_ready) {        // the hinted sweep did not build the coarse histogram
+        const unsigned hgrid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
+        hipLaunchKernelGGL(k_hist_from_keys, dim3(hgrid), dim3(256), 0, st, keys, m, hist);
+      }
       const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 256));
       hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m, (u32)K, cand);
       hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K, (u32)N,

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
   }
   const int cx = threadIdx.x & 255, ly = threadIdx.x >> 8;
   const i64 j = (i64)blockIdx.x * 256 + cx;
-  if (FUSE && keys) { for (int i = threadIdx.x; i < FAST_BINS; i += 1024) shh[i] = 0u; }
+  if (FUSE && hist) { for (int i = threadIdx.x; i < FAST_BINS; i += 1024) shh[i] = 0u; }
   i64 v = 0;
   if (j < dim) {
     const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
       if (keys) {
         const u64 kk = abs_key(gv);
         keys[j - 1] = kk;
-        atomicAdd(&shh[(u32)(kk >> FAST_SHIFT)], 1u);
+        if (hist) atomicAdd(&shh[(u32)(kk >> FAST_SHIFT)], 1u);
         if (tau != 0ull && kk >= tau) {                       // hinted compaction (SelHint)
           const u32 pos = atomicAdd(cursor, 1u);
           if (pos < GCAND_CAP) { cand[pos].key = kk; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
       }
     } else ibuf[j] = sum;
   }
-  if (FUSE && keys) {
+  if (FUSE && hist) {
     __syncthreads();
     for (int i = threadIdx.x; i < FAST_BINS; i += 1024) if (shh[i]) atomicAdd(&hist[i], shh[i]);
   }
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
                                                   u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
   // grid-stride; the coarse key histogram is privatised in LDS (most keys share a few bins)
   __shared__ u32 sh[FAST_BINS];
-  if (keys) {
+  if (hist) {
     for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
     __syncthreads();
   }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
       if (keys) {                                             // selection key of feature j-1
         const u64 k = abs_key(v);
         keys[j - 1] = k;
-        atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+        if (hist) atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
         if (tau != 0ull && k >= tau) {                          // hinted compaction (SelHint)
           const u32 pos = atomicAdd(cursor, 1u);
           if (pos < GCAND_CAP) { cand[pos].key = k; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
       g[dim] = ibuf[dim + 4] ? nan("") : l;
     }
   }
-  if (keys) {
+  if (hist) {
     __syncthreads();
     for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
   }
@@ -799,6 +799,7 @@ int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double
 int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
                      const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint) {
   const u64 tau = hint && keys ? hint->tau : 0ull;
+  if (tau) hist = nullptr;                       // hinted: the coarse histogram is only built if the hint fails (select_from_device)
   Cand* hcand = hint ? hint->cand : nullptr;
   u32* hcur = hint ? &hint->ctl->cursor : nullptr;
   const i64 n = mat->n, dim = mat->dim;
