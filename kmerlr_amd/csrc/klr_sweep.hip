@@ -96,8 +96,23 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
       const VT* val = (const VT*)a.val;
       // LinearPdf (:47-68): r = theta[0] + sum_{j>=1} v_j theta[i_j]; entry 0 is the bias
       double acc = 0.0;
-      if (inl) { for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * sth[a.col[p]]; }
-      else     { for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * a.theta[a.col[p]]; }
+      if (inl) {
+        // four entries per lane and trip, their loads in flight together (the adds keep their order: same result)
+        for (i64 p = b + 1 + lane; p < e; p += 4 * G) {
+          u32 c[4]; double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const i64 pp = p + (i64)u * G;
+            const bool ok = pp < e;
+            c[u] = ok ? a.col[pp] : 0u;
+            v[u] = ok ? (double)val[pp] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (p + (i64)u * G < e) acc += v[u] * sth[c[u]];
+        }
+      } else {
+        for (i64 p = b + 1 + lane; p < e; p += G) acc += (double)val[p] * a.theta[a.col[p]];
+      }
       acc = group_sum<G>(acc);
       r = (inl ? sth[0] : a.theta[0]) + acc;
     }
