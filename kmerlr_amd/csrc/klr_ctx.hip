@@ -5,6 +5,8 @@
 #include <dlfcn.h>
 
 #include <cstdarg>
+#include <mutex>
+#include <set>
 
 thread_local std::string g_klr_err;
 
@@ -24,6 +26,8 @@ extern "C" const char* klr_version(void) { return "kmerlr-hip 0.1 (gfx950)"; }
 extern "C" const char* klr_last_error(const klr_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_klr_err.c_str();
 }
+
+static void ctx_register(const klr_ctx* ctx);
 
 extern "C" int klr_ctx_create(int device_id, klr_ctx** out) {
   if (!out) return klr_fail(nullptr, KLR_EINVAL, "klr_ctx_create: out is NULL");
@@ -50,6 +54,7 @@ extern "C" int klr_ctx_create(int device_id, klr_ctx** out) {
     return klr_fail(nullptr, KLR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
   }
   ctx->own_stream = true;
+  ctx_register(ctx);
   *out = ctx;
   return KLR_OK;
 }
@@ -141,10 +146,71 @@ int klr_allreduce(klr_ctx* ctx, void* dev, i64 count, int dtype) {
   return KLR_OK;
 }
 
+// ---- live contexts: a matrix released after its context went away frees its block itself ------------------
+static std::mutex g_live_mu;
+static std::set<const klr_ctx*> g_live;
+bool ctx_alive(const klr_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return g_live.count(ctx) != 0;
+}
+static void ctx_register(const klr_ctx* ctx) { std::lock_guard<std::mutex> lk(g_live_mu); g_live.insert(ctx); }
+static void ctx_unregister(const klr_ctx* ctx) { std::lock_guard<std::mutex> lk(g_live_mu); g_live.erase(ctx); }
+
+// ---- pooled blocks of reduced matrices.  Everything that touches a block runs on ctx->stream, so a block put
+// back by the host while kernels on it are still queued is safe to hand to the next sub-select (stream order);
+// hipFree (eviction) synchronises by itself.
+#define POOL_MAX 4
+int pool_get(klr_ctx* ctx, size_t bytes, void** p, size_t* cap) {
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool.size(); i++)
+    if (ctx->pool[i].second >= bytes && (best < 0 || ctx->pool[i].second < ctx->pool[best].second)) best = i;
+  if (best >= 0) {
+    *p = ctx->pool[best].first; *cap = ctx->pool[best].second;
+    ctx->pool.erase(ctx->pool.begin() + best);
+    return KLR_OK;
+  }
+  // head room: the next epoch's selection is a little larger or smaller than this one
+  const size_t want = bytes + bytes / 2 + (1u << 16);
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(p, bytes); if (e == hipSuccess) { *cap = bytes; return KLR_OK; } }
+  if (e != hipSuccess) return klr_fail(ctx, KLR_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  *cap = want;
+  return KLR_OK;
+}
+void pool_put(klr_ctx* ctx, void* p, size_t cap) {
+  if (!p) return;
+  ctx->pool.emplace_back(p, cap);
+  if ((int)ctx->pool.size() > POOL_MAX) {                         // drop the smallest
+    int worst = 0;
+    for (int i = 1; i < (int)ctx->pool.size(); i++) if (ctx->pool[i].second < ctx->pool[worst].second) worst = i;
+    (void)hipFree(ctx->pool[worst].first);
+    ctx->pool.erase(ctx->pool.begin() + worst);
+  }
+}
+
+int stage_get(klr_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx->stage_ev) KLR_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming));
+  else KLR_HIP(ctx, hipEventSynchronize(ctx->stage_ev));
+  if (ctx->stage_cap < bytes) {
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    ctx->stage = nullptr; ctx->stage_cap = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    hipError_t e = hipHostMalloc(&ctx->stage, want, hipHostMallocDefault);
+    if (e != hipSuccess) return klr_fail(ctx, KLR_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    ctx->stage_cap = want;
+  }
+  *out = ctx->stage;
+  return KLR_OK;
+}
+
 extern "C" void klr_ctx_destroy(klr_ctx* ctx) {
   if (!ctx) return;
+  ctx_unregister(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->pool) (void)hipFree(b.first);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
+  if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   for (auto& pr : ctx->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (int i = 0; i < WS_COUNT; i++) if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);

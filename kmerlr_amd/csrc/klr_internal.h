@@ -64,7 +64,19 @@ struct klr_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   int          n_cu = 256;
   void*        sel_hist_zeroed = nullptr;   // selection histogram known to be all zero
+  // device blocks of released reduced matrices (one block per matrix), reused in stream order by the next
+  // column sub-select: a leapfrog epoch allocates nothing
+  std::vector<std::pair<void*, size_t>> pool;
+  // pinned staging of the small host tables of a column sub-select, one async copy; stage_ev = last copy out of it
+  void*        stage = nullptr;
+  size_t       stage_cap = 0;
+  hipEvent_t   stage_ev = nullptr;
 };
+
+bool ctx_alive(const klr_ctx* ctx);                              // false once klr_ctx_destroy ran
+int  pool_get(klr_ctx* ctx, size_t bytes, void** p, size_t* cap);
+void pool_put(klr_ctx* ctx, void* p, size_t cap);
+int  stage_get(klr_ctx* ctx, size_t bytes, void** out);          // waits for the previous copy out of the buffer
 
 struct klr_mat {
   klr_ctx* ctx = nullptr;
@@ -89,6 +101,11 @@ struct klr_mat {
   int  group = 64;               // lanes per chunk
   uint8_t* labels = nullptr;     // n
   uint8_t* active = nullptr;     // n row mask (nullable): rows that take part in sums over samples
+  // reduced matrices: every device array above is a slice of ONE pooled block (arena); active_slot = the n bytes
+  // reserved for a row mask
+  void*    arena = nullptr;
+  size_t   arena_cap = 0;
+  uint8_t* active_slot = nullptr;
   i64  n_total_all = 0;          // n_total without a mask
   i64  n_active_local = 0;       // active local rows (valid when active != nullptr)
   std::vector<uint8_t> h_labels; // host copy (class counts under a mask)

@@ -23,6 +23,13 @@ void mat_free(klr_mat* m) {
   if (!m) return;
   // the owning ctx may already be gone: use the recorded device, wait for everything on it
   (void)hipSetDevice(m->device);
+  if (m->arena) {
+    // a reduced matrix: one pooled block; the context hands it to the next column sub-select in stream order
+    if (ctx_alive(m->ctx)) pool_put(m->ctx, m->arena, m->arena_cap);
+    else { (void)hipDeviceSynchronize(); (void)hipFree(m->arena); }
+    delete m;
+    return;
+  }
   (void)hipDeviceSynchronize();
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
                 m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->active, m->t_ent, m->t_piece, m->t_wgpiece,
@@ -551,7 +558,8 @@ extern "C" int klr_mat_set_active_rows(klr_ctx* ctx, klr_mat* mat, const uint8_t
   KLR_HIP(ctx, hipSetDevice(ctx->device));
   KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (!mask) {
-    if (mat->active) { (void)hipFree(mat->active); mat->active = nullptr; }
+    if (mat->active && !mat->arena) (void)hipFree(mat->active);
+    mat->active = nullptr;
     mat->n_total = mat->n_total_all;
     mat->n1_local = 0;
     for (uint8_t l : mat->h_labels) if (l) mat->n1_local++;
@@ -559,7 +567,10 @@ extern "C" int klr_mat_set_active_rows(klr_ctx* ctx, klr_mat* mat, const uint8_t
     return KLR_OK;
   }
   KLR_ARG(ctx, n_active_total > 0);
-  if (!mat->active) KLR_TRY(dev_alloc(ctx, (void**)&mat->active, (size_t)std::max<i64>(mat->n, 1)));
+  if (!mat->active) {
+    if (mat->arena) mat->active = mat->active_slot;
+    else KLR_TRY(dev_alloc(ctx, (void**)&mat->active, (size_t)std::max<i64>(mat->n, 1)));
+  }
   KLR_HIP(ctx, hipMemcpy(mat->active, mask, (size_t)mat->n, hipMemcpyHostToDevice));
   i64 na = 0, n1 = 0;
   for (i64 i = 0; i < mat->n; i++) if (mask[i]) { na++; if (mat->h_labels[(size_t)i]) n1++; }
@@ -683,23 +694,83 @@ int launch_exscan_u32(klr_ctx* ctx, const u32* in, i64 n, i64* out) {
 // column sub-select: featureSelection.Data (kmerLr_feature_selection.go:309-343) + Transform.Apply
 // (kmerLr_transform.go:584-629), built from the CSC side so only the selected columns are read.
 // =================================================================================================
-template <typename VT>
-__global__ __launch_bounds__(256) void k_gather_cols(const i64* __restrict__ src_colptr, const u32* __restrict__ src_len,
-                                                     const u32* __restrict__ crow, const VT* __restrict__ cval,
-                                                     const i64* __restrict__ sel, const i64* __restrict__ dst_colptr,
-                                                     const double* __restrict__ scale, u32* __restrict__ rcrow,
-                                                     double* __restrict__ rcval) {
-  // one block per selected column; the source column holds no explicit zeros
-  const int p = blockIdx.x;
-  const i64 j = sel[p];
-  const i64 sb = src_colptr[j];
-  const i64 len = src_len[p];
-  const i64 db = dst_colptr[p], de = dst_colptr[p + 1];
-  const double sc = scale ? scale[p] : 1.0;
-  for (i64 e = threadIdx.x; e < de - db; e += 256) {
-    if (e < len) { rcrow[db + e] = crow[sb + e]; rcval[db + e] = (double)cval[sb + e] * sc; }
-    else         { rcrow[db + e] = 0u;           rcval[db + e] = 0.0; }
-  }
+// Flat over the padded entries of the reduced CSC (one thread per entry, its column by binary search in the
+// LDS copy of the column offsets): a block per column left the bias column (n entries) to one block -- 0.9 ms of
+// a 1 ms sub-select at configs[2].  RED_MASK_WORDS_MAX*64 selected columns or fewer: every row keeps a bit mask of
+// the selected columns it holds (atomicOr: order free), from which both the row lengths and the position of an
+// entry inside its row (= the set bits below its column) follow -- rows come out sorted by column without a sort
+// and without a cursor.
+#define RED_MASK_WORDS_MAX 16
+#define RED_LDS_COLS 4096
+
+__device__ __forceinline__ int red_find_col(const i64* __restrict__ cp, int c1, i64 e) {
+  int lo = 0, hi = c1;                                  // largest p with cp[p] <= e
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cp[mid] <= e) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// GATHER: copy (and scale) the source column entries; else the reduced CSC is already filled (explicit-zero path)
+// and only the row marks are made.  mask != null: bit p of row r; else cnt[r]++.
+template <typename VT, bool GATHER>
+__global__ __launch_bounds__(256) void k_red_gather(const i64* __restrict__ src_colptr, const u32* __restrict__ crow,
+                                                    const VT* __restrict__ cval, const i64* __restrict__ sel,
+                                                    const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len, int c1,
+                                                    const double* __restrict__ scale, u32* __restrict__ rcrow,
+                                                    double* __restrict__ rcval, unsigned long long* __restrict__ mask, int W,
+                                                    u32* __restrict__ cnt) {
+  extern __shared__ i64 red_cp[];
+  const bool in_lds = c1 + 1 <= RED_LDS_COLS;
+  if (in_lds) { for (int t = threadIdx.x; t <= c1; t += 256) red_cp[t] = dst_colptr[t]; __syncthreads(); }
+  const i64* cp = in_lds ? red_cp : dst_colptr;
+  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (e >= cp[c1]) return;
+  const int p = red_find_col(cp, c1, e);
+  const i64 off = e - cp[p];
+  u32 r = 0;
+  if (off < (i64)dst_len[p]) {
+    if (GATHER) {
+      const i64 sb = src_colptr[sel[p]];
+      r = crow[sb + off];
+      rcrow[e] = r; rcval[e] = (double)cval[sb + off] * (scale ? scale[p] : 1.0);
+    } else r = rcrow[e];
+    if (mask) atomicOr(&mask[(i64)r * W + (p >> 6)], 1ull << (p & 63));
+    else atomicAdd(&cnt[r], 1u);
+  } else if (GATHER) { rcrow[e] = 0u; rcval[e] = 0.0; }
+}
+
+__global__ __launch_bounds__(256) void k_red_count(const unsigned long long* __restrict__ mask, int W, i64 n, u32* __restrict__ cnt) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u32 c = 0;
+  for (int w = 0; w < W; w++) c += (u32)__popcll(mask[i * W + w]);
+  cnt[i] = c;
+}
+
+// CSR side: entry (r, p) goes to rowptr[r] + (selected columns below p in row r) -- or, without masks, to the next
+// free slot of the row (k_sort_rows then orders the row)
+__global__ __launch_bounds__(256) void k_red_fill(const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len, int c1,
+                                                  const u32* __restrict__ rcrow, const double* __restrict__ rcval,
+                                                  const i64* __restrict__ rrowptr, const unsigned long long* __restrict__ mask,
+                                                  int W, u32* __restrict__ cursor, u32* __restrict__ rcol, double* __restrict__ rval) {
+  extern __shared__ i64 red_cp[];
+  const bool in_lds = c1 + 1 <= RED_LDS_COLS;
+  if (in_lds) { for (int t = threadIdx.x; t <= c1; t += 256) red_cp[t] = dst_colptr[t]; __syncthreads(); }
+  const i64* cp = in_lds ? red_cp : dst_colptr;
+  const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (e >= cp[c1]) return;
+  const int p = red_find_col(cp, c1, e);
+  if (e - cp[p] >= (i64)dst_len[p]) return;
+  const u32 r = rcrow[e];
+  i64 slot = rrowptr[r];
+  if (mask) {
+    const unsigned long long* mr = mask + (i64)r * W;
+    int below = 0;
+    for (int w = 0; w < (p >> 6); w++) below += __popcll(mr[w]);
+    below += __popcll(mr[p >> 6] & ((1ull << (p & 63)) - 1ull));
+    slot += below;
+  } else slot += (i64)atomicAdd(&cursor[r], 1u);
+  rcol[slot] = (u32)p;
+  rval[slot] = rcval[e];
 }
 
 template <typename VT>
@@ -728,29 +799,6 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
     o += __popcll(mask);
   }
   for (i64 e = o + lane; e < de; e += 64) { rcrow[e] = 0u; rcval[e] = 0.0; }
-}
-
-__global__ __launch_bounds__(256) void k_count_rows(const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len,
-                                                    const u32* __restrict__ rcrow, u32* __restrict__ cnt) {
-  const int p = blockIdx.x;
-  const i64 db = dst_colptr[p];
-  const i64 len = dst_len[p];
-  for (i64 e = threadIdx.x; e < len; e += 256) atomicAdd(&cnt[rcrow[db + e]], 1u);
-}
-
-__global__ __launch_bounds__(256) void k_fill_rows(const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len,
-                                                   const u32* __restrict__ rcrow, const double* __restrict__ rcval,
-                                                   const i64* __restrict__ rrowptr, u32* __restrict__ cursor,
-                                                   u32* __restrict__ rcol, double* __restrict__ rval) {
-  const int p = blockIdx.x;
-  const i64 db = dst_colptr[p];
-  const i64 len = dst_len[p];
-  for (i64 e = threadIdx.x; e < len; e += 256) {
-    const u32 r = rcrow[db + e];
-    const i64 slot = rrowptr[r] + (i64)atomicAdd(&cursor[r], 1u);
-    rcol[slot] = (u32)p;
-    rval[slot] = rcval[db + e];
-  }
 }
 
 // in-row insertion sort by (distinct) reduced column id -> deterministic, ascending rows
@@ -812,16 +860,15 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
   klr_mat* r = new klr_mat();
   r->ctx = ctx; r->device = ctx->device; r->n = n; r->dim = c1; r->n_total = full->n_total; r->val_f64 = true;
   r->n1_local = full->n1_local; r->n_total_all = full->n_total_all; r->h_labels = full->h_labels;
+  r->n_active_local = full->n_active_local;
   r->h_colptr.assign((size_t)c1 + 1, 0);
   r->h_collen.assign((size_t)c1, 0);
   r->h_colnz.assign((size_t)c1, 0);
-  std::vector<u32> src_len((size_t)c1);
   const bool dense = offset != nullptr;
   const i64 colstride = (n + 3) & ~(i64)3;
   bool any_zero = false;
   for (i64 p = 0; p < c1; p++) {
     const i64 j = cols[p];
-    src_len[p] = full->h_collen[j];
     const u32 len = dense ? (u32)n : full->h_colnz[j];
     if (full->h_colnz[j] != full->h_collen[j]) any_zero = true;
     r->h_collen[p] = len; r->h_colnz[p] = len;
@@ -830,36 +877,80 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
   }
   r->nnz_pad = r->h_colptr[c1];
   r->avg_row = n ? (double)r->nnz / (double)n : 0.0;
+  // chunks of the column sums (k_xt_s): columns cut at CHUNK_MAX entries
+  i64 nch = 0;
+  for (i64 p = 0; p < c1; p++) nch += ceil_div(r->h_colptr[p + 1] - r->h_colptr[p], CHUNK_MAX);
+  r->nchunks = nch;
+  r->group = pick_group(nch ? (double)r->nnz_pad / (double)nch : 4.0);
+
+  // ---- ONE pooled block for every device array of the matrix, ONE pinned staging copy for the host tables:
+  // (eleven hipMalloc + as many hipFree and nine pageable copies per epoch were 1 ms of host time)
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t nn = (size_t)std::max<i64>(n, 1), nz = (size_t)std::max<i64>(r->nnz, 1), nzp = (size_t)std::max<i64>(r->nnz_pad, 1);
+  const size_t nchs = (size_t)std::max<i64>(nch, 1);
+  size_t o = 0;
+  const size_t o_rowptr = o; o += al((nn + 1) * 8);
+  const size_t o_col = o;    o += al(nz * 4);
+  const size_t o_val = o;    o += al(nz * 8);
+  const size_t o_crow = o;   o += al(nzp * 4);
+  const size_t o_cval = o;   o += al(nzp * 8);
+  const size_t o_lab = o;    o += al(nn);
+  const size_t o_act = o;    o += al(nn);
+  // tables, in staging order: colptr | colchunk | chunk_begin | sel | scale | offset | chunk_len | src_len | dst_len
+  const size_t o_tab = o;
+  size_t t = 0;
+  const size_t t_colptr = t;   t += (size_t)(c1 + 1) * 8;
+  const size_t t_colchunk = t; t += (size_t)(c1 + 1) * 8;
+  const size_t t_cbegin = t;   t += nchs * 8;
+  const size_t t_sel = t;      t += (size_t)c1 * 8;
+  const size_t t_scale = t;    t += (size_t)c1 * 8;
+  const size_t t_off = t;      t += (size_t)c1 * 8;
+  const size_t t_clen = t;     t += nchs * 4;
+  const size_t t_srclen = t;   t += (size_t)c1 * 4;
+  const size_t t_dstlen = t;   t += (size_t)c1 * 4;
+  const size_t tab_bytes = t;
+  o += al(tab_bytes);
 
   int rc = KLR_OK;
-  i64* d_sel = nullptr; u32* d_srclen = nullptr; u32* d_dstlen = nullptr; double* d_scale = nullptr; double* d_off = nullptr;
   do {
-    if ((rc = dev_alloc(ctx, (void**)&r->rowptr, (size_t)(n + 1) * sizeof(i64)))) break;
-    if ((rc = dev_alloc(ctx, (void**)&r->col, (size_t)r->nnz * sizeof(u32)))) break;
-    if ((rc = dev_alloc(ctx, &r->val, (size_t)r->nnz * 8))) break;
-    if ((rc = dev_alloc(ctx, (void**)&r->crow, (size_t)r->nnz_pad * sizeof(u32)))) break;
-    if ((rc = dev_alloc(ctx, &r->cval, (size_t)r->nnz_pad * 8))) break;
-    if ((rc = dev_alloc(ctx, (void**)&r->labels, (size_t)n))) break;
-    if ((rc = mat_build_chunks_and_upload(ctx, r))) break;
-    // small per-call tables
-    char* tab;
-    const size_t tab_bytes = (size_t)c1 * (8 + 4 + 4 + 8 + 8) + 64;
-    if ((rc = ws_get(ctx, WS_TMP0, tab_bytes, (void**)&tab))) break;
-    d_sel = (i64*)tab;
-    d_scale = (double*)(tab + (size_t)c1 * 8);
-    d_off = (double*)(tab + (size_t)c1 * 16);
-    d_srclen = (u32*)(tab + (size_t)c1 * 24);
-    d_dstlen = (u32*)(tab + (size_t)c1 * 28);
+    if ((rc = pool_get(ctx, o, &r->arena, &r->arena_cap))) break;
+    char* base = (char*)r->arena;
+    r->rowptr = (i64*)(base + o_rowptr); r->col = (u32*)(base + o_col); r->val = base + o_val;
+    r->crow = (u32*)(base + o_crow); r->cval = base + o_cval;
+    r->labels = (uint8_t*)(base + o_lab); r->active_slot = (uint8_t*)(base + o_act);
+    char* dtab = base + o_tab;
+    r->colptr = (i64*)(dtab + t_colptr); r->colchunk = (i64*)(dtab + t_colchunk);
+    r->chunk_begin = (i64*)(dtab + t_cbegin); r->chunk_len = (u32*)(dtab + t_clen);
+    const i64* d_sel = (const i64*)(dtab + t_sel);
+    const double* d_scale = (const double*)(dtab + t_scale);
+    const double* d_off = (const double*)(dtab + t_off);
+    const u32* d_srclen = (const u32*)(dtab + t_srclen);
+    const u32* d_dstlen = (const u32*)(dtab + t_dstlen);
+    char* htab;
+    if ((rc = stage_get(ctx, tab_bytes, (void**)&htab))) break;
+    {
+      i64* h_colptr = (i64*)(htab + t_colptr); i64* h_colchunk = (i64*)(htab + t_colchunk);
+      i64* h_cbegin = (i64*)(htab + t_cbegin); u32* h_clen = (u32*)(htab + t_clen);
+      i64* h_sel = (i64*)(htab + t_sel); double* h_scale = (double*)(htab + t_scale); double* h_off = (double*)(htab + t_off);
+      u32* h_srclen = (u32*)(htab + t_srclen); u32* h_dstlen = (u32*)(htab + t_dstlen);
+      i64 k = 0;
+      for (i64 p = 0; p < c1; p++) {
+        h_colptr[p] = r->h_colptr[p]; h_colchunk[p] = k;
+        for (i64 b = r->h_colptr[p]; b < r->h_colptr[p + 1]; b += CHUNK_MAX) {
+          h_cbegin[k] = b; h_clen[k] = (u32)std::min(CHUNK_MAX, r->h_colptr[p + 1] - b); k++;
+        }
+        h_sel[p] = cols[p]; h_scale[p] = scale ? scale[p] : 1.0; h_off[p] = offset ? offset[p] : 0.0;
+        h_srclen[p] = full->h_collen[cols[p]]; h_dstlen[p] = r->h_collen[p];
+      }
+      h_colptr[c1] = r->h_colptr[c1]; h_colchunk[c1] = k;
+    }
     hipStream_t st = ctx->stream;
-    hipError_t e = hipMemcpyAsync(d_sel, cols, (size_t)c1 * 8, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)c1 * 8, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && offset) e = hipMemcpyAsync(d_off, offset, (size_t)c1 * 8, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_srclen, src_len.data(), (size_t)c1 * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_dstlen, r->h_collen.data(), (size_t)c1 * 4, hipMemcpyHostToDevice, st);
+    hipError_t e = hipMemcpyAsync(dtab, htab, tab_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(ctx->stage_ev, st);
     if (e == hipSuccess && n) e = hipMemcpyAsync(r->labels, full->labels, (size_t)n, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && n && full->active) {
-      e = hipMalloc((void**)&r->active, (size_t)n);
-      if (e == hipSuccess) e = hipMemcpyAsync(r->active, full->active, (size_t)n, hipMemcpyDeviceToDevice, st);
+      r->active = r->active_slot;
+      e = hipMemcpyAsync(r->active, full->active, (size_t)n, hipMemcpyDeviceToDevice, st);
     }
     if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns copy failed: %s", hipGetErrorString(e)); break; }
     const double* scp = scale ? d_scale : nullptr;
@@ -882,36 +973,44 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
         hipLaunchKernelGGL(k_dense_overwrite<float>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
                            (const float*)full->cval, d_sel, (int)c1, colstride, scp, d_off, (double*)r->val, (double*)r->cval);
     } else {
+      // row marks: bit masks (sorted rows for free) when they are small, else counters + cursor + in-row sort
+      const int W = (int)ceil_div(c1, (i64)64);
+      const bool use_mask = W <= RED_MASK_WORDS_MAX && !getenv("KLR_SUBSELECT_SORT");
+      u32* cnt; unsigned long long* mask = nullptr;
+      const size_t cnt_bytes = al(nn * sizeof(u32));
+      if ((rc = ws_get(ctx, WS_TMP1, cnt_bytes + (use_mask ? nn * (size_t)W * 8 : 0), (void**)&cnt))) break;
+      if (use_mask) { mask = (unsigned long long*)((char*)cnt + cnt_bytes); (void)hipMemsetAsync(mask, 0, nn * (size_t)W * 8, st); }
+      else (void)hipMemsetAsync(cnt, 0, nn * sizeof(u32), st);
+      const unsigned eb = (unsigned)std::max<i64>(1, ceil_div(r->nnz_pad, (i64)256));
+      const size_t lds = c1 + 1 <= RED_LDS_COLS ? (size_t)(c1 + 1) * 8 : 0;
       if (any_zero) {
+        // explicit zeros in a selected column are dropped (:332): compact per column, then mark
         if (full->val_f64)
           hipLaunchKernelGGL(k_gather_cols_nz<double>, dim3((unsigned)c1), dim3(64), 0, st, full->colptr, d_srclen, full->crow,
                              (const double*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
         else
           hipLaunchKernelGGL(k_gather_cols_nz<float>, dim3((unsigned)c1), dim3(64), 0, st, full->colptr, d_srclen, full->crow,
                              (const float*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
+        hipLaunchKernelGGL((k_red_gather<float, false>), dim3(eb), dim3(256), lds, st, full->colptr, full->crow, (const float*)nullptr,
+                           d_sel, r->colptr, d_dstlen, (int)c1, scp, r->crow, (double*)r->cval, mask, W, cnt);
+      } else if (full->val_f64) {
+        hipLaunchKernelGGL((k_red_gather<double, true>), dim3(eb), dim3(256), lds, st, full->colptr, full->crow, (const double*)full->cval,
+                           d_sel, r->colptr, d_dstlen, (int)c1, scp, r->crow, (double*)r->cval, mask, W, cnt);
       } else {
-        if (full->val_f64)
-          hipLaunchKernelGGL(k_gather_cols<double>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
-                             (const double*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
-        else
-          hipLaunchKernelGGL(k_gather_cols<float>, dim3((unsigned)c1), dim3(256), 0, st, full->colptr, d_srclen, full->crow,
-                             (const float*)full->cval, d_sel, r->colptr, scp, r->crow, (double*)r->cval);
+        hipLaunchKernelGGL((k_red_gather<float, true>), dim3(eb), dim3(256), lds, st, full->colptr, full->crow, (const float*)full->cval,
+                           d_sel, r->colptr, d_dstlen, (int)c1, scp, r->crow, (double*)r->cval, mask, W, cnt);
       }
-      u32* cnt;
-      if ((rc = ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * sizeof(u32), (void**)&cnt))) break;
-      (void)hipMemsetAsync(cnt, 0, (size_t)std::max<i64>(n, 1) * sizeof(u32), st);
-      hipLaunchKernelGGL(k_count_rows, dim3((unsigned)c1), dim3(256), 0, st, r->colptr, d_dstlen, r->crow, cnt);
+      if (use_mask && n) hipLaunchKernelGGL(k_red_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, mask, W, n, cnt);
       if ((rc = launch_exscan_u32(ctx, cnt, n, r->rowptr))) break;
-      (void)hipMemsetAsync(cnt, 0, (size_t)std::max<i64>(n, 1) * sizeof(u32), st);
-      hipLaunchKernelGGL(k_fill_rows, dim3((unsigned)c1), dim3(256), 0, st, r->colptr, d_dstlen, r->crow, (const double*)r->cval,
-                         r->rowptr, cnt, r->col, (double*)r->val);
-      if (n) hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, r->rowptr, n, r->col, (double*)r->val);
+      if (!use_mask) (void)hipMemsetAsync(cnt, 0, nn * sizeof(u32), st);
+      hipLaunchKernelGGL(k_red_fill, dim3(eb), dim3(256), lds, st, r->colptr, d_dstlen, (int)c1, r->crow, (const double*)r->cval,
+                         r->rowptr, mask, W, cnt, r->col, (double*)r->val);
+      if (!use_mask && n)
+        hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, r->rowptr, n, r->col, (double*)r->val);
     }
     e = hipGetLastError();
     if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns launch failed: %s", hipGetErrorString(e)); break; }
-    // the per-call tables live in workspace that later calls reuse: finish before returning
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns failed: %s", hipGetErrorString(e)); break; }
+    // no synchronisation: the tables are part of the matrix's own block, everything downstream runs on ctx->stream
   } while (0);
   if (rc != KLR_OK) { std::string keep = ctx->err; mat_free(r); ctx->err = keep; return rc; }
   *out = r;

@@ -399,8 +399,11 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
 }
 #undef CD_STEP
 
-// log-loss of up to KSPEC iterates in one pass over the reduced rows (thread per row); the iterates
-// are staged in LDS, each stored entry is read once and applied to all of them
+// log-loss of up to KSPEC iterates in one pass over the reduced rows: lane (row, k) -- 8 lanes per row, one per
+// iterate -- so the exp / log1p of the KSPEC iterates of a row run side by side instead of one after the other (a
+// thread per row spent most of its 30 us there); the entries of a row are same-address loads for its 8 lanes; the
+// iterates are staged in LDS as [column][k].  32 rows per block, block partials in a fixed order.
+#define LM_ROWS (256 / KSPEC)
 template <bool LDS>
 __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                     const double* __restrict__ val, const uint8_t* __restrict__ labels,
@@ -412,49 +415,29 @@ __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowp
   const int K = *ndone;
   if (LDS) {
     for (int t = threadIdx.x; t < KSPEC * d; t += 256) {
-      const int k = t / d, c = t % d;
-      lm_lds[c * KSPEC + k] = k < K ? hist[(i64)k * d + c] : 0.0;
+      const int c = t / KSPEC, k = t % KSPEC;
+      lm_lds[t] = k < K ? hist[(i64)k * d + c] : 0.0;
     }
     __syncthreads();
   }
-  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-  double term[KSPEC];
-#pragma unroll
-  for (int k = 0; k < KSPEC; k++) term[k] = 0.0;
-  if (i < n && (!active || active[i])) {
+  const int k = threadIdx.x % KSPEC;
+  const i64 i = (i64)blockIdx.x * LM_ROWS + threadIdx.x / KSPEC;
+  double term = 0.0;
+  if (i < n && k < K && (!active || active[i])) {
     const i64 b = rowptr[i], e = rowptr[i + 1];
     const int y = labels[i] != 0;
-    double r[KSPEC];
-#pragma unroll
-    for (int k = 0; k < KSPEC; k++) r[k] = 0.0;
-    for (i64 p = b + 1; p < e; p++) {
-      const double v = val[p];
-      if (LDS) {
-        const double* t = lm_lds + (size_t)col[p] * KSPEC;
-#pragma unroll
-        for (int k = 0; k < KSPEC; k++) r[k] += v * t[k];
-      } else {
-        const double* t = hist + col[p];
-#pragma unroll
-        for (int k = 0; k < KSPEC; k++) if (k < K) r[k] += v * t[(i64)k * d];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < KSPEC; k++) {
-      if (k < K) {
-        const double rr = (LDS ? lm_lds[k] : hist[(i64)k * d]) + r[k];     // theta[0] + sum
-        const double l1p = log1p(exp(-fabs(rr)));
-        // y: -log sigma(r) = LogAdd(0,-r);  !y: LogAdd(0,r)
-        term[k] = y ? cw1 * (fmax(-rr, 0.0) + l1p) : cw0 * (fmax(rr, 0.0) + l1p);
-      }
-    }
+    double r = 0.0;
+    if (LDS) { for (i64 p = b + 1; p < e; p++) r += val[p] * lm_lds[(size_t)col[p] * KSPEC + k]; }
+    else     { for (i64 p = b + 1; p < e; p++) r += val[p] * hist[(i64)k * d + col[p]]; }
+    const double rr = (LDS ? lm_lds[k] : hist[(i64)k * d]) + r;            // theta[0] + sum
+    const double l1p = log1p(exp(-fabs(rr)));
+    // y: -log sigma(r) = LogAdd(0,-r);  !y: LogAdd(0,r)
+    term = y ? cw1 * (fmax(-rr, 0.0) + l1p) : cw0 * (fmax(rr, 0.0) + l1p);
   }
-#pragma unroll
-  for (int k = 0; k < KSPEC; k++) {
-    double v = term[k];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
-  }
+  // rows of the wave: lanes k, k+8, ..., k+56
+  double v = term;
+  for (int o = 32; o >= KSPEC; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) < KSPEC) sh[k][threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x < KSPEC) blk[(i64)blockIdx.x * KSPEC + threadIdx.x] =
       (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
@@ -539,7 +522,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const size_t report_bytes = ((size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 1) * sizeof(int);
   char* pin_report;
   KLR_TRY(pin_get(ctx, report_bytes, (void**)&pin_report));
-  const i64 nb = std::max<i64>(1, ceil_div(n, 256));
+  const i64 nb = std::max<i64>(1, ceil_div(n, (i64)LM_ROWS));          // blocks of k_loss_multi
   KLR_TRY(ws_get(ctx, WS_CD_LOSS, ((size_t)nb * KSPEC + KSPEC) * 8, (void**)&lossb));
 
   std::vector<double> th(theta, theta + d), tp(d), hhist((size_t)KSPEC * d), hdelta(KSPEC), hloss(KSPEC);

@@ -76,6 +76,33 @@ def test_roundtrip_and_select_columns(ctx, synth_small):
         np.testing.assert_array_equal(val, ro.val)         # same single multiply -> bit-exact
 
 
+@pytest.mark.parametrize("ncols,sort_path", [(1, False), (40, True), (700, False), (1500, False)])
+def test_select_columns_paths_and_block_reuse(ctx, synth_small, monkeypatch, ncols, sort_path):
+    """Bit-mask ranks (<= 1024 columns), counters + in-row sort (more columns, or KLR_SUBSELECT_SORT), and the pooled
+    block of a released reduced matrix handed to the next sub-select: same CSR as featureSelection.Data + Transform
+    (oracle), same column sums through the reduced CSC."""
+    x, labels = synth_small
+    m = upload(ctx, x, labels)
+    if sort_path:
+        monkeypatch.setenv("KLR_SUBSELECT_SORT", "1")
+    rng = np.random.default_rng(ncols)
+    for rep in range(3):                                   # released blocks are reused by the next call
+        k = max(0, ncols - 1 - 7 * rep)
+        cols = np.concatenate([[0], 1 + np.sort(rng.choice(x.dim - 1, size=k, replace=False))]).astype(np.int64)
+        red = m.select_columns(cols)
+        ro = O.select_columns(x, cols)
+        rp, col, val = red.to_csr()
+        np.testing.assert_array_equal(rp, ro.rowptr)
+        np.testing.assert_array_equal(col, ro.col)
+        np.testing.assert_array_equal(val, ro.val)
+        theta = rng.normal(size=len(cols)) * 0.05
+        cw = O.class_weights(labels)
+        g = K.gradient_dense(ctx, red, theta, cw)          # column sums over the reduced CSC
+        go = O.gradient(ro, labels, theta, cw)
+        np.testing.assert_allclose(g, go, rtol=1e-11, atol=1e-13)
+        del red
+
+
 def test_select_columns_drops_explicit_zeros(ctx, scores):
     x, labels, dense = scores
     d2 = dense.copy(); d2[3, 1] = 0.0; d2[9, 6] = 0.0; d2[0, 0] = 0.0
