@@ -189,6 +189,7 @@ int   launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode
 
 // column sweep: g_raw[j] = sum_i s[i] * x_ij (sq: x_ij^2) for every column of mat (length dim)
 int   launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g_raw_dev, bool square);
+int   launch_irls_cols(klr_ctx* ctx, const klr_mat* mat, const double* w, const double* z, double** part_out);
 
 // full-width sweep incl. the cross-rank reduction: gbuf[0..dim) = X's, gbuf[dim] = sum of loss terms.
 // Count data (mat->tiled): lterm_dev holds per-row loss terms; otherwise gbuf[dim] must already hold the

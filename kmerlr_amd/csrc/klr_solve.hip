@@ -49,6 +49,39 @@ __global__ __launch_bounds__(256) void k_gram_scale(const double* __restrict__ n
   }
 }
 
+// Column sums of a re-linearisation from their chunk partials (chunk order: same sums as k_finish_cols), three
+// per column: a0 | nm | xy (contiguous, 3d).  SCALE (single rank: the sums are already global): the Gram scale in
+// the same launch; the eleven tiny launches of an IRLS set-up were ~5 us each.  One block.
+template <bool SCALE>
+__global__ __launch_bounds__(1024) void k_irls_finish(const i64* __restrict__ colchunk, int d, i64 nchunks,
+                                                      const double* __restrict__ part, double* __restrict__ a0nmxy,
+                                                      double* __restrict__ sc) {
+  __shared__ double sh[1024];
+  double mx = 0.0;
+  for (int j = threadIdx.x; j < d; j += 1024) {
+    const i64 c0 = colchunk[j], c1 = colchunk[j + 1];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (i64 c = c0; c < c1; c++) { v0 += part[c]; v1 += part[nchunks + c]; v2 += part[2 * nchunks + c]; }
+    a0nmxy[j] = v0; a0nmxy[d + j] = v1; a0nmxy[2 * d + j] = v2;
+    if (j >= 1) mx = fmax(mx, fabs(v1));
+  }
+  if (!SCALE) return;
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {                       // k_gram_scale
+    double m = sh[0];
+    if (!(m > 0.0) || m != m || m > 1e300) m = 1.0;
+    int e;
+    (void)frexp(m, &e);
+    sc[0] = ldexp(1.0, 61 - e);
+    sc[1] = ldexp(1.0, e - 61);
+  }
+}
+
 // off-diagonal, non-bias Gram cells from the short reduced rows, upper triangle only:
 //   Gi[ja][jb] += round(w_i v_a v_b 2^E)  for a < b   (integer atomics: exact, order free)
 // 16 lanes per row: every lane holds one stored entry (coalesced load), partners arrive by shuffle, so a row
@@ -129,6 +162,38 @@ __global__ __launch_bounds__(256) void k_gram_reduce(unsigned long long* __restr
   sh[ly][cx] = v;
   __syncthreads();
   if (ly == 0 && t < dd) Gi[t] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+}
+
+// Single rank: k_gram_reduce and k_gram_assemble in one launch.  Only the upper triangle j < k (j >= 1) carries
+// integers; cell (j, k) sums its partials (same order as k_gram_reduce) and writes G[j][k] and G[k][j]; row /
+// column 0 and the diagonal come from the column sums.
+__global__ __launch_bounds__(256) void k_gram_reduce_assemble(const unsigned long long* __restrict__ Gi, int d, int nblk,
+                                                              const double* __restrict__ a0, const double* __restrict__ nm,
+                                                              const double* __restrict__ sc, double* __restrict__ G) {
+  __shared__ unsigned long long sh[4][64];
+  const int dd = d * d;
+  const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + cx;
+  const int j = t < dd ? t / d : 0, k = t < dd ? t % d : 0;
+  const bool upper = t < dd && j >= 1 && j < k;
+  unsigned long long v = 0ull;
+  if (upper) {
+    for (int b = 1 + ly; b <= nblk; b += 32) {
+      unsigned long long x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = (b + 4 * u <= nblk) ? Gi[(size_t)(b + 4 * u) * dd + t] : 0ull;
+      v += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    }
+  }
+  sh[ly][cx] = v;
+  __syncthreads();
+  if (ly != 0 || t >= dd) return;
+  if (upper) {
+    const double g = (double)(i64)((sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx])) * sc[1];
+    G[(i64)j * d + k] = g; G[(i64)k * d + j] = g;
+  } else if (j == k) G[t] = nm[j];
+  else if (j == 0) G[t] = a0[k];
+  else if (k == 0) G[t] = a0[j];
 }
 
 // G from its parts: row/column 0 and the diagonal from the column sweeps, the rest from the integers
@@ -498,11 +563,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   }
 
   hipStream_t st = ctx->stream;
-  double *w, *z, *wz, *G, *vec, *lossb;
+  double *w, *z, *G, *vec, *lossb;
   i64* Gi;
   KLR_TRY(ws_get(ctx, WS_S, (size_t)std::max<i64>(n, 1) * 8, (void**)&w));
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&z));
-  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)std::max<i64>(n, 1) * 8, (void**)&wz));
   // LDS-privatised Gram build: one partial per workgroup after the result slot
   // ... unless the rows are so short that there are few pairs in all (k-mer data: 2-3 stored entries per reduced
   // row): then zeroing, writing and re-reading one 80 KiB partial per workgroup is the whole cost (150 us per
@@ -542,27 +606,40 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   for (i64 iter = 0; iter < max_iter; iter++) {
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
     KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr));
-    if (n) hipLaunchKernelGGL(k_mul, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, w, z, wz, n);
-    KLR_TRY(launch_xt_s(ctx, red, w, a0, false));      // sum_i w_i x_ij      -> row/column 0
-    KLR_TRY(launch_xt_s(ctx, red, w, nm, true));       // sum_i w_i x_ij^2    -> diagonal (norm)
-    KLR_TRY(launch_xt_s(ctx, red, wz, xy, false));     // sum_i w_i z_i x_ij  -> inner_xy
-    KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
-    hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
-    KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
+    // [a0 | nm | xy] = sum_i w x | sum_i w x^2 (diagonal, norm) | sum_i w z x (inner_xy): one pass, one finish
+    const bool single = ctx->ar_fn == nullptr;
+    double* part3;
+    KLR_TRY(launch_irls_cols(ctx, red, w, z, &part3));
+    if (single) hipLaunchKernelGGL(k_irls_finish<true>, dim3(1), dim3(1024), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc);
+    else {
+      hipLaunchKernelGGL(k_irls_finish<false>, dim3(1), dim3(1024), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc);
+      KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
+      hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
+    }
+    // the LDS-privatised build writes whole partials and the reduce overwrites the result slot: nothing to zero
+    if (!gram_lds || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
+    bool assembled = false;
     if (n) {
       if (gram_lds) {
         hipLaunchKernelGGL(k_gram_offdiag<true>, dim3(gram_blocks), dim3(1024), (size_t)d * d * 8, st, red->rowptr, red->col,
                            (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
-        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
-                           d * d, (int)gram_blocks);
+        if (single) {
+          hipLaunchKernelGGL(k_gram_reduce_assemble, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st,
+                             (const unsigned long long*)Gi, d, (int)gram_blocks, a0, nm, gsc, G);
+          assembled = true;
+        } else
+          hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
+                             d * d, (int)gram_blocks);
       } else {
         const unsigned gb = (unsigned)std::max<i64>(1, std::min<i64>(4 * ctx->n_cu, ceil_div(n * 16, 1024)));
         hipLaunchKernelGGL(k_gram_offdiag<false>, dim3(gb), dim3(1024), 0, st, red->rowptr, red->col,
                            (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);
       }
     }
-    KLR_TRY(klr_allreduce(ctx, Gi, (i64)d * d, KLR_I64));
-    hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, a0, nm, Gi, gsc, d, G);
+    if (!assembled) {
+      KLR_TRY(klr_allreduce(ctx, Gi, (i64)d * d, KLR_I64));
+      hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, a0, nm, Gi, gsc, d, G);
+    }
     KLR_HIP(ctx, hipGetLastError());
     tp = th;
 

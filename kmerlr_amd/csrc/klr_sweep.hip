@@ -291,6 +291,56 @@ __global__ __launch_bounds__(256) void k_xt_s(const u32* __restrict__ crow, cons
   if (lane == 0) part[gid] = acc;
 }
 
+// The three column sums of an IRLS re-linearisation in ONE pass over the reduced CSC (f64 values):
+//   part[0][c] = sum w x   part[1][c] = sum w x^2   part[2][c] = sum (w z) x      per chunk c,
+// same lane striding, same fma order and same group sum as three k_xt_s launches over w, w (squared) and w*z.
+template <int G>
+__global__ __launch_bounds__(256) void k_irls_cols(const u32* __restrict__ crow, const double* __restrict__ cval,
+                                                   const i64* __restrict__ chunk_begin, const u32* __restrict__ chunk_len,
+                                                   i64 nchunks, const double* __restrict__ w, const double* __restrict__ z,
+                                                   double* __restrict__ part) {
+  const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
+  const int lane = threadIdx.x % G;
+  if (gid >= nchunks) return;            // whole groups leave together
+  const i64 b = chunk_begin[gid];
+  const i64 e = b + (i64)chunk_len[gid];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 2
+  for (i64 p = b + 4 * lane; p < e; p += 4 * G) {
+    const uint4 r = *reinterpret_cast<const uint4*>(crow + p);
+    const double4 v = *reinterpret_cast<const double4*>(cval + p);
+    const double w0 = w[r.x], w1 = w[r.y], w2 = w[r.z], w3 = w[r.w];
+    const double z0 = z[r.x], z1 = z[r.y], z2 = z[r.z], z3 = z[r.w];
+    a0 = fma(w0, v.x, a0); a0 = fma(w1, v.y, a0); a0 = fma(w2, v.z, a0); a0 = fma(w3, v.w, a0);
+    a1 = fma(w0, v.x * v.x, a1); a1 = fma(w1, v.y * v.y, a1); a1 = fma(w2, v.z * v.z, a1); a1 = fma(w3, v.w * v.w, a1);
+    a2 = fma(w0 * z0, v.x, a2); a2 = fma(w1 * z1, v.y, a2); a2 = fma(w2 * z2, v.z, a2); a2 = fma(w3 * z3, v.w, a2);
+  }
+  a0 = group_sum<G>(a0); a1 = group_sum<G>(a1); a2 = group_sum<G>(a2);
+  if (lane == 0) { part[gid] = a0; part[nchunks + gid] = a1; part[2 * nchunks + gid] = a2; }
+}
+
+// part = 3 * nchunks doubles (WS_PART), consumed by the solver's k_irls_finish
+int launch_irls_cols(klr_ctx* ctx, const klr_mat* mat, const double* w, const double* z, double** part_out) {
+  double* part;
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<i64>(mat->nchunks, 1) * 3 * sizeof(double), (void**)&part));
+  *part_out = part;
+  if (mat->nchunks > 0) {
+    const int g = mat->group;
+    const dim3 grid((unsigned)ceil_div(mat->nchunks * g, 256));
+    const double* cv = (const double*)mat->cval;
+    hipStream_t st = ctx->stream;
+    switch (g) {
+      case 4:  hipLaunchKernelGGL(k_irls_cols<4>, grid, dim3(256), 0, st, mat->crow, cv, mat->chunk_begin, mat->chunk_len, mat->nchunks, w, z, part); break;
+      case 8:  hipLaunchKernelGGL(k_irls_cols<8>, grid, dim3(256), 0, st, mat->crow, cv, mat->chunk_begin, mat->chunk_len, mat->nchunks, w, z, part); break;
+      case 16: hipLaunchKernelGGL(k_irls_cols<16>, grid, dim3(256), 0, st, mat->crow, cv, mat->chunk_begin, mat->chunk_len, mat->nchunks, w, z, part); break;
+      case 32: hipLaunchKernelGGL(k_irls_cols<32>, grid, dim3(256), 0, st, mat->crow, cv, mat->chunk_begin, mat->chunk_len, mat->nchunks, w, z, part); break;
+      default: hipLaunchKernelGGL(k_irls_cols<64>, grid, dim3(256), 0, st, mat->crow, cv, mat->chunk_begin, mat->chunk_len, mat->nchunks, w, z, part); break;
+    }
+    KLR_HIP(ctx, hipGetLastError());
+  }
+  return KLR_OK;
+}
+
 // adds a column's chunk sums in chunk order
 __global__ __launch_bounds__(256) void k_finish_cols(const i64* __restrict__ colchunk, i64 dim,
                                                      const double* __restrict__ part, double* __restrict__ g) {
