@@ -877,9 +877,12 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
   }
   r->nnz_pad = r->h_colptr[c1];
   r->avg_row = n ? (double)r->nnz / (double)n : 0.0;
-  // chunks of the column sums (k_xt_s): columns cut at CHUNK_MAX entries
+  // chunks of the column sums (k_xt_s, k_irls_cols): columns cut at RED_CHUNK entries -- short chunks: the sums over
+  // a reduced matrix are latency bound (a lane group walks its chunk in dependent gather round trips), and the
+  // bias column alone is n entries
+  const i64 RED_CHUNK = 512;
   i64 nch = 0;
-  for (i64 p = 0; p < c1; p++) nch += ceil_div(r->h_colptr[p + 1] - r->h_colptr[p], CHUNK_MAX);
+  for (i64 p = 0; p < c1; p++) nch += ceil_div(r->h_colptr[p + 1] - r->h_colptr[p], RED_CHUNK);
   r->nchunks = nch;
   r->group = pick_group(nch ? (double)r->nnz_pad / (double)nch : 4.0);
 
@@ -936,8 +939,8 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
       i64 k = 0;
       for (i64 p = 0; p < c1; p++) {
         h_colptr[p] = r->h_colptr[p]; h_colchunk[p] = k;
-        for (i64 b = r->h_colptr[p]; b < r->h_colptr[p + 1]; b += CHUNK_MAX) {
-          h_cbegin[k] = b; h_clen[k] = (u32)std::min(CHUNK_MAX, r->h_colptr[p + 1] - b); k++;
+        for (i64 b = r->h_colptr[p]; b < r->h_colptr[p + 1]; b += RED_CHUNK) {
+          h_cbegin[k] = b; h_clen[k] = (u32)std::min(RED_CHUNK, r->h_colptr[p + 1] - b); k++;
         }
         h_sel[p] = cols[p]; h_scale[p] = scale ? scale[p] : 1.0; h_off[p] = offset ? offset[p] : 0.0;
         h_srclen[p] = full->h_collen[cols[p]]; h_dstlen[p] = r->h_collen[p];

@@ -49,36 +49,46 @@ __global__ __launch_bounds__(256) void k_gram_scale(const double* __restrict__ n
   }
 }
 
-// Column sums of a re-linearisation from their chunk partials (chunk order: same sums as k_finish_cols), three
-// per column: a0 | nm | xy (contiguous, 3d).  SCALE (single rank: the sums are already global): the Gram scale in
-// the same launch; the eleven tiny launches of an IRLS set-up were ~5 us each.  One block.
+// Column sums of a re-linearisation from their chunk partials, three per column: a0 | nm | xy (contiguous, 3d).
+// A wavefront per column: lanes stride over the column's chunks, then a fixed shuffle tree (the bias column of a
+// reduced matrix is n entries = hundreds of chunks; one thread walking them took 28 us).  SCALE (single rank: the
+// sums are already global): the Gram scale in the same launch -- the largest |diagonal| by an integer atomic max on
+// the bits of the non-negative doubles, the last block to finish (ticket) turns it into the power of two and
+// resets both words.  ctl = {ticket, max bits}, zero before the first launch.
 template <bool SCALE>
-__global__ __launch_bounds__(1024) void k_irls_finish(const i64* __restrict__ colchunk, int d, i64 nchunks,
-                                                      const double* __restrict__ part, double* __restrict__ a0nmxy,
-                                                      double* __restrict__ sc) {
-  __shared__ double sh[1024];
-  double mx = 0.0;
-  for (int j = threadIdx.x; j < d; j += 1024) {
+__global__ __launch_bounds__(256) void k_irls_finish(const i64* __restrict__ colchunk, int d, i64 nchunks,
+                                                     const double* __restrict__ part, double* __restrict__ a0nmxy,
+                                                     double* __restrict__ sc, unsigned long long* __restrict__ ctl) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j < d) {
     const i64 c0 = colchunk[j], c1 = colchunk[j + 1];
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-    for (i64 c = c0; c < c1; c++) { v0 += part[c]; v1 += part[nchunks + c]; v2 += part[2 * nchunks + c]; }
-    a0nmxy[j] = v0; a0nmxy[d + j] = v1; a0nmxy[2 * d + j] = v2;
-    if (j >= 1) mx = fmax(mx, fabs(v1));
+    for (i64 c = c0 + lane; c < c1; c += 64) { v0 += part[c]; v1 += part[nchunks + c]; v2 += part[2 * nchunks + c]; }
+    for (int o = 32; o > 0; o >>= 1) {
+      v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64);
+    }
+    if (lane == 0) {
+      a0nmxy[j] = v0; a0nmxy[d + j] = v1; a0nmxy[2 * d + j] = v2;
+      if (SCALE && j >= 1 && v1 == v1) atomicMax(&ctl[1], (unsigned long long)__double_as_longlong(fabs(v1)));
+    }
   }
   if (!SCALE) return;
-  sh[threadIdx.x] = mx;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {                       // k_gram_scale
-    double m = sh[0];
-    if (!(m > 0.0) || m != m || m > 1e300) m = 1.0;
-    int e;
-    (void)frexp(m, &e);
-    sc[0] = ldexp(1.0, 61 - e);
-    sc[1] = ldexp(1.0, e - 61);
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long t = atomicAdd(&ctl[0], 1ull);
+    if (t == gridDim.x - 1) {                    // k_gram_scale
+      __threadfence();
+      double m = __longlong_as_double((long long)atomicMax(&ctl[1], 0ull));
+      if (!(m > 0.0) || m != m || m > 1e300) m = 1.0;
+      int e;
+      (void)frexp(m, &e);
+      sc[0] = ldexp(1.0, 61 - e);
+      sc[1] = ldexp(1.0, e - 61);
+      atomicExch(&ctl[1], 0ull);
+      atomicExch(&ctl[0], 0ull);
+    }
   }
 }
 
@@ -464,6 +474,133 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
 }
 #undef CD_STEP
 
+// d <= 128: the same wave-synchronous sweeps with every operand in LDS at padded strides, so that a step is its
+// arithmetic chain and little else (a single wavefront pays ~4-8 cycles of issue per instruction of ANY kind; the
+// k_cd_wave step spent 29 instructions, twelve of them scalar address arithmetic and clamps, for a chain of 9):
+//   * Gram rows staged at a stride of 128 doubles, columns >= d and row d zero: row j+1 is read without a clamp at
+//     [row pointer] and [row pointer + 512 bytes], the pointer a per-lane register that advances by one add;
+//   * {c_j, old theta_j, 1/(norm_j + l2), theta_j} packed 32 bytes per coordinate (entry d a dummy): one pointer
+//     (kept in a vector register on purpose: a uniform address would be re-materialised from scalar registers for
+//     every LDS instruction) serves the two operand reads of step j+1 and the theta_j write of step j.
+// Same arithmetic, same order, same results as k_cd_wave<2, true>.  LDS: (d+1) * 132 doubles <= 136 KiB.
+#define CDL_STRIDE 128
+#define CDL_STEP(Q, JL, L1, G0, G1, C, O, I, GN0, GN1, CN, ON, IN)                                            \
+  {                                                                                                            \
+    GN0 = grow[0]; GN1 = grow[64]; grow += CDL_STRIDE;                                                        \
+    const double2 p01_ = *reinterpret_cast<const double2*>(pj + 4);                                            \
+    CN = p01_.x; ON = p01_.y; IN = pj[6];                                                                      \
+    const double qj_ = bcast_lane(Q, (JL));                                                                    \
+    const double t0_ = C - qj_;                                   /* coordinate.go:56-59 */                    \
+    const double m_ = fmax(fabs(t0_) - (L1), 0.0);                /* :60-67 soft threshold */                  \
+    const double tn_ = copysign(m_, t0_) * I;                     /* :69 (reciprocal) */                       \
+    const double dl_ = tn_ - O;                                                                                \
+    q0 = fma(dl_, G0, q0); q1 = fma(dl_, G1, q1);                                                              \
+    pj[3] = tn_;                                                  /* every lane, same value, same address */   \
+    pj += 4;                                                                                                   \
+  }
+
+__global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a) {
+  extern __shared__ double lds[];
+  const int d = a.d, lane = threadIdx.x & 63;
+  double* Gl = lds;                                         // (d+1) x 128
+  double* pk = lds + (size_t)(d + 1) * CDL_STRIDE;          // (d+1) x 4
+#pragma unroll 4
+  for (int t = threadIdx.x; t < (d + 1) * CDL_STRIDE; t += 1024) {
+    const int j = t >> 7, i = t & (CDL_STRIDE - 1);
+    Gl[t] = (j < d && i < d) ? a.G[(i64)j * d + i] : 0.0;
+  }
+  for (int t = threadIdx.x; t < 4 * (d + 1); t += 1024) pk[t] = ((t & 3) == 3 && (t >> 2) < d) ? a.theta[t >> 2] : 0.0;
+  __syncthreads();
+  if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
+  const int i0 = lane, i1 = 64 + lane;
+  const double xy0 = i0 < d ? a.xy[i0] : 0.0, xy1 = i1 < d ? a.xy[i1] : 0.0;
+  const double dg0 = i0 < d ? Gl[(size_t)i0 * CDL_STRIDE + i0] : 1.0, dg1 = i1 < d ? Gl[(size_t)i1 * CDL_STRIDE + i1] : 1.0;
+  const double inv0 = 1.0 / (dg0 + a.l2reg), inv1 = 1.0 / (dg1 + a.l2reg);      // :69 as a reciprocal (<= 1 ulp)
+  double q0 = 0.0, q1 = 0.0;
+  // q = G theta (skipping zero coefficients)
+  for (int k = 0; k < d; k++) {
+    const double t = pk[4 * k + 3];
+    if (t != 0.0) { q0 += Gl[(size_t)k * CDL_STRIDE + i0] * t; q1 += Gl[(size_t)k * CDL_STRIDE + i1] * t; }
+  }
+  int zero_v;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));      // opaque: keeps the operand pointer in a vector register
+  const double l1 = a.l1reg;
+  int done = 0;
+  for (int k = 0; k < a.K; k++) {
+    double told0 = 0.0, told1 = 0.0;
+    if (i0 < d) { const double t = pk[4 * i0 + 3]; told0 = t; pk[4 * i0] = xy0 + dg0 * t; pk[4 * i0 + 1] = t; pk[4 * i0 + 2] = inv0; }   // :56
+    if (i1 < d) { const double t = pk[4 * i1 + 3]; told1 = t; pk[4 * i1] = xy1 + dg1 * t; pk[4 * i1 + 1] = t; pk[4 * i1 + 2] = inv1; }
+    __builtin_amdgcn_wave_barrier();
+    double gA0 = Gl[i0], gA1 = Gl[i1], cA = pk[0], oA = pk[1], iA = pk[2];
+    double gB0, gB1, cB, oB, iB;
+    const double* grow = Gl + CDL_STRIDE + lane;        // row 1
+    double* pj = pk + zero_v;                           // coordinate 0
+    {
+      const int j1 = d < 64 ? d : 64;
+      int j = 0;
+      CDL_STEP(q0, j, 0.0, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);     // the bias is not penalised (:60)
+      j++;
+      if (j < j1) { CDL_STEP(q0, j, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA); j++; }
+      else { gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB; }            // d == 1: keep the sets aligned
+      for (; j + 1 < j1; j += 2) {
+        CDL_STEP(q0, j, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+        CDL_STEP(q0, j + 1, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA);
+      }
+      if (j < j1) {
+        CDL_STEP(q0, j, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+        gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB;
+      }
+    }
+    {
+      int j = 64;
+      for (; j + 1 < d; j += 2) {
+        CDL_STEP(q1, j - 64, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+        CDL_STEP(q1, j - 63, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA);
+      }
+      if (j < d) {
+        CDL_STEP(q1, j - 64, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+        gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // eval_stopping (proximal.go:30-52) from the old and the new iterate, lane parallel
+    double max_x = 0.0, max_delta = 0.0;
+    int isnan_ = 0;
+    if (i0 < d) {
+      const double tn = pk[4 * i0 + 3];
+      a.hist[(i64)k * d + i0] = tn;
+      isnan_ |= (tn != tn) ? 1 : 0;
+      max_x = fmax(max_x, fabs(tn));
+      max_delta = fmax(max_delta, fabs(tn - told0));
+    }
+    if (i1 < d) {
+      const double tn = pk[4 * i1 + 3];
+      a.hist[(i64)k * d + i1] = tn;
+      isnan_ |= (tn != tn) ? 1 : 0;
+      max_x = fmax(max_x, fabs(tn));
+      max_delta = fmax(max_delta, fabs(tn - told1));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      max_x = fmax(max_x, __shfl_xor(max_x, o, 64));
+      max_delta = fmax(max_delta, __shfl_xor(max_delta, o, 64));
+      isnan_ |= __shfl_xor(isnan_, o, 64);
+    }
+    double delta; int stop;
+    if (isnan_) { delta = nan(""); stop = 1; }
+    else {
+      delta = (max_x != 0.0) ? max_delta / max_x : max_delta;
+      stop = ((max_x != 0.0 && max_delta / max_x <= a.eps) || (max_x == 0.0 && max_delta == 0.0)) ? 1 : 0;
+    }
+    if (lane == 0) { a.delta[k] = delta; a.stopf[k] = stop; }
+    done = k + 1;
+    if (stop) break;
+  }
+  if (i0 < d) a.theta[i0] = pk[4 * i0 + 3];
+  if (i1 < d) a.theta[i1] = pk[4 * i1 + 3];
+  if (lane == 0) *a.ndone = done;
+}
+#undef CDL_STEP
+
 // log-loss of up to KSPEC iterates in one pass over the reduced rows: lane (row, k) -- 8 lanes per row, one per
 // iterate -- so the exp / log1p of the KSPEC iterates of a row run side by side instead of one after the other (a
 // thread per row spent most of its 30 us there); the entries of a row are same-address loads for its 8 lanes; the
@@ -557,7 +694,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   static bool attr_set = false;
   if (!attr_set) {
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_wave<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_lds2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
     KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     attr_set = true;
   }
@@ -578,11 +715,13 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
   // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
-  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int);
+  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16;
   KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
   double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d; double* hist = thd + d;
   double* delta = hist + (size_t)KSPEC * d; double* losses = delta + KSPEC; double* gsc = losses + KSPEC;
   int* stopf = (int*)(gsc + 2); int* ndone = stopf + KSPEC;
+  unsigned long long* fin_ctl = (unsigned long long*)(stopf + KSPEC + 8);     // {ticket, max bits} of k_irls_finish
+  KLR_HIP(ctx, hipMemsetAsync(fin_ctl, 0, 16, st));
   const size_t report_bytes = ((size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 1) * sizeof(int);
   char* pin_report;
   KLR_TRY(pin_get(ctx, report_bytes, (void**)&pin_report));
@@ -610,9 +749,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     const bool single = ctx->ar_fn == nullptr;
     double* part3;
     KLR_TRY(launch_irls_cols(ctx, red, w, z, &part3));
-    if (single) hipLaunchKernelGGL(k_irls_finish<true>, dim3(1), dim3(1024), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc);
+    const unsigned fin_blocks = (unsigned)ceil_div((i64)d, (i64)4);
+    if (single) hipLaunchKernelGGL(k_irls_finish<true>, dim3(fin_blocks), dim3(256), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc, fin_ctl);
     else {
-      hipLaunchKernelGGL(k_irls_finish<false>, dim3(1), dim3(1024), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc);
+      hipLaunchKernelGGL(k_irls_finish<false>, dim3(fin_blocks), dim3(256), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc, fin_ctl);
       KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
       hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
     }
@@ -645,13 +785,14 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
 
     // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
     bool inner_done = false;
+    const i64 dbg_iter0 = iter; int dbg_stopk = 0;
     double accepted_sum = NAN; bool have_sum = false;
     while (!inner_done && iter < max_iter) {
       const int Kb = (int)std::min<i64>(KSPEC, max_iter - iter);
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
-      if (d <= 128 && g_in_lds) hipLaunchKernelGGL((k_cd_wave<2, true>), dim3(1), dim3(256), lds_wave, st, a);
+      if (d <= 128) hipLaunchKernelGGL(k_cd_lds2, dim3(1), dim3(1024), (size_t)(d + 1) * (CDL_STRIDE + 4) * sizeof(double), st, a);
       else if (d <= 128) hipLaunchKernelGGL((k_cd_wave<2, false>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false>), dim3(1), dim3(256), lds_wave, st, a);
@@ -681,7 +822,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       for (int k = 0; k < nd; k++) {
         th.assign(hhist.begin() + (size_t)k * d, hhist.begin() + (size_t)(k + 1) * d);
         if (eval_loss) { accepted_sum = hloss[k]; have_sum = true; }
-        if (hstop[k]) { inner_done = true; cut = (k + 1 < nd); break; }                  // coordinate.go:74-75
+        if (hstop[k]) { inner_done = true; cut = (k + 1 < nd); dbg_stopk = 1; break; }                  // coordinate.go:74-75
         // hook (kmerLr_estimator_hook.go:46-99)
         std::swap(loss_old, loss_new);
         if (eval_loss) loss_new = full_loss(th.data(), hloss[k]);
@@ -700,6 +841,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (cut) KLR_TRY(h2d(ctx, thd, th.data(), (size_t)d * 8));
       if (nd == 0) inner_done = true;
     }
+    if (getenv("KLR_CD_DEBUG")) fprintf(stderr, "[cd] d=%d inner sweeps=%lld stopf=%d\n", d, (long long)(iter - dbg_iter0), dbg_stopk);
     // ---- outer checks -----------------------------------------------------------------------------
     double dl;
     if (host_eval_stopping(tp.data(), th.data(), d, eps, &dl)) break;                   // coordinate.go:119-120
