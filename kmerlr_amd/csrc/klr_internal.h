@@ -182,7 +182,8 @@ enum { ROW_SWEEP = 0, ROW_LOSS = 1, ROW_IRLS = 2, ROW_LOGPDF = 3, ROW_SWEEP_FIX 
 //  ROW_LOGPDF: out0[i] = log sigma(r_i)
 // loss_acc_dev (nullable) is OVERWRITTEN with the local sum (deterministic two-stage reduction).
 int   launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, int mode,
-                      const double cw[2], double* out0, double* out1, double* loss_acc_dev);
+                      const double cw[2], double* out0, double* out1, double* loss_acc_dev,
+                      const double* theta_host = nullptr, i64 theta_len = 0);   // theta_host (<= 128): in the kernel arguments
 // out0 for rows when theta has only a bias (no matrix access)
 int   launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
                        double* out0, double* out1, double* loss_acc_dev);

@@ -499,7 +499,9 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
     pj += 4;                                                                                                   \
   }
 
-__global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a) {
+struct CdTheta { int n; double v[128]; };     // n > 0: the start iterate travels in the kernel arguments (no upload)
+
+__global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
   extern __shared__ double lds[];
   const int d = a.d, lane = threadIdx.x & 63;
   double* Gl = lds;                                         // (d+1) x 128
@@ -509,7 +511,8 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a) {
     const int j = t >> 7, i = t & (CDL_STRIDE - 1);
     Gl[t] = (j < d && i < d) ? a.G[(i64)j * d + i] : 0.0;
   }
-  for (int t = threadIdx.x; t < 4 * (d + 1); t += 1024) pk[t] = ((t & 3) == 3 && (t >> 2) < d) ? a.theta[t >> 2] : 0.0;
+  for (int t = threadIdx.x; t < 4 * (d + 1); t += 1024)
+    pk[t] = ((t & 3) == 3 && (t >> 2) < d) ? (th0.n > 0 ? th0.v[t >> 2] : a.theta[t >> 2]) : 0.0;
   __syncthreads();
   if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
   const int i0 = lane, i1 = 64 + lane;
@@ -730,7 +733,15 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
 
   std::vector<double> th(theta, theta + d), tp(d), hhist((size_t)KSPEC * d), hdelta(KSPEC), hloss(KSPEC);
   std::vector<int> hstop(KSPEC + 1);
-  KLR_TRY(h2d(ctx, thd, th.data(), (size_t)d * 8));
+  // the device copy of theta is refreshed lazily: a small iterate (d <= 128) rides in the kernel arguments of the
+  // next row pass / first batch of sweeps instead of a pageable upload per rewind
+  bool thd_stale = true;
+  auto sync_thd = [&]() -> int {
+    if (thd_stale) { KLR_TRY(h2d(ctx, thd, th.data(), (size_t)d * 8)); thd_stale = false; }
+    return KLR_OK;
+  };
+  const bool inline_theta = d <= 128;
+  if (!inline_theta) KLR_TRY(sync_thd());
 
   const auto t0 = std::chrono::steady_clock::now();
   const double lambda = l1reg / (double)n_total;
@@ -744,7 +755,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
 
   for (i64 iter = 0; iter < max_iter; iter++) {
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
-    KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr));
+    if (thd_stale) KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr, th.data(), d));
+    else KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr));
     // [a0 | nm | xy] = sum_i w x | sum_i w x^2 (diagonal, norm) | sum_i w z x (inner_xy): one pass, one finish
     const bool single = ctx->ar_fn == nullptr;
     double* part3;
@@ -792,7 +804,11 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
-      if (d <= 128) hipLaunchKernelGGL(k_cd_lds2, dim3(1), dim3(1024), (size_t)(d + 1) * (CDL_STRIDE + 4) * sizeof(double), st, a);
+      if (d <= 128) {
+        CdTheta t0; t0.n = 0;
+        if (thd_stale) { t0.n = d; memcpy(t0.v, th.data(), (size_t)d * 8); thd_stale = false; }   // the kernel writes thd
+        hipLaunchKernelGGL(k_cd_lds2, dim3(1), dim3(1024), (size_t)(d + 1) * (CDL_STRIDE + 4) * sizeof(double), st, a, t0);
+      }
       else if (d <= 128) hipLaunchKernelGGL((k_cd_wave<2, false>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false>), dim3(1), dim3(256), lds_wave, st, a);
@@ -838,7 +854,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         iter++;
         if (iter >= max_iter) { inner_done = true; cut = (k + 1 < nd); break; }
       }
-      if (cut) KLR_TRY(h2d(ctx, thd, th.data(), (size_t)d * 8));
+      if (cut) { thd_stale = true; if (!inline_theta) KLR_TRY(sync_thd()); }
       if (nd == 0) inner_done = true;
     }
     if (getenv("KLR_CD_DEBUG")) fprintf(stderr, "[cd] d=%d inner sweeps=%lld stopf=%d\n", d, (long long)(iter - dbg_iter0), dbg_stopk);
@@ -848,6 +864,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     if (eval_loss && eps_loss != 0.0) {
       if (!have_sum) {
         double* acc = lossb;
+        KLR_TRY(sync_thd());
         KLR_TRY(launch_row_pass(ctx, red, thd, ROW_LOSS, cw, nullptr, nullptr, acc));
         KLR_TRY(klr_allreduce(ctx, acc, 1, KLR_F64));
         KLR_TRY(d2h_sync(ctx, &accepted_sum, acc, 8));

@@ -232,8 +232,9 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
 }
 
 int launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, int mode, const double cw[2],
-                    double* out0, double* out1, double* loss_acc_dev) {
-  return row_pass_common(ctx, mat, theta_dev, 0.0, false, mode, cw, out0, out1, loss_acc_dev);
+                    double* out0, double* out1, double* loss_acc_dev, const double* theta_host, i64 theta_len) {
+  return row_pass_common(ctx, mat, theta_dev, 0.0, false, mode, cw, out0, out1, loss_acc_dev, 0.0, nullptr, nullptr,
+                         theta_host, theta_len);
 }
 
 int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
