@@ -753,7 +753,9 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     return r;
   };
 
-  for (i64 iter = 0; iter < max_iter; iter++) {
+  int relin = 0;                   // re-linearisations so far
+  const int first_k = getenv("KLR_CD_FIRST_BATCH") ? std::max(1, std::min(KSPEC, atoi(getenv("KLR_CD_FIRST_BATCH")))) : 1;
+  for (i64 iter = 0; iter < max_iter; iter++, relin++) {
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
     if (thd_stale) KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr, th.data(), d));
     else KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr));
@@ -796,11 +798,15 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     tp = th;
 
     // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
-    bool inner_done = false;
+    bool inner_done = false, first_batch = true;
     const i64 dbg_iter0 = iter; int dbg_stopk = 0;
     double accepted_sum = NAN; bool have_sum = false;
     while (!inner_done && iter < max_iter) {
-      const int Kb = (int)std::min<i64>(KSPEC, max_iter - iter);
+      // sweeps are launched in speculative batches; the loss rule usually ends the inner loop of a LATER
+      // re-linearisation at its first sweep (the model barely moves any more): probe with one sweep first
+      const bool probe = relin >= 1 && first_batch && eps_loss != 0.0;
+      first_batch = false;
+      const int Kb = (int)std::min<i64>(probe ? first_k : KSPEC, max_iter - iter);
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
