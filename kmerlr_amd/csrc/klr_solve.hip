@@ -501,99 +501,128 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
 
 struct CdTheta { int n; double v[128]; };     // n > 0: the start iterate travels in the kernel arguments (no upload)
 
+struct CdlLane { double xy0, xy1, dg0, dg1, inv0, inv1; };
+
+// stage the Gram matrix and the start iterate (all threads of the block), then __syncthreads
+__device__ __forceinline__ void cdl_stage(const CdArgs& a, const CdTheta& th0, double* Gl, double* pk) {
+  const int d = a.d;
+#pragma unroll 4
+  for (int t = threadIdx.x; t < (d + 1) * CDL_STRIDE; t += blockDim.x) {
+    const int j = t >> 7, i = t & (CDL_STRIDE - 1);
+    Gl[t] = (j < d && i < d) ? a.G[(i64)j * d + i] : 0.0;
+  }
+  for (int t = threadIdx.x; t < 4 * (d + 1); t += blockDim.x)
+    pk[t] = ((t & 3) == 3 && (t >> 2) < d) ? (th0.n > 0 ? th0.v[t >> 2] : a.theta[t >> 2]) : 0.0;
+  __syncthreads();
+}
+
+// per-lane constants and q = G theta (skipping zero coefficients); one wavefront
+__device__ __forceinline__ void cdl_init(const CdArgs& a, int lane, const double* Gl, const double* pk, CdlLane& c,
+                                         double& q0, double& q1) {
+  const int d = a.d, i0 = lane, i1 = 64 + lane;
+  c.xy0 = i0 < d ? a.xy[i0] : 0.0; c.xy1 = i1 < d ? a.xy[i1] : 0.0;
+  c.dg0 = i0 < d ? Gl[(size_t)i0 * CDL_STRIDE + i0] : 1.0; c.dg1 = i1 < d ? Gl[(size_t)i1 * CDL_STRIDE + i1] : 1.0;
+  c.inv0 = 1.0 / (c.dg0 + a.l2reg); c.inv1 = 1.0 / (c.dg1 + a.l2reg);      // :69 as a reciprocal (<= 1 ulp)
+  q0 = 0.0; q1 = 0.0;
+  for (int k = 0; k < d; k++) {
+    const double t = pk[4 * k + 3];
+    if (t != 0.0) { q0 += Gl[(size_t)k * CDL_STRIDE + i0] * t; q1 += Gl[(size_t)k * CDL_STRIDE + i1] * t; }
+  }
+}
+
+// one sweep over all coordinates; told = the iterate before it (this lane's two coordinates)
+__device__ __forceinline__ void cdl_sweep(int d, int lane, const double* Gl, double* pk, const CdlLane& c, double l1,
+                                          int zero_v, double& q0, double& q1, double& told0, double& told1) {
+  const int i0 = lane, i1 = 64 + lane;
+  told0 = 0.0; told1 = 0.0;
+  if (i0 < d) { const double t = pk[4 * i0 + 3]; told0 = t; pk[4 * i0] = c.xy0 + c.dg0 * t; pk[4 * i0 + 1] = t; pk[4 * i0 + 2] = c.inv0; }   // :56
+  if (i1 < d) { const double t = pk[4 * i1 + 3]; told1 = t; pk[4 * i1] = c.xy1 + c.dg1 * t; pk[4 * i1 + 1] = t; pk[4 * i1 + 2] = c.inv1; }
+  __builtin_amdgcn_wave_barrier();
+  double gA0 = Gl[i0], gA1 = Gl[i1], cA = pk[0], oA = pk[1], iA = pk[2];
+  double gB0, gB1, cB, oB, iB;
+  const double* grow = Gl + CDL_STRIDE + lane;        // row 1
+  double* pj = pk + zero_v;                           // coordinate 0
+  {
+    const int j1 = d < 64 ? d : 64;
+    int j = 0;
+    CDL_STEP(q0, j, 0.0, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);     // the bias is not penalised (:60)
+    j++;
+    if (j < j1) { CDL_STEP(q0, j, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA); j++; }
+    else { gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB; }            // d == 1: keep the sets aligned
+    for (; j + 1 < j1; j += 2) {
+      CDL_STEP(q0, j, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+      CDL_STEP(q0, j + 1, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA);
+    }
+    if (j < j1) {
+      CDL_STEP(q0, j, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+      gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB;
+    }
+  }
+  {
+    int j = 64;
+    for (; j + 1 < d; j += 2) {
+      CDL_STEP(q1, j - 64, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+      CDL_STEP(q1, j - 63, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA);
+    }
+    if (j < d) {
+      CDL_STEP(q1, j - 64, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
+      gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// eval_stopping (proximal.go:30-52) from the old and the new iterate, lane parallel; also the nonzero count
+__device__ __forceinline__ void cdl_stop(int d, int lane, const double* pk, double told0, double told1, double eps,
+                                         double& tn0, double& tn1, double& delta, int& stop, int& nz) {
+  const int i0 = lane, i1 = 64 + lane;
+  double max_x = 0.0, max_delta = 0.0;
+  int isnan_ = 0;
+  tn0 = 0.0; tn1 = 0.0;
+  if (i0 < d) {
+    tn0 = pk[4 * i0 + 3];
+    isnan_ |= (tn0 != tn0) ? 1 : 0;
+    max_x = fmax(max_x, fabs(tn0));
+    max_delta = fmax(max_delta, fabs(tn0 - told0));
+  }
+  if (i1 < d) {
+    tn1 = pk[4 * i1 + 3];
+    isnan_ |= (tn1 != tn1) ? 1 : 0;
+    max_x = fmax(max_x, fabs(tn1));
+    max_delta = fmax(max_delta, fabs(tn1 - told1));
+  }
+  nz = __popcll(__ballot(i0 < d && tn0 != 0.0)) + __popcll(__ballot(i1 < d && tn1 != 0.0));
+  for (int o = 32; o > 0; o >>= 1) {
+    max_x = fmax(max_x, __shfl_xor(max_x, o, 64));
+    max_delta = fmax(max_delta, __shfl_xor(max_delta, o, 64));
+    isnan_ |= __shfl_xor(isnan_, o, 64);
+  }
+  if (isnan_) { delta = nan(""); stop = 1; }
+  else {
+    delta = (max_x != 0.0) ? max_delta / max_x : max_delta;
+    stop = ((max_x != 0.0 && max_delta / max_x <= eps) || (max_x == 0.0 && max_delta == 0.0)) ? 1 : 0;
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
   extern __shared__ double lds[];
   const int d = a.d, lane = threadIdx.x & 63;
   double* Gl = lds;                                         // (d+1) x 128
   double* pk = lds + (size_t)(d + 1) * CDL_STRIDE;          // (d+1) x 4
-#pragma unroll 4
-  for (int t = threadIdx.x; t < (d + 1) * CDL_STRIDE; t += 1024) {
-    const int j = t >> 7, i = t & (CDL_STRIDE - 1);
-    Gl[t] = (j < d && i < d) ? a.G[(i64)j * d + i] : 0.0;
-  }
-  for (int t = threadIdx.x; t < 4 * (d + 1); t += 1024)
-    pk[t] = ((t & 3) == 3 && (t >> 2) < d) ? (th0.n > 0 ? th0.v[t >> 2] : a.theta[t >> 2]) : 0.0;
-  __syncthreads();
+  cdl_stage(a, th0, Gl, pk);
   if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
-  const int i0 = lane, i1 = 64 + lane;
-  const double xy0 = i0 < d ? a.xy[i0] : 0.0, xy1 = i1 < d ? a.xy[i1] : 0.0;
-  const double dg0 = i0 < d ? Gl[(size_t)i0 * CDL_STRIDE + i0] : 1.0, dg1 = i1 < d ? Gl[(size_t)i1 * CDL_STRIDE + i1] : 1.0;
-  const double inv0 = 1.0 / (dg0 + a.l2reg), inv1 = 1.0 / (dg1 + a.l2reg);      // :69 as a reciprocal (<= 1 ulp)
-  double q0 = 0.0, q1 = 0.0;
-  // q = G theta (skipping zero coefficients)
-  for (int k = 0; k < d; k++) {
-    const double t = pk[4 * k + 3];
-    if (t != 0.0) { q0 += Gl[(size_t)k * CDL_STRIDE + i0] * t; q1 += Gl[(size_t)k * CDL_STRIDE + i1] * t; }
-  }
+  CdlLane c; double q0, q1;
+  cdl_init(a, lane, Gl, pk, c, q0, q1);
   int zero_v;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));      // opaque: keeps the operand pointer in a vector register
-  const double l1 = a.l1reg;
+  const int i0 = lane, i1 = 64 + lane;
   int done = 0;
   for (int k = 0; k < a.K; k++) {
-    double told0 = 0.0, told1 = 0.0;
-    if (i0 < d) { const double t = pk[4 * i0 + 3]; told0 = t; pk[4 * i0] = xy0 + dg0 * t; pk[4 * i0 + 1] = t; pk[4 * i0 + 2] = inv0; }   // :56
-    if (i1 < d) { const double t = pk[4 * i1 + 3]; told1 = t; pk[4 * i1] = xy1 + dg1 * t; pk[4 * i1 + 1] = t; pk[4 * i1 + 2] = inv1; }
-    __builtin_amdgcn_wave_barrier();
-    double gA0 = Gl[i0], gA1 = Gl[i1], cA = pk[0], oA = pk[1], iA = pk[2];
-    double gB0, gB1, cB, oB, iB;
-    const double* grow = Gl + CDL_STRIDE + lane;        // row 1
-    double* pj = pk + zero_v;                           // coordinate 0
-    {
-      const int j1 = d < 64 ? d : 64;
-      int j = 0;
-      CDL_STEP(q0, j, 0.0, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);     // the bias is not penalised (:60)
-      j++;
-      if (j < j1) { CDL_STEP(q0, j, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA); j++; }
-      else { gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB; }            // d == 1: keep the sets aligned
-      for (; j + 1 < j1; j += 2) {
-        CDL_STEP(q0, j, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
-        CDL_STEP(q0, j + 1, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA);
-      }
-      if (j < j1) {
-        CDL_STEP(q0, j, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
-        gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB;
-      }
-    }
-    {
-      int j = 64;
-      for (; j + 1 < d; j += 2) {
-        CDL_STEP(q1, j - 64, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
-        CDL_STEP(q1, j - 63, l1, gB0, gB1, cB, oB, iB, gA0, gA1, cA, oA, iA);
-      }
-      if (j < d) {
-        CDL_STEP(q1, j - 64, l1, gA0, gA1, cA, oA, iA, gB0, gB1, cB, oB, iB);
-        gA0 = gB0; gA1 = gB1; cA = cB; oA = oB; iA = iB;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // eval_stopping (proximal.go:30-52) from the old and the new iterate, lane parallel
-    double max_x = 0.0, max_delta = 0.0;
-    int isnan_ = 0;
-    if (i0 < d) {
-      const double tn = pk[4 * i0 + 3];
-      a.hist[(i64)k * d + i0] = tn;
-      isnan_ |= (tn != tn) ? 1 : 0;
-      max_x = fmax(max_x, fabs(tn));
-      max_delta = fmax(max_delta, fabs(tn - told0));
-    }
-    if (i1 < d) {
-      const double tn = pk[4 * i1 + 3];
-      a.hist[(i64)k * d + i1] = tn;
-      isnan_ |= (tn != tn) ? 1 : 0;
-      max_x = fmax(max_x, fabs(tn));
-      max_delta = fmax(max_delta, fabs(tn - told1));
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      max_x = fmax(max_x, __shfl_xor(max_x, o, 64));
-      max_delta = fmax(max_delta, __shfl_xor(max_delta, o, 64));
-      isnan_ |= __shfl_xor(isnan_, o, 64);
-    }
-    double delta; int stop;
-    if (isnan_) { delta = nan(""); stop = 1; }
-    else {
-      delta = (max_x != 0.0) ? max_delta / max_x : max_delta;
-      stop = ((max_x != 0.0 && max_delta / max_x <= a.eps) || (max_x == 0.0 && max_delta == 0.0)) ? 1 : 0;
-    }
+    double told0, told1, tn0, tn1, delta; int stop, nz;
+    cdl_sweep(d, lane, Gl, pk, c, a.l1reg, zero_v, q0, q1, told0, told1);
+    cdl_stop(d, lane, pk, told0, told1, a.eps, tn0, tn1, delta, stop, nz);
+    if (i0 < d) a.hist[(i64)k * d + i0] = tn0;
+    if (i1 < d) a.hist[(i64)k * d + i1] = tn1;
     if (lane == 0) { a.delta[k] = delta; a.stopf[k] = stop; }
     done = k + 1;
     if (stop) break;
@@ -602,6 +631,7 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
   if (i1 < d) a.theta[i1] = pk[4 * i1 + 3];
   if (lane == 0) *a.ndone = done;
 }
+
 #undef CDL_STEP
 
 // log-loss of up to KSPEC iterates in one pass over the reduced rows: lane (row, k) -- 8 lanes per row, one per
