@@ -25,7 +25,7 @@ void mat_free(klr_mat* m) {
   (void)hipSetDevice(m->device);
   if (m->arena) {
     // a reduced matrix: one pooled block; the context hands it to the next column sub-select in stream order
-    if (ctx_alive(m->ctx)) pool_put(m->ctx, m->arena, m->arena_cap);
+    if (ctx_alive(m->ctx) && m->ctx->device == m->device) pool_put(m->ctx, m->arena, m->arena_cap);
     else { (void)hipDeviceSynchronize(); (void)hipFree(m->arena); }
     delete m;
     return;
