@@ -154,6 +154,99 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
   }
 }
 
+// 128 < d <= 1024: the integer Gram no longer fits LDS and global 64-bit atomics run at ~20 G/s at the memory side
+// (440 us per re-linearisation for 5.6M pairs at d = 501).  The Gram is cut into GT x GT tiles; workgroup
+// (row group g, tile pair A <= B) privatises ONE tile in LDS (128 KiB), walks its rows with the same 16-lane DPP
+// scheme and keeps the pairs (ja in A, jb in B); partial tiles are summed by k_gram_tiled_reduce.  The rows are read
+// once per tile pair (they are short and L2 resident); the pair work is the same in total.
+#define GT 128
+template <int O>
+__device__ __forceinline__ void dpp_pairs_tiled(int arow, int ja, double wa, int jc_own, double vc_own, int B0,
+                                                unsigned long long* acc) {
+  if constexpr (O < 16) {
+    int jc; double vc;
+    if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
+    else {
+      constexpr int ctrl = 0x120 + O;                 // row_ror:O
+      jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
+      vc = __hiloint2double(hi, lo);
+    }
+    const unsigned cb = (unsigned)(jc - B0);
+    if (arow >= 0 && jc > ja && cb < (unsigned)GT) atomicAdd(&acc[arow + (int)cb], (unsigned long long)__double2ll_rn(wa * vc));
+    dpp_pairs_tiled<O + 1>(arow, ja, wa, jc_own, vc_own, B0, acc);
+  }
+}
+
+__device__ __forceinline__ void gram_tile_pair(int p, int nt, int& A, int& B) {       // p-th pair (A <= B), row major
+  A = 0;
+  while (p >= nt - A) { p -= nt - A; A++; }
+  B = A + p;
+}
+
+__global__ __launch_bounds__(1024) void k_gram_offdiag_tiled(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                             const double* __restrict__ val, const double* __restrict__ w,
+                                                             i64 n, int d, const double* __restrict__ sc,
+                                                             unsigned long long* __restrict__ part) {
+  extern __shared__ unsigned long long gl[];
+  for (int t = threadIdx.x; t < GT * GT; t += 1024) gl[t] = 0ull;
+  __syncthreads();
+  const int nt = (d + GT - 1) / GT;
+  int A, B;
+  gram_tile_pair((int)blockIdx.y, nt, A, B);
+  const int A0 = A * GT, B0 = B * GT;
+  const double s0 = sc[0];
+  const int lane = threadIdx.x & 15;
+  const i64 grp0 = ((i64)blockIdx.x * 1024 + threadIdx.x) >> 4, ngrp = ((i64)gridDim.x * 1024) >> 4;
+  for (i64 i = grp0; i < n; i += ngrp) {
+    const i64 b = rowptr[i] + 1, e = rowptr[i + 1];            // skip the bias entry
+    const double wi = w[i] * s0;
+    for (i64 a0 = b; a0 < e; a0 += 16) {
+      const bool ha = a0 + lane < e;
+      const int ja = ha ? (int)col[a0 + lane] : 0;
+      const double wa = ha ? wi * val[a0 + lane] : 0.0;
+      const unsigned ab = (unsigned)(ja - A0);
+      const int arow = (ha && ab < (unsigned)GT) ? (int)ab * GT : -1;
+      for (i64 c0 = a0; c0 < e; c0 += 16) {
+        const bool hc = c0 + lane < e;
+        const int jc_own = hc ? (int)col[c0 + lane] : -1;
+        const double vc_own = hc ? val[c0 + lane] : 0.0;
+        dpp_pairs_tiled<0>(arow, ja, wa, jc_own, vc_own, B0, gl);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (GT * GT);
+  for (int t = threadIdx.x; t < GT * GT; t += 1024) out[t] = gl[t];
+}
+
+// cell (j, k), 1 <= j < k: the sum of its tile's partials in group order.  G != null (single rank): G[j][k] =
+// G[k][j] = sum * 2^-E and row / column 0 and the diagonal from the column sums; else Gi[j][k] = sum (all-reduced and
+// assembled by the caller).
+__global__ __launch_bounds__(256) void k_gram_tiled_reduce(const unsigned long long* __restrict__ part, int d, int ngroups,
+                                                           const double* __restrict__ a0, const double* __restrict__ nm,
+                                                           const double* __restrict__ sc, double* __restrict__ G,
+                                                           i64* __restrict__ Gi) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)d * d) return;
+  const int j = (int)(t / d), k = (int)(t % d);
+  if (j >= 1 && j < k) {
+    const int nt = (d + GT - 1) / GT;
+    const int A = j / GT, B = k / GT;
+    const int p = A * nt - A * (A - 1) / 2 + (B - A);
+    const unsigned long long* src = part + (size_t)p * ngroups * (GT * GT) + (size_t)(j - A * GT) * GT + (k - B * GT);
+    unsigned long long v = 0ull;
+    for (int g = 0; g < ngroups; g++) v += src[(size_t)g * (GT * GT)];
+    if (G) { const double x = (double)(i64)v * sc[1]; G[(i64)j * d + k] = x; G[(i64)k * d + j] = x; }
+    else Gi[t] = (i64)v;
+  } else if (G) {
+    if (j == k) G[t] = nm[j];
+    else if (j == 0) G[t] = a0[k];
+    else if (k == 0) G[t] = a0[j];
+  } else Gi[t] = 0;
+}
+
 // 64 cells x 4 partial lanes per block, 8 loads in flight per lane (one lane walking all 256 partials of a cell
 // took 66 us for 21 MB)
 __global__ __launch_bounds__(256) void k_gram_reduce(unsigned long long* __restrict__ Gi, int dd, int nblk) {
@@ -742,9 +835,21 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // row): then zeroing, writing and re-reading one 80 KiB partial per workgroup is the whole cost (150 us per
   // re-weighting at configs[2]) and plain global integer atomics are the cheaper build
   const double est_pairs = (double)n * std::max(0.0, red->avg_row - 1.0) * std::max(0.0, red->avg_row - 2.0) * 0.5 + (double)n;
-  const bool gram_lds = (size_t)d * d * 8 <= 128 * 1024 && est_pairs > 4e6;
+  // KLR_GRAM_PATH=lds|global forces the privatised (LDS / tiled) or the global-atomics build (tests)
+  const char* gram_env = getenv("KLR_GRAM_PATH");
+  const bool gram_many = gram_env ? (gram_env[0] == 'l') : est_pairs > 4e6;
+  const bool gram_lds = (size_t)d * d * 8 <= 128 * 1024 && gram_many;
   const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
-  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)(2 + gram_blocks) * d * d * 8, (void**)&G));
+  // 128 < d <= 1024 with many pairs: tile pairs privatised in LDS (k_gram_offdiag_tiled)
+  const int gram_nt = (d + GT - 1) / GT, gram_npairs = gram_nt * (gram_nt + 1) / 2;
+  const bool gram_tiled = !gram_lds && (size_t)d * d * 8 > 128 * 1024 && d <= 1024 && gram_many;
+  const unsigned gram_groups = gram_tiled ? (unsigned)std::max<i64>(1, std::min<i64>(std::max(1, ctx->n_cu / gram_npairs), ceil_div(n * 16, 4 * 1024))) : 0u;
+  if (gram_tiled) {
+    static bool attr = false;
+    if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, GT * GT * 8)); attr = true; }
+  }
+  const size_t gram_part_bytes = gram_tiled ? (size_t)gram_npairs * gram_groups * GT * GT * 8 : (size_t)gram_blocks * d * d * 8;
+  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8 + gram_part_bytes, (void**)&G));
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
   // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
@@ -801,7 +906,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
     }
     // the LDS-privatised build writes whole partials and the reduce overwrites the result slot: nothing to zero
-    if (!gram_lds || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
+    if ((!gram_lds && !gram_tiled) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     bool assembled = false;
     if (n) {
       if (gram_lds) {
@@ -814,6 +919,13 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         } else
           hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
                              d * d, (int)gram_blocks);
+      } else if (gram_tiled) {
+        unsigned long long* gpart = (unsigned long long*)(Gi + (size_t)d * d);
+        hipLaunchKernelGGL(k_gram_offdiag_tiled, dim3(gram_groups, (unsigned)gram_npairs), dim3(1024), (size_t)GT * GT * 8, st,
+                           red->rowptr, red->col, (const double*)red->val, w, n, d, gsc, gpart);
+        hipLaunchKernelGGL(k_gram_tiled_reduce, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st,
+                           (const unsigned long long*)gpart, d, (int)gram_groups, a0, nm, gsc, single ? G : (double*)nullptr, Gi);
+        assembled = single;
       } else {
         const unsigned gb = (unsigned)std::max<i64>(1, std::min<i64>(4 * ctx->n_cu, ceil_div(n * 16, 1024)));
         hipLaunchKernelGGL(k_gram_offdiag<false>, dim3(gb), dim3(1024), 0, st, red->rowptr, red->col,

@@ -431,10 +431,14 @@ def test_full_size_properties(ctx):
     assert np.max(np.abs(ra["g"] - g_lin)) <= 1e-12 * np.max(np.abs(g_lin))
 
 
+@pytest.mark.parametrize("gram_path", [None, "lds", "global"])
 @pytest.mark.parametrize("N", [40, 150, 300, 560])
-def test_cd_solve_solver_variants(ctx, N):
+def test_cd_solve_solver_variants(ctx, N, gram_path, monkeypatch):
     """d = N+1 selects the solver kernel: one wavefront with 2/4/8 q values per lane, or the workgroup
-    version; all must follow the oracle's iterate sequence."""
+    version; all must follow the oracle's iterate sequence.  gram_path forces the Gram build: privatised in LDS
+    (d <= 128: whole, d <= 1024: tile pairs) or global integer atomics -- the default picks by the number of pairs."""
+    if gram_path:
+        monkeypatch.setenv("KLR_GRAM_PATH", gram_path)
     x, labels = O.synth_csr(77, 0, 3000, 3000, 8192, 400, 2 * N)
     m = upload(ctx, x, labels)
     cw = O.class_weights(labels)
