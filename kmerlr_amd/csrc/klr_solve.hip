@@ -199,20 +199,46 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag_tiled(const i64* __restri
   const double s0 = sc[0];
   const int lane = threadIdx.x & 15;
   const i64 grp0 = ((i64)blockIdx.x * 1024 + threadIdx.x) >> 4, ngrp = ((i64)gridDim.x * 1024) >> 4;
-  for (i64 i = grp0; i < n; i += ngrp) {
-    const i64 b = rowptr[i] + 1, e = rowptr[i + 1];            // skip the bias entry
-    const double wi = w[i] * s0;
-    for (i64 a0 = b; a0 < e; a0 += 16) {
-      const bool ha = a0 + lane < e;
-      const int ja = ha ? (int)col[a0 + lane] : 0;
-      const double wa = ha ? wi * val[a0 + lane] : 0.0;
-      const unsigned ab = (unsigned)(ja - A0);
-      const int arow = (ha && ab < (unsigned)GT) ? (int)ab * GT : -1;
-      for (i64 c0 = a0; c0 < e; c0 += 16) {
-        const bool hc = c0 + lane < e;
-        const int jc_own = hc ? (int)col[c0 + lane] : -1;
-        const double vc_own = hc ? val[c0 + lane] : 0.0;
-        dpp_pairs_tiled<0>(arow, ja, wa, jc_own, vc_own, B0, gl);
+  // a workgroup walks thousands of rows here (the grid is tile pairs x row groups): four rows per trip, their
+  // offsets and first 16 entries loaded together, or every row is two dependent round trips to L2
+  constexpr int RB = 4;
+  for (i64 i0 = grp0; i0 < n; i0 += RB * ngrp) {
+    i64 rb[RB], re[RB]; double rw[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const i64 i = i0 + r * ngrp;
+      const bool ok = i < n;
+      rb[r] = ok ? rowptr[i] + 1 : 0;                           // skip the bias entry
+      re[r] = ok ? rowptr[i + 1] : 0;
+      rw[r] = ok ? w[i] : 0.0;
+    }
+    int fj[RB]; double fv[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const bool h = rb[r] + lane < re[r];
+      fj[r] = h ? (int)col[rb[r] + lane] : -1;
+      fv[r] = h ? val[rb[r] + lane] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const i64 b = rb[r], e = re[r];
+      const double wi = rw[r] * s0;
+      for (i64 a0 = b; a0 < e; a0 += 16) {
+        int ja_raw; double va_raw;
+        if (a0 == b) { ja_raw = fj[r]; va_raw = fv[r]; }
+        else { const bool h = a0 + lane < e; ja_raw = h ? (int)col[a0 + lane] : -1; va_raw = h ? val[a0 + lane] : 0.0; }
+        const bool ha = ja_raw >= 0;
+        const int ja = ha ? ja_raw : 0;
+        const double wa = ha ? wi * va_raw : 0.0;
+        const unsigned ab = (unsigned)(ja - A0);
+        const int arow = (ha && ab < (unsigned)GT) ? (int)ab * GT : -1;
+        dpp_pairs_tiled<0>(arow, ja, wa, ja_raw, va_raw, B0, gl);          // partners inside the same 16 entries
+        for (i64 c0 = a0 + 16; c0 < e; c0 += 16) {
+          const bool hc = c0 + lane < e;
+          const int jc_own = hc ? (int)col[c0 + lane] : -1;
+          const double vc_own = hc ? val[c0 + lane] : 0.0;
+          dpp_pairs_tiled<0>(arow, ja, wa, jc_own, vc_own, B0, gl);
+        }
       }
     }
   }
@@ -324,6 +350,8 @@ struct CdArgs {
   int* stopf;                 // K eval_stopping verdicts
   int* ndone;
   int g_in_lds;
+  double* q_io;               // k_cd_wave: q = G theta is stored here at exit and, with q_load, taken from here at entry
+  int q_load;
 };
 
 // One workgroup.  LDS: theta[d], q[d], diag[d], xyv[d] (+ G[d*d] when it fits); up to d = 4900.
@@ -477,12 +505,19 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
     if (i < d) thl[i] = a.theta[i];
   }
   __builtin_amdgcn_wave_barrier();                     // single wave from here on: LDS ops are in order
-  // q = G theta (skipping zero coefficients)
-  for (int k = 0; k < d; k++) {
-    const double t = thl[k];
-    if (t != 0.0) {
+  if (a.q_load) {
+    // q comes from the previous batch of the same inner loop, or from k_gtheta: one wavefront walking all d rows
+    // of a Gram matrix in L2 for every batch was 150 us at d = 501
 #pragma unroll
-      for (int s = 0; s < QPL; s++) q[s] += gram_at<GLDS>(Gg, (i64)k * d + off[s]) * t;
+    for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; q[s] = i < d ? a.q_io[i] : 0.0; }
+  } else {
+    // q = G theta (skipping zero coefficients)
+    for (int k = 0; k < d; k++) {
+      const double t = thl[k];
+      if (t != 0.0) {
+#pragma unroll
+        for (int s = 0; s < QPL; s++) q[s] += gram_at<GLDS>(Gg, (i64)k * d + off[s]) * t;
+      }
     }
   }
   int done = 0;
@@ -562,10 +597,24 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
     if (stop) break;
   }
 #pragma unroll
-  for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) a.theta[i] = thl[i]; }
+  for (int s = 0; s < QPL; s++) { const int i = s * 64 + lane; if (i < d) { a.theta[i] = thl[i]; if (a.q_io) a.q_io[i] = q[s]; } }
   if (lane == 0) *a.ndone = done;
 }
 #undef CD_STEP
+
+// q = G theta (zero coefficients skipped, k ascending: the same sums as the in-kernel loop), a wavefront per 64
+// coordinates instead of one wavefront for all of them
+__global__ __launch_bounds__(64) void k_gtheta(const double* __restrict__ G, const double* __restrict__ theta, int d,
+                                               double* __restrict__ q) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int ic = i < d ? i : d - 1;
+  double s = 0.0;
+  for (int k = 0; k < d; k++) {
+    const double t = theta[k];
+    if (t != 0.0) s += G[(i64)k * d + ic] * t;
+  }
+  if (i < d) q[i] = s;
+}
 
 // d <= 128: the same wave-synchronous sweeps with every operand in LDS at padded strides, so that a step is its
 // arithmetic chain and little else (a single wavefront pays ~4-8 cycles of issue per instruction of ANY kind; the
@@ -853,13 +902,14 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
   // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
-  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16;
+  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16 + (size_t)d * 8;
   KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
   double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d; double* hist = thd + d;
   double* delta = hist + (size_t)KSPEC * d; double* losses = delta + KSPEC; double* gsc = losses + KSPEC;
   int* stopf = (int*)(gsc + 2); int* ndone = stopf + KSPEC;
   unsigned long long* fin_ctl = (unsigned long long*)(stopf + KSPEC + 8);     // {ticket, max bits} of k_irls_finish
   KLR_HIP(ctx, hipMemsetAsync(fin_ctl, 0, 16, st));
+  double* q_dev = (double*)(fin_ctl + 2);                                      // q = G theta between batches (k_cd_wave)
   const size_t report_bytes = ((size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 1) * sizeof(int);
   char* pin_report;
   KLR_TRY(pin_get(ctx, report_bytes, (void**)&pin_report));
@@ -890,6 +940,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
 
   int relin = 0;                   // re-linearisations so far
   const int first_k = getenv("KLR_CD_FIRST_BATCH") ? std::max(1, std::min(KSPEC, atoi(getenv("KLR_CD_FIRST_BATCH")))) : 1;
+  // sweeps per speculative batch: a batch costs ~45 us beside its sweeps (launches, loss pass, report, host turn) and
+  // wastes (K-1)/2 sweeps on average when the loss rule stops it; a sweep is ~8 us at d = 101 and ~67 us at d = 501:
+  // small problems want full batches, large ones shorter ones (measured at d = 501: 8 -> 190 ms, 4 -> 180, 2 -> 187)
+  const int batch_k = getenv("KLR_CD_BATCH") ? std::max(1, std::min(KSPEC, atoi(getenv("KLR_CD_BATCH")))) : (d <= 128 ? KSPEC : KSPEC / 2);
   for (i64 iter = 0; iter < max_iter; iter++, relin++) {
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
     if (thd_stale) KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr, th.data(), d));
@@ -941,6 +995,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
 
     // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
     bool inner_done = false, first_batch = true;
+    bool q_stale = true;             // a new Gram matrix
     const i64 dbg_iter0 = iter; int dbg_stopk = 0;
     double accepted_sum = NAN; bool have_sum = false;
     while (!inner_done && iter < max_iter) {
@@ -948,10 +1003,16 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       // re-linearisation at its first sweep (the model barely moves any more): probe with one sweep first
       const bool probe = relin >= 1 && first_batch && eps_loss != 0.0;
       first_batch = false;
-      const int Kb = (int)std::min<i64>(probe ? first_k : KSPEC, max_iter - iter);
+      const int Kb = (int)std::min<i64>(probe ? first_k : batch_k, max_iter - iter);
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
+      a.q_io = nullptr; a.q_load = 0;
+      if (d > 128 && d <= 512) {
+        a.q_io = q_dev; a.q_load = 1;
+        if (q_stale) hipLaunchKernelGGL(k_gtheta, dim3((unsigned)ceil_div((i64)d, (i64)64)), dim3(64), 0, st, G, thd, d, q_dev);
+        q_stale = false;
+      }
       if (d <= 128) {
         CdTheta t0; t0.n = 0;
         if (thd_stale) { t0.n = d; memcpy(t0.v, th.data(), (size_t)d * 8); thd_stale = false; }   // the kernel writes thd
@@ -962,7 +1023,9 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false>), dim3(1), dim3(256), lds_wave, st, a);
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
-        if ((size_t)KSPEC * d * 8 <= 48 * 1024)
+        // iterates staged in LDS only while that is cheaper than reading them where they are: a block of 32 rows
+        // stages KSPEC * d values but uses ~KSPEC * 32 * (row length) of them
+        if ((double)d <= 32.0 * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024)
           hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nb), dim3(256), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
         else
@@ -1002,7 +1065,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         iter++;
         if (iter >= max_iter) { inner_done = true; cut = (k + 1 < nd); break; }
       }
-      if (cut) { thd_stale = true; if (!inline_theta) KLR_TRY(sync_thd()); }
+      if (cut) { thd_stale = true; q_stale = true; if (!inline_theta) KLR_TRY(sync_thd()); }
       if (nd == 0) inner_done = true;
     }
     if (getenv("KLR_CD_DEBUG")) fprintf(stderr, "[cd] d=%d inner sweeps=%lld stopf=%d\n", d, (long long)(iter - dbg_iter0), dbg_stopk);
