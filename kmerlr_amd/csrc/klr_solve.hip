@@ -99,20 +99,26 @@ __global__ __launch_bounds__(256) void k_irls_finish(const i64* __restrict__ col
 // LDSACC: the d x d integer Gram is privatised in LDS (d*d*8 <= 128 KiB) and written out as one partial per
 // workgroup (summed by k_gram_reduce); otherwise global integer atomics.
 template <int O>
-__device__ __forceinline__ void dpp_pairs(bool ha, int ja, double wa, int jc_own, double vc_own, int d, unsigned long long* acc) {
+__device__ __forceinline__ void dpp_pairs(bool ha, int ja, double wa, int jc_own, double vc_own, int d, unsigned long long* acc,
+                                          int nrot) {
   if constexpr (O < 16) {
-    int jc; double vc;
-    if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
-    else {
-      constexpr int ctrl = 0x120 + O;                 // row_ror:O -> lane l receives lane (l + O) & 15 of its row
-      jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
-      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
-      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
-      vc = __hiloint2double(hi, lo);
+    // row_ror:O rotates right: lane l receives lane (l - O) & 15, i.e. the entry 16 - O places further on.  Inside
+    // the same 16 entries a row of at most nrot entries has partners 1 .. nrot - 1 places on: rotations 17 - nrot .. 15
+    // (nrot is the same for every active lane; 16 = all rotations, a different chunk of the row)
+    if (O == 0 || O > 16 - nrot) {
+      int jc; double vc;
+      if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
+      else {
+        constexpr int ctrl = 0x120 + O;
+        jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
+        vc = __hiloint2double(hi, lo);
+      }
+      // columns ascend inside a row: the pair is taken once, with ja < jc
+      if (ha && jc > ja) atomicAdd(&acc[ja * d + jc], (unsigned long long)__double2ll_rn(wa * vc));
     }
-    // columns ascend inside a row: the pair is taken once, with ja < jc
-    if (ha && jc > ja) atomicAdd(&acc[ja * d + jc], (unsigned long long)__double2ll_rn(wa * vc));
-    dpp_pairs<O + 1>(ha, ja, wa, jc_own, vc_own, d, acc);
+    dpp_pairs<O + 1>(ha, ja, wa, jc_own, vc_own, d, acc, nrot);
   }
 }
 
@@ -142,8 +148,15 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
         const bool hc = c0 + lane < e;
         const int jc_own = hc ? (int)col[c0 + lane] : -1;
         const double vc_own = hc ? val[c0 + lane] : 0.0;
-        // the 16 lanes of a row are one DPP row: partner o arrives by a row rotation (VALU, no LDS round trip)
-        dpp_pairs<0>(ha, ja, wa, jc_own, vc_own, d, acc);
+        // the 16 lanes of a row are one DPP row: partners arrive by row rotations (VALU, no LDS round trip);
+        // inside the same 16 entries only the rotations that reach 1 .. (longest row of the wavefront) - 1 places on
+        int nrot = 16;
+        if (c0 == a0) {
+          const unsigned long long hm = __ballot(ha);
+          const unsigned m16 = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xFFFFull);
+          nrot = 32 - __clz((int)m16);
+        }
+        dpp_pairs<0>(ha, ja, wa, jc_own, vc_own, d, acc, nrot);
       }
     }
   }
@@ -162,20 +175,22 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
 #define GT 128
 template <int O>
 __device__ __forceinline__ void dpp_pairs_tiled(int arow, int ja, double wa, int jc_own, double vc_own, int B0,
-                                                unsigned long long* acc) {
+                                                unsigned long long* acc, int nrot) {
   if constexpr (O < 16) {
-    int jc; double vc;
-    if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
-    else {
-      constexpr int ctrl = 0x120 + O;                 // row_ror:O
-      jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
-      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
-      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
-      vc = __hiloint2double(hi, lo);
+    if (O == 0 || O > 16 - nrot) {                    // see dpp_pairs
+      int jc; double vc;
+      if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
+      else {
+        constexpr int ctrl = 0x120 + O;               // row_ror:O
+        jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
+        vc = __hiloint2double(hi, lo);
+      }
+      const unsigned cb = (unsigned)(jc - B0);
+      if (arow >= 0 && jc > ja && cb < (unsigned)GT) atomicAdd(&acc[arow + (int)cb], (unsigned long long)__double2ll_rn(wa * vc));
     }
-    const unsigned cb = (unsigned)(jc - B0);
-    if (arow >= 0 && jc > ja && cb < (unsigned)GT) atomicAdd(&acc[arow + (int)cb], (unsigned long long)__double2ll_rn(wa * vc));
-    dpp_pairs_tiled<O + 1>(arow, ja, wa, jc_own, vc_own, B0, acc);
+    dpp_pairs_tiled<O + 1>(arow, ja, wa, jc_own, vc_own, B0, acc, nrot);
   }
 }
 
@@ -232,12 +247,17 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag_tiled(const i64* __restri
         const double wa = ha ? wi * va_raw : 0.0;
         const unsigned ab = (unsigned)(ja - A0);
         const int arow = (ha && ab < (unsigned)GT) ? (int)ab * GT : -1;
-        dpp_pairs_tiled<0>(arow, ja, wa, ja_raw, va_raw, B0, gl);          // partners inside the same 16 entries
+        // partners inside the same 16 entries: entry l pairs with l + o for o < (entries of the longest of the four
+        // rows of this wavefront); further rotations only meet smaller columns or empty lanes
+        const unsigned long long hm = __ballot(ha);
+        const unsigned m16 = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xFFFFull);
+        const int nrot = 32 - __clz((int)m16);
+        dpp_pairs_tiled<0>(arow, ja, wa, ja_raw, va_raw, B0, gl, nrot);
         for (i64 c0 = a0 + 16; c0 < e; c0 += 16) {
           const bool hc = c0 + lane < e;
           const int jc_own = hc ? (int)col[c0 + lane] : -1;
           const double vc_own = hc ? val[c0 + lane] : 0.0;
-          dpp_pairs_tiled<0>(arow, ja, wa, jc_own, vc_own, B0, gl);
+          dpp_pairs_tiled<0>(arow, ja, wa, jc_own, vc_own, B0, gl, 16);
         }
       }
     }
@@ -609,9 +629,20 @@ __global__ __launch_bounds__(64) void k_gtheta(const double* __restrict__ G, con
   const int i = blockIdx.x * 64 + threadIdx.x;
   const int ic = i < d ? i : d - 1;
   double s = 0.0;
-  for (int k = 0; k < d; k++) {
+  // loads unconditional and eight in flight (a load behind the `t != 0` branch is one L2 round trip per k: 147 us at
+  // d = 501); the zero coefficients are still skipped in the sum
+  int k = 0;
+  for (; k + 8 <= d; k += 8) {
+    double g[8], t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { g[u] = G[(i64)(k + u) * d + ic]; t[u] = theta[k + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const double v = s + g[u] * t[u]; s = t[u] != 0.0 ? v : s; }
+  }
+  for (; k < d; k++) {
     const double t = theta[k];
-    if (t != 0.0) s += G[(i64)k * d + ic] * t;
+    const double v = s + G[(i64)k * d + ic] * t;
+    s = t != 0.0 ? v : s;
   }
   if (i < d) q[i] = s;
 }
@@ -944,6 +975,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // wastes (K-1)/2 sweeps on average when the loss rule stops it; a sweep is ~8 us at d = 101 and ~67 us at d = 501:
   // small problems want full batches, large ones shorter ones (measured at d = 501: 8 -> 190 ms, 4 -> 180, 2 -> 187)
   const int batch_k = getenv("KLR_CD_BATCH") ? std::max(1, std::min(KSPEC, atoi(getenv("KLR_CD_BATCH")))) : (d <= 128 ? KSPEC : KSPEC / 2);
+  const bool dbg_sync = getenv("KLR_CD_DEBUG") && atoi(getenv("KLR_CD_DEBUG")) >= 2;
+#define DBG_STEP(name) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[cd] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
   for (i64 iter = 0; iter < max_iter; iter++, relin++) {
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
     if (thd_stale) KLR_TRY(launch_row_pass(ctx, red, thd, ROW_IRLS, cw, w, z, nullptr, th.data(), d));
@@ -959,6 +992,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
       hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
     }
+    DBG_STEP("irls sums");
     // the LDS-privatised build writes whole partials and the reduce overwrites the result slot: nothing to zero
     if ((!gram_lds && !gram_tiled) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     bool assembled = false;
@@ -991,6 +1025,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       hipLaunchKernelGGL(k_gram_assemble, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, a0, nm, Gi, gsc, d, G);
     }
     KLR_HIP(ctx, hipGetLastError());
+    DBG_STEP("gram");
     tp = th;
 
     // ---- sweeps (speculative batches of KSPEC) -----------------------------------------------------
@@ -1035,6 +1070,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
       }
       KLR_HIP(ctx, hipGetLastError());
+      DBG_STEP("batch");
       KLR_HIP(ctx, hipMemcpyAsync(pin_report, hist, report_bytes, hipMemcpyDeviceToHost, st));
       KLR_HIP(ctx, hipStreamSynchronize(st));
       {
