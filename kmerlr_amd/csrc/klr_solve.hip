@@ -488,7 +488,27 @@ __device__ __forceinline__ double gram_at(const double* __restrict__ Gg, i64 idx
     thl[(J)] = tn_;                                               /* every lane, same value, same address */   \
   }
 
-template <int QPL, bool GLDS>
+// The same step with the Gram row requested TWO steps ahead (three register sets in rotation): rows that come from
+// L2 (GLDS = false, d > 128) take 500-700 cycles, a step ~250 -- one step of distance left every step waiting.
+#define CD_STEP3(S0, J, L1, G, GN2, C, O, I, CN, ON, IN)                                                      \
+  {                                                                                                            \
+    const int j2_ = (J) + 2 < d ? (J) + 2 : d - 1;                                                             \
+    const char* rowb_ = reinterpret_cast<const char*>(Gg) + (i64)j2_ * d * 8;      /* uniform row base */           \
+    _Pragma("unroll") for (int s_ = 0; s_ < QPL; s_++)                                                            \
+      GN2[s_] = *reinterpret_cast<const double*>(rowb_ + lane8 + s_ * 512);     /* columns >= d: never used */   \
+    const int jn_ = (J) + 1 < d ? (J) + 1 : (J);                                                               \
+    const double2 p01_ = *reinterpret_cast<const double2*>(pk + 4 * jn_);                                      \
+    CN = p01_.x; ON = p01_.y; IN = pk[4 * jn_ + 2];                                                            \
+    const double qj_ = bcast_lane(q[S0], (J) & 63);                                                            \
+    const double t0_ = C - qj_;                                                                                \
+    const double m_ = fmax(fabs(t0_) - (L1), 0.0);                                                             \
+    const double tn_ = copysign(m_, t0_) * I;                                                                  \
+    const double dl_ = tn_ - O;                                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < QPL; s_++) q[s_] = fma(dl_, G[s_], q[s_]);                          \
+    thl[(J)] = tn_;                                                                                            \
+  }
+
+template <int QPL, bool GLDS, bool PF2 = false>
 __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
   // 256 threads stage the Gram matrix into LDS (one wave alone would spend ~1 us per dependent load);
   // wavefront 0 then runs the sweeps.  A single wavefront cannot hide anything: every instruction of a step
@@ -556,34 +576,74 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
       }
     }
     __builtin_amdgcn_wave_barrier();
-    double gA[QPL], gB[QPL], cA, oA, iA, cB, oB, iB;
-#pragma unroll
-    for (int s = 0; s < QPL; s++) gA[s] = gram_at<GLDS>(Gg, off[s]);
-    cA = pk[0]; oA = pk[1]; iA = pk[2];
     const double l1 = a.l1reg;
+    if constexpr (PF2) {
+      // d >= 129 here: slot 0 is full.  Sets X / Y / Z hold rows j, j+1, j+2 in rotation; operands c/o/i one step ahead.
+      // unclamped row reads (scalar row base + lane * 8 + slot * 512 as an immediate: no address arithmetic per load):
+      // lanes past d run into the next row -- or, on the last row, up to 512 * QPL - 8 d bytes past the matrix, into
+      // the integer Gram that follows it in the same workspace block (d * d * 8 bytes); their q slots are never read
+      const unsigned lane8 = (unsigned)lane * 8u;
+      double gX[QPL], gY[QPL], gZ[QPL], cX, oX, iX, cY, oY, iY, cZ, oZ, iZ;
 #pragma unroll
-    for (int s0 = 0; s0 < QPL; s0++) {
-      const int j0 = s0 * 64, j1 = d < j0 + 64 ? d : j0 + 64;     // an even number of steps unless it is the last slot
-      int j = j0;
-      if (s0 == 0 && j < j1) {                                      // the bias is not penalised (:60)
-        CD_STEP(s0, j, 0.0, gA, cA, oA, iA, gB, cB, oB, iB);
-        j++;
-        if (j < j1) { CD_STEP(s0, j, l1, gB, cB, oB, iB, gA, cA, oA, iA); j++; }
-        else {                                                      // d == 1: keep the sets aligned
+      for (int s = 0; s < QPL; s++) { gX[s] = Gg[off[s]]; gY[s] = Gg[(i64)(d > 1 ? 1 : 0) * d + off[s]]; }
+      cX = pk[0]; oX = pk[1]; iX = pk[2];
 #pragma unroll
+      for (int s0 = 0; s0 < QPL; s0++) {
+        const int j0 = s0 * 64, j1 = d < j0 + 64 ? d : j0 + 64;
+        int j = j0;
+        if (s0 == 0) {                                               // the bias is not penalised (:60)
+          CD_STEP3(s0, 0, 0.0, gX, gZ, cX, oX, iX, cY, oY, iY);
+          CD_STEP3(s0, 1, l1, gY, gX, cY, oY, iY, cZ, oZ, iZ);
+          CD_STEP3(s0, 2, l1, gZ, gY, cZ, oZ, iZ, cX, oX, iX);
+          j = 3;
+        }
+        for (; j + 2 < j1; j += 3) {
+          CD_STEP3(s0, j, l1, gX, gZ, cX, oX, iX, cY, oY, iY);
+          CD_STEP3(s0, j + 1, l1, gY, gX, cY, oY, iY, cZ, oZ, iZ);
+          CD_STEP3(s0, j + 2, l1, gZ, gY, cZ, oZ, iZ, cX, oX, iX);
+        }
+        if (j + 1 == j1) {                                           // one step left: rotate the sets by one
+          CD_STEP3(s0, j, l1, gX, gZ, cX, oX, iX, cY, oY, iY);
+#pragma unroll
+          for (int s = 0; s < QPL; s++) { gX[s] = gY[s]; gY[s] = gZ[s]; }
+          cX = cY; oX = oY; iX = iY;
+        } else if (j + 2 == j1) {                                    // two steps left: rotate by two
+          CD_STEP3(s0, j, l1, gX, gZ, cX, oX, iX, cY, oY, iY);
+          CD_STEP3(s0, j + 1, l1, gY, gX, cY, oY, iY, cZ, oZ, iZ);
+#pragma unroll
+          for (int s = 0; s < QPL; s++) { const double t = gX[s]; gX[s] = gZ[s]; gY[s] = t; }
+          cX = cZ; oX = oZ; iX = iZ;
+        }
+      }
+    } else {
+      double gA[QPL], gB[QPL], cA, oA, iA, cB, oB, iB;
+  #pragma unroll
+      for (int s = 0; s < QPL; s++) gA[s] = gram_at<GLDS>(Gg, off[s]);
+      cA = pk[0]; oA = pk[1]; iA = pk[2];
+  #pragma unroll
+      for (int s0 = 0; s0 < QPL; s0++) {
+        const int j0 = s0 * 64, j1 = d < j0 + 64 ? d : j0 + 64;     // an even number of steps unless it is the last slot
+        int j = j0;
+        if (s0 == 0 && j < j1) {                                      // the bias is not penalised (:60)
+          CD_STEP(s0, j, 0.0, gA, cA, oA, iA, gB, cB, oB, iB);
+          j++;
+          if (j < j1) { CD_STEP(s0, j, l1, gB, cB, oB, iB, gA, cA, oA, iA); j++; }
+          else {                                                      // d == 1: keep the sets aligned
+  #pragma unroll
+            for (int s = 0; s < QPL; s++) gA[s] = gB[s];
+            cA = cB; oA = oB; iA = iB;
+          }
+        }
+        for (; j + 1 < j1; j += 2) {
+          CD_STEP(s0, j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
+          CD_STEP(s0, j + 1, l1, gB, cB, oB, iB, gA, cA, oA, iA);
+        }
+        if (j < j1) {                                                 // odd tail (last slot only): one step, sets swapped back
+          CD_STEP(s0, j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
+  #pragma unroll
           for (int s = 0; s < QPL; s++) gA[s] = gB[s];
           cA = cB; oA = oB; iA = iB;
         }
-      }
-      for (; j + 1 < j1; j += 2) {
-        CD_STEP(s0, j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
-        CD_STEP(s0, j + 1, l1, gB, cB, oB, iB, gA, cA, oA, iA);
-      }
-      if (j < j1) {                                                 // odd tail (last slot only): one step, sets swapped back
-        CD_STEP(s0, j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
-#pragma unroll
-        for (int s = 0; s < QPL; s++) gA[s] = gB[s];
-        cA = cB; oA = oB; iA = iB;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -621,6 +681,7 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
   if (lane == 0) *a.ndone = done;
 }
 #undef CD_STEP
+#undef CD_STEP3
 
 // q = G theta (zero coefficients skipped, k ascending: the same sums as the in-kernel loop), a wavefront per 64
 // coordinates instead of one wavefront for all of them
@@ -1054,8 +1115,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         hipLaunchKernelGGL(k_cd_lds2, dim3(1), dim3(1024), (size_t)(d + 1) * (CDL_STRIDE + 4) * sizeof(double), st, a, t0);
       }
       else if (d <= 128) hipLaunchKernelGGL((k_cd_wave<2, false>), dim3(1), dim3(256), lds_wave, st, a);
-      else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false>), dim3(1), dim3(256), lds_wave, st, a);
-      else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false>), dim3(1), dim3(256), lds_wave, st, a);
+      else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false, true>), dim3(1), dim3(256), lds_wave, st, a);
+      else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false, true>), dim3(1), dim3(256), lds_wave, st, a);
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
         // iterates staged in LDS only while that is cheaper than reading them where they are: a block of 32 rows
