@@ -683,6 +683,186 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
 #undef CD_STEP
 #undef CD_STEP3
 
+// ---- d > 512: blocked Gauss-Seidel over 16 wavefronts ----------------------------------------------------------
+// Coordinates in blocks of 64; q = G theta lives in registers, slot s (coordinates 64 s .. 64 s + 63) on wavefront
+// s % 16.  For block B the wavefront that owns it runs the 64 dependent steps ALONE, against the 64 x 64 diagonal
+// block of G staged in LDS (the step of k_cd_lds2 with one q value per lane) and leaves the 64 deltas in LDS; after
+// one barrier every wavefront adds  sum_j delta_j G[64 B + j][.]  to its own slots, j ascending -- the very fma
+// sequence a coordinate-at-a-time sweep applies to those q values, which nobody reads in between: same results,
+// but the other slots' updates (all the memory traffic: one pass over G per sweep) run beside the next block's
+// dependent steps instead of inside them.  The wavefront that owns block B+1 stages its diagonal block while it
+// would otherwise wait for block B's steps.  k_cd_sweeps walked the coordinates on one thread with two barriers per
+// moving coordinate: 568 us per sweep at d = 1001.
+#define CDB_ROWS 65                                  // 64 rows + the harmless prefetch of "row 64"
+#define CDB_STEP(JL, L1, G, C, O, I, GN, CN, ON, IN)                                                          \
+  {                                                                                                            \
+    GN = grow[0]; grow += 64;                                                                                  \
+    const double2 p01_ = *reinterpret_cast<const double2*>(pj + 4);                                            \
+    CN = p01_.x; ON = p01_.y; IN = pj[6];                                                                      \
+    const double qj_ = bcast_lane(qb, (JL));                                                                   \
+    const double t0_ = C - qj_;                                                                                \
+    const double m_ = fmax(fabs(t0_) - (L1), 0.0);                                                             \
+    const double tn_ = copysign(m_, t0_) * I;                                                                  \
+    const double dl_ = tn_ - O;                                                                                \
+    qb = fma(dl_, G, qb);                                                                                      \
+    pj[3] = tn_; pj[0] = dl_;                                     /* c_j is spent: its place takes the delta */ \
+    pj += 4;                                                                                                   \
+  }
+
+template <int QW>
+__global__ __launch_bounds__(1024) void k_cd_blocked(CdArgs a) {
+  __shared__ double Gd[2][CDB_ROWS * 64];            // diagonal blocks, double buffered
+  __shared__ double pk[2][CDB_ROWS * 4];             // {c_j -> delta_j, old theta_j, 1/(norm_j + l2), theta_j}
+  __shared__ double sh_mx[16], sh_md[16];
+  __shared__ int sh_nan[16], sh_stop;
+  const int d = a.d, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int S = (d + 63) >> 6;                       // blocks / slots
+  const double* __restrict__ G = a.G;
+  double q[QW], th[QW], xy[QW], dg[QW], inv[QW];
+#pragma unroll
+  for (int t = 0; t < QW; t++) {
+    const int i = (w + 16 * t) * 64 + lane;
+    const bool ok = i < d;
+    th[t] = ok ? a.theta[i] : 0.0;
+    xy[t] = ok ? a.xy[i] : 0.0;
+    dg[t] = ok ? G[(i64)i * d + i] : 1.0;
+    inv[t] = 1.0 / (dg[t] + a.l2reg);
+    q[t] = ok ? a.q_io[i] : 0.0;                     // q = G theta from k_gtheta or the previous batch
+  }
+  if (threadIdx.x < 64) { Gd[0][64 * 64 + lane] = 0.0; Gd[1][64 * 64 + lane] = 0.0; }
+  if (threadIdx.x < 8) { pk[0][64 * 4 + (threadIdx.x & 3)] = 0.0; pk[1][64 * 4 + (threadIdx.x & 3)] = 0.0; }
+  // diagonal block of block 0
+  if (w == 0) {
+#pragma unroll 8
+    for (int r = 0; r < 64; r++) {
+      const int row = r < d ? r : d - 1, cc = lane < d ? lane : d - 1;
+      Gd[0][r * 64 + lane] = G[(i64)row * d + cc];
+    }
+  }
+  __syncthreads();
+  int zero_v;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+  const double l1 = a.l1reg;
+  int done = 0;
+  for (int k = 0; k < a.K; k++) {
+    double told[QW];
+#pragma unroll
+    for (int t = 0; t < QW; t++) told[t] = th[t];
+    for (int B = 0; B < S; B++) {
+      const int ow = B & 15, bb = (k * S + B) & 1;         // LDS buffers alternate over ALL blocks of the batch
+      if (w == ow) {
+        // ---- the 64 dependent steps of block B ----
+        const int nbk = d - B * 64 < 64 ? d - B * 64 : 64;             // coordinates in this block
+        double qb = 0.0, thb = 0.0, xyb = 0.0, dgb = 1.0, invb = 1.0;
+#pragma unroll
+        for (int t = 0; t < QW; t++) if (B == ow + 16 * t) { qb = q[t]; thb = th[t]; xyb = xy[t]; dgb = dg[t]; invb = inv[t]; }
+        double* pkb = pk[bb];
+        pkb[4 * lane] = xyb + dgb * thb; pkb[4 * lane + 1] = thb; pkb[4 * lane + 2] = invb; pkb[4 * lane + 3] = thb;   // :56
+        __builtin_amdgcn_wave_barrier();
+        const double* grow = Gd[bb] + 64 + lane;                        // row 1 of the diagonal block
+        double* pj = pkb + zero_v;
+        double gA = Gd[bb][lane], cA = pkb[0], oA = pkb[1], iA = pkb[2], gB, cB, oB, iB;
+        int j = 0;
+        if (B == 0) {                                                   // the bias is not penalised (:60)
+          CDB_STEP(0, 0.0, gA, cA, oA, iA, gB, cB, oB, iB);
+          j = 1;
+          if (j < nbk) { CDB_STEP(1, l1, gB, cB, oB, iB, gA, cA, oA, iA); j = 2; }
+          else { gA = gB; cA = cB; oA = oB; iA = iB; }
+        }
+        for (; j + 1 < nbk; j += 2) {
+          CDB_STEP(j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
+          CDB_STEP(j + 1, l1, gB, cB, oB, iB, gA, cA, oA, iA);
+        }
+        if (j < nbk) { CDB_STEP(j, l1, gA, cA, oA, iA, gB, cB, oB, iB); }
+        __builtin_amdgcn_wave_barrier();
+        // coordinates past the end of the last block: no move
+        if (lane >= nbk) pkb[4 * lane] = 0.0;
+        const double thn = pkb[4 * lane + 3];
+#pragma unroll
+        for (int t = 0; t < QW; t++) if (B == ow + 16 * t) { q[t] = qb; th[t] = thn; }
+      } else if (w == ((ow + 1) & 15)) {
+        // ---- meanwhile: stage the diagonal block of the next block (block 0 of the next sweep after the last) ----
+        const int Bn = B + 1 == S ? 0 : B + 1;
+        double* dst = Gd[bb ^ 1];
+        const int c0 = Bn * 64 + lane, cc = c0 < d ? c0 : d - 1;
+#pragma unroll 8
+        for (int r = 0; r < 64; r++) {
+          const int row = Bn * 64 + r < d ? Bn * 64 + r : d - 1;
+          dst[r * 64 + lane] = G[(i64)row * d + cc];
+        }
+      }
+      __syncthreads();                                                  // deltas of block B visible
+      // ---- every wavefront: its own slots += sum_j delta_j G[64 B + j][slot], j ascending ----
+      // One compute unit reads all of G once per sweep (64 bytes per clock: 3.4 us per block at d = 1001, next to
+      // 4.2 us of steps).  Letting the next owner update first and alone and the others stream beside its steps was
+      // slower (318 ms against 300 for the lambda-auto=1000 run): the streaming wavefronts share the SIMDs with the
+      // one that runs the dependent steps.
+      const double* dlp = pk[bb];
+      const int nbk = d - B * 64 < 64 ? d - B * 64 : 64;
+#pragma unroll
+      for (int t = 0; t < QW; t++) {
+        const int sl = w + 16 * t;
+        if (sl < S && sl != B) {
+          const int ci = sl * 64 + lane;
+          const double* col = G + (i64)B * 64 * d + (ci < d ? ci : d - 1);
+          double qq = q[t];
+          int j = 0;
+          for (; j + 8 <= nbk; j += 8) {
+            double g[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) g[u] = col[(i64)(j + u) * d];
+#pragma unroll
+            for (int u = 0; u < 8; u++) qq = fma(dlp[4 * (j + u)], g[u], qq);
+          }
+          for (; j < nbk; j++) qq = fma(dlp[4 * j], col[(i64)j * d], qq);
+          q[t] = qq;
+        }
+      }
+    }
+    // ---- eval_stopping (proximal.go:30-52), the iterate ----
+    double max_x = 0.0, max_delta = 0.0; int isnan_ = 0;
+#pragma unroll
+    for (int t = 0; t < QW; t++) {
+      const int i = (w + 16 * t) * 64 + lane;
+      if (i < d) {
+        const double tn = th[t];
+        a.hist[(i64)k * d + i] = tn;
+        isnan_ |= (tn != tn) ? 1 : 0;
+        max_x = fmax(max_x, fabs(tn));
+        max_delta = fmax(max_delta, fabs(tn - told[t]));
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      max_x = fmax(max_x, __shfl_xor(max_x, o, 64));
+      max_delta = fmax(max_delta, __shfl_xor(max_delta, o, 64));
+      isnan_ |= __shfl_xor(isnan_, o, 64);
+    }
+    if (lane == 0) { sh_mx[w] = max_x; sh_md[w] = max_delta; sh_nan[w] = isnan_; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double mx = 0.0, md = 0.0; int nn = 0;
+      for (int t = 0; t < 16; t++) { mx = fmax(mx, sh_mx[t]); md = fmax(md, sh_md[t]); nn |= sh_nan[t]; }
+      double delta; int stop;
+      if (nn) { delta = nan(""); stop = 1; }
+      else {
+        delta = (mx != 0.0) ? md / mx : md;
+        stop = ((mx != 0.0 && md / mx <= a.eps) || (mx == 0.0 && md == 0.0)) ? 1 : 0;
+      }
+      a.delta[k] = delta; a.stopf[k] = stop; sh_stop = stop;
+    }
+    done = k + 1;
+    __syncthreads();
+    if (sh_stop) break;
+  }
+#pragma unroll
+  for (int t = 0; t < QW; t++) {
+    const int i = (w + 16 * t) * 64 + lane;
+    if (i < d) { a.theta[i] = th[t]; a.q_io[i] = q[t]; }
+  }
+  if (threadIdx.x == 0) *a.ndone = done;
+}
+#undef CDB_STEP
+
 // q = G theta (zero coefficients skipped, k ascending: the same sums as the in-kernel loop), a wavefront per 64
 // coordinates instead of one wavefront for all of them
 __global__ __launch_bounds__(64) void k_gtheta(const double* __restrict__ G, const double* __restrict__ theta, int d,
@@ -1104,7 +1284,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
       a.q_io = nullptr; a.q_load = 0;
-      if (d > 128 && d <= 512) {
+      if (d > 128) {
         a.q_io = q_dev; a.q_load = 1;
         if (q_stale) hipLaunchKernelGGL(k_gtheta, dim3((unsigned)ceil_div((i64)d, (i64)64)), dim3(64), 0, st, G, thd, d, q_dev);
         q_stale = false;
@@ -1117,6 +1297,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       else if (d <= 128) hipLaunchKernelGGL((k_cd_wave<2, false>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false, true>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false, true>), dim3(1), dim3(256), lds_wave, st, a);
+      else if (d <= 1024 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<1>, dim3(1), dim3(1024), 0, st, a);
+      else if (d <= 2048 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<2>, dim3(1), dim3(1024), 0, st, a);
+      else if (d <= 3072 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<3>, dim3(1), dim3(1024), 0, st, a);
+      else if (d <= 5120 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<5>, dim3(1), dim3(1024), 0, st, a);
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
         // iterates staged in LDS only while that is cheaper than reading them where they are: a block of 32 rows

@@ -432,7 +432,7 @@ def test_full_size_properties(ctx):
 
 
 @pytest.mark.parametrize("gram_path", [None, "lds", "global"])
-@pytest.mark.parametrize("N", [40, 150, 300, 560])
+@pytest.mark.parametrize("N", [40, 150, 300, 560, 1100])
 def test_cd_solve_solver_variants(ctx, N, gram_path, monkeypatch):
     """d = N+1 selects the solver kernel: one wavefront with 2/4/8 q values per lane, or the workgroup
     version; all must follow the oracle's iterate sequence.  gram_path forces the Gram build: privatised in LDS
