@@ -173,35 +173,37 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
 // scheme and keeps the pairs (ja in A, jb in B); partial tiles are summed by k_gram_tiled_reduce.  The rows are read
 // once per tile pair (they are short and L2 resident); the pair work is the same in total.
 #define GT 128
-template <int O>
-__device__ __forceinline__ void dpp_pairs_tiled(int arow, int ja, double wa, int jc_own, double vc_own, int B0,
-                                                unsigned long long* acc, int nrot) {
-  if constexpr (O < 16) {
-    if (O == 0 || O > 16 - nrot) {                    // see dpp_pairs
-      int jc; double vc;
-      if constexpr (O == 0) { jc = jc_own; vc = vc_own; }
-      else {
-        constexpr int ctrl = 0x120 + O;               // row_ror:O
-        jc = __builtin_amdgcn_update_dpp(0, jc_own, ctrl, 0xF, 0xF, false);
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(vc_own), ctrl, 0xF, 0xF, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(vc_own), ctrl, 0xF, 0xF, false);
-        vc = __hiloint2double(hi, lo);
-      }
-      const unsigned cb = (unsigned)(jc - B0);
-      if (arow >= 0 && jc > ja && cb < (unsigned)GT) atomicAdd(&acc[arow + (int)cb], (unsigned long long)__double2ll_rn(wa * vc));
-    }
-    dpp_pairs_tiled<O + 1>(arow, ja, wa, jc_own, vc_own, B0, acc, nrot);
-  }
-}
-
 __device__ __forceinline__ void gram_tile_pair(int p, int nt, int& A, int& B) {       // p-th pair (A <= B), row major
   A = 0;
   while (p >= nt - A) { p -= nt - A; A++; }
   B = A + p;
 }
 
+// toff[i][t], t = 0 .. nt: position (inside row i, bias skipped) of the first entry with column >= t * GT -- the
+// column tiles of a row; the rows of a reduced matrix do not change during a solve, so this is built once per call
+__global__ __launch_bounds__(256) void k_row_tile_offsets(const i64* __restrict__ rowptr, const u32* __restrict__ col, i64 n,
+                                                          int nt, unsigned short* __restrict__ toff) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const i64 b = rowptr[i] + 1, e = rowptr[i + 1];
+  unsigned short* o = toff + i * (nt + 1);
+  int t = 0;
+  for (i64 p = b; p < e; p++) {
+    const int ct = (int)(col[p] / GT);
+    while (t <= ct) o[t++] = (unsigned short)(p - b);
+  }
+  while (t <= nt) o[t++] = (unsigned short)(e - b);
+}
+
+// A thread per row: with the tile offsets a row knows at once which of its entries fall in tile A and which in
+// tile B (usually a few, often none) and takes exactly those pairs -- the 16-lane rotation scheme of the small case
+// walked all 256 lane pairs of every row in every one of the (nt + 1) nt / 2 passes (700 us at d = 1001).  Rows longer
+// than 65535 entries cannot occur (d <= 1024).  Same addends as k_gram_offdiag: round(w_i v_a 2^E * v_b).  (For the
+// single-tile kernel above a thread per row is SLOWER than the rotations: 45 sequential pairs per thread, 24.3 -> 33 ms
+// for the configs[2] estimate.)
 __global__ __launch_bounds__(1024) void k_gram_offdiag_tiled(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                              const double* __restrict__ val, const double* __restrict__ w,
+                                                             const unsigned short* __restrict__ toff,
                                                              i64 n, int d, const double* __restrict__ sc,
                                                              unsigned long long* __restrict__ part) {
   extern __shared__ unsigned long long gl[];
@@ -212,54 +214,17 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag_tiled(const i64* __restri
   gram_tile_pair((int)blockIdx.y, nt, A, B);
   const int A0 = A * GT, B0 = B * GT;
   const double s0 = sc[0];
-  const int lane = threadIdx.x & 15;
-  const i64 grp0 = ((i64)blockIdx.x * 1024 + threadIdx.x) >> 4, ngrp = ((i64)gridDim.x * 1024) >> 4;
-  // a workgroup walks thousands of rows here (the grid is tile pairs x row groups): four rows per trip, their
-  // offsets and first 16 entries loaded together, or every row is two dependent round trips to L2
-  constexpr int RB = 4;
-  for (i64 i0 = grp0; i0 < n; i0 += RB * ngrp) {
-    i64 rb[RB], re[RB]; double rw[RB];
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-      const i64 i = i0 + r * ngrp;
-      const bool ok = i < n;
-      rb[r] = ok ? rowptr[i] + 1 : 0;                           // skip the bias entry
-      re[r] = ok ? rowptr[i + 1] : 0;
-      rw[r] = ok ? w[i] : 0.0;
-    }
-    int fj[RB]; double fv[RB];
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-      const bool h = rb[r] + lane < re[r];
-      fj[r] = h ? (int)col[rb[r] + lane] : -1;
-      fv[r] = h ? val[rb[r] + lane] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-      const i64 b = rb[r], e = re[r];
-      const double wi = rw[r] * s0;
-      for (i64 a0 = b; a0 < e; a0 += 16) {
-        int ja_raw; double va_raw;
-        if (a0 == b) { ja_raw = fj[r]; va_raw = fv[r]; }
-        else { const bool h = a0 + lane < e; ja_raw = h ? (int)col[a0 + lane] : -1; va_raw = h ? val[a0 + lane] : 0.0; }
-        const bool ha = ja_raw >= 0;
-        const int ja = ha ? ja_raw : 0;
-        const double wa = ha ? wi * va_raw : 0.0;
-        const unsigned ab = (unsigned)(ja - A0);
-        const int arow = (ha && ab < (unsigned)GT) ? (int)ab * GT : -1;
-        // partners inside the same 16 entries: entry l pairs with l + o for o < (entries of the longest of the four
-        // rows of this wavefront); further rotations only meet smaller columns or empty lanes
-        const unsigned long long hm = __ballot(ha);
-        const unsigned m16 = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xFFFFull);
-        const int nrot = 32 - __clz((int)m16);
-        dpp_pairs_tiled<0>(arow, ja, wa, ja_raw, va_raw, B0, gl, nrot);
-        for (i64 c0 = a0 + 16; c0 < e; c0 += 16) {
-          const bool hc = c0 + lane < e;
-          const int jc_own = hc ? (int)col[c0 + lane] : -1;
-          const double vc_own = hc ? val[c0 + lane] : 0.0;
-          dpp_pairs_tiled<0>(arow, ja, wa, jc_own, vc_own, B0, gl, 16);
-        }
-      }
+  for (i64 i = (i64)blockIdx.x * 1024 + threadIdx.x; i < n; i += (i64)gridDim.x * 1024) {
+    const unsigned short* o = toff + i * (nt + 1);
+    const int a0 = o[A], a1 = o[A + 1], b0 = o[B], b1 = o[B + 1];
+    if (a1 == a0 || b1 == b0) continue;
+    const i64 rb = rowptr[i] + 1;
+    const double wi = w[i] * s0;
+    for (int pa = a0; pa < a1; pa++) {
+      const int ja = (int)col[rb + pa] - A0;
+      const double wa = wi * val[rb + pa];
+      for (int pb = (b0 > pa + 1 ? b0 : pa + 1); pb < b1; pb++)
+        atomicAdd(&gl[ja * GT + ((int)col[rb + pb] - B0)], (unsigned long long)__double2ll_rn(wa * val[rb + pb]));
     }
   }
   __syncthreads();
@@ -1164,13 +1129,18 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // 128 < d <= 1024 with many pairs: tile pairs privatised in LDS (k_gram_offdiag_tiled)
   const int gram_nt = (d + GT - 1) / GT, gram_npairs = gram_nt * (gram_nt + 1) / 2;
   const bool gram_tiled = !gram_lds && (size_t)d * d * 8 > 128 * 1024 && d <= 1024 && gram_many;
-  const unsigned gram_groups = gram_tiled ? (unsigned)std::max<i64>(1, std::min<i64>(std::max(1, ctx->n_cu / gram_npairs), ceil_div(n * 16, 4 * 1024))) : 0u;
+  const unsigned gram_groups = gram_tiled ? (unsigned)std::max<i64>(1, std::min<i64>(std::max(1, ctx->n_cu / gram_npairs), ceil_div(n, 2 * 1024))) : 0u;
   if (gram_tiled) {
     static bool attr = false;
     if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, GT * GT * 8)); attr = true; }
   }
   const size_t gram_part_bytes = gram_tiled ? (size_t)gram_npairs * gram_groups * GT * GT * 8 : (size_t)gram_blocks * d * d * 8;
-  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8 + gram_part_bytes, (void**)&G));
+  const size_t gram_toff_bytes = gram_tiled ? (size_t)n * (gram_nt + 1) * sizeof(unsigned short) : 0;
+  KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8 + gram_part_bytes + gram_toff_bytes, (void**)&G));
+  unsigned short* gram_toff = (unsigned short*)((char*)G + (size_t)2 * d * d * 8 + gram_part_bytes);
+  if (gram_tiled && n)
+    hipLaunchKernelGGL(k_row_tile_offsets, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, red->rowptr, red->col, n,
+                       gram_nt, gram_toff);
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
   // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
@@ -1251,7 +1221,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       } else if (gram_tiled) {
         unsigned long long* gpart = (unsigned long long*)(Gi + (size_t)d * d);
         hipLaunchKernelGGL(k_gram_offdiag_tiled, dim3(gram_groups, (unsigned)gram_npairs), dim3(1024), (size_t)GT * GT * 8, st,
-                           red->rowptr, red->col, (const double*)red->val, w, n, d, gsc, gpart);
+                           red->rowptr, red->col, (const double*)red->val, w, gram_toff, n, d, gsc, gpart);
         hipLaunchKernelGGL(k_gram_tiled_reduce, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st,
                            (const unsigned long long*)gpart, d, (int)gram_groups, a0, nm, gsc, single ? G : (double*)nullptr, Gi);
         assembled = single;
