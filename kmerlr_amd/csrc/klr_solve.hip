@@ -826,6 +826,156 @@ __global__ __launch_bounds__(1024) void k_cd_blocked(CdArgs a) {
   }
   if (threadIdx.x == 0) *a.ndone = done;
 }
+
+// ---- d > 2048: the same blocked sweep cut into super-blocks of 8 blocks (512 coordinates), two launches each ------
+// One compute unit streaming all of G per sweep is 2.35 ms at d = 5001 (200 MB).  k_cd_sb_steps runs the blocked
+// sweep INSIDE super-block sb (its 8 q slots, the 512 x 512 diagonal part of G) and leaves the 512 deltas in global
+// memory; k_cd_sb_update adds  sum_j delta_j G[512 sb + j][.]  (j ascending) to every other q slot, a wavefront per
+// slot on as many compute units as there are slots -- again the fma sequence of the coordinate-at-a-time sweep;
+// k_cd_sb_stop closes a sweep (eval_stopping, the iterate count, the halt flag the later launches of the batch obey).
+#define SBW 8
+__global__ __launch_bounds__(1024) void k_cd_sb_steps(CdArgs a, int k, int sb, const int* __restrict__ halt,
+                                                      double* __restrict__ dlbuf) {
+  __shared__ double Gd[2][CDB_ROWS * 64];
+  __shared__ double pk[2][CDB_ROWS * 4];
+  if (*halt) return;
+  const int d = a.d, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int S = (d + 63) >> 6;
+  const int B0 = sb * SBW, nbl = S - B0 < SBW ? S - B0 : SBW;          // blocks of this super-block
+  const double* __restrict__ G = a.G;
+  const int mi = (B0 + w) * 64 + lane;                                // my coordinate (waves 0 .. nbl-1)
+  const bool mine = w < nbl && mi < d;
+  double q = mine ? a.q_io[mi] : 0.0, th = mine ? a.theta[mi] : 0.0;
+  const double xy = mine ? a.xy[mi] : 0.0, dg = mine ? G[(i64)mi * d + mi] : 1.0;
+  const double inv = 1.0 / (dg + a.l2reg);
+  if (threadIdx.x < 64) { Gd[0][64 * 64 + lane] = 0.0; Gd[1][64 * 64 + lane] = 0.0; }
+  if (threadIdx.x < 8) { pk[0][64 * 4 + (threadIdx.x & 3)] = 0.0; pk[1][64 * 4 + (threadIdx.x & 3)] = 0.0; }
+  if (w == 15) {                                                       // diagonal block of the first block
+    const int c0 = B0 * 64 + lane, cc = c0 < d ? c0 : d - 1;
+#pragma unroll 8
+    for (int r = 0; r < 64; r++) {
+      const int row = B0 * 64 + r < d ? B0 * 64 + r : d - 1;
+      Gd[0][r * 64 + lane] = G[(i64)row * d + cc];
+    }
+  }
+  __syncthreads();
+  int zero_v;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+  const double l1 = a.l1reg;
+  for (int bl = 0; bl < nbl; bl++) {
+    const int B = B0 + bl, bb = bl & 1;
+    const int nbk = d - B * 64 < 64 ? d - B * 64 : 64;
+    if (w == bl) {
+      double qb = q;
+      double* pkb = pk[bb];
+      pkb[4 * lane] = xy + dg * th; pkb[4 * lane + 1] = th; pkb[4 * lane + 2] = inv; pkb[4 * lane + 3] = th;   // :56
+      __builtin_amdgcn_wave_barrier();
+      const double* grow = Gd[bb] + 64 + lane;
+      double* pj = pkb + zero_v;
+      double gA = Gd[bb][lane], cA = pkb[0], oA = pkb[1], iA = pkb[2], gB, cB, oB, iB;
+      int j = 0;
+      if (B == 0) {                                                   // the bias is not penalised (:60)
+        CDB_STEP(0, 0.0, gA, cA, oA, iA, gB, cB, oB, iB);
+        j = 1;
+        if (j < nbk) { CDB_STEP(1, l1, gB, cB, oB, iB, gA, cA, oA, iA); j = 2; }
+        else { gA = gB; cA = cB; oA = oB; iA = iB; }
+      }
+      for (; j + 1 < nbk; j += 2) {
+        CDB_STEP(j, l1, gA, cA, oA, iA, gB, cB, oB, iB);
+        CDB_STEP(j + 1, l1, gB, cB, oB, iB, gA, cA, oA, iA);
+      }
+      if (j < nbk) { CDB_STEP(j, l1, gA, cA, oA, iA, gB, cB, oB, iB); }
+      __builtin_amdgcn_wave_barrier();
+      if (lane >= nbk) pkb[4 * lane] = 0.0;
+      dlbuf[bl * 64 + lane] = pkb[4 * lane];                           // for k_cd_sb_update
+      q = qb; th = pkb[4 * lane + 3];
+    } else if (w == bl + 1 && bl + 1 < nbl) {
+      // the owner of the next block stages its diagonal block meanwhile
+      const int Bn = B + 1;
+      double* dst = Gd[bb ^ 1];
+      const int c0 = Bn * 64 + lane, cc = c0 < d ? c0 : d - 1;
+#pragma unroll 8
+      for (int r = 0; r < 64; r++) {
+        const int row = Bn * 64 + r < d ? Bn * 64 + r : d - 1;
+        dst[r * 64 + lane] = G[(i64)row * d + cc];
+      }
+    }
+    __syncthreads();
+    if (w < nbl && w != bl) {                                          // the other slots of the super-block
+      const double* dlp = pk[bb];
+      const int ci = (B0 + w) * 64 + lane;
+      const double* col = G + (i64)B * 64 * d + (ci < d ? ci : d - 1);
+      int j = 0;
+      for (; j + 8 <= nbk; j += 8) {
+        double g[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) g[u] = col[(i64)(j + u) * d];
+#pragma unroll
+        for (int u = 0; u < 8; u++) q = fma(dlp[4 * (j + u)], g[u], q);
+      }
+      for (; j < nbk; j++) q = fma(dlp[4 * j], col[(i64)j * d], q);
+    }
+  }
+  if (mine) { a.q_io[mi] = q; a.theta[mi] = th; a.hist[(i64)k * d + mi] = th; }
+}
+
+__global__ __launch_bounds__(256) void k_cd_sb_update(const double* __restrict__ G, int d, int sb,
+                                                      const double* __restrict__ dlbuf, double* __restrict__ q,
+                                                      const int* __restrict__ halt) {
+  if (*halt) return;
+  const int S = (d + 63) >> 6, lane = threadIdx.x & 63;
+  int sl = blockIdx.x * 4 + (threadIdx.x >> 6);                        // slots outside the super-block
+  if (sl >= sb * SBW) sl += SBW;
+  if (sl >= S) return;
+  const int ci = sl * 64 + lane;
+  const int nj = d - sb * SBW * 64 < SBW * 64 ? d - sb * SBW * 64 : SBW * 64;
+  const double* col = G + (i64)sb * SBW * 64 * d + (ci < d ? ci : d - 1);
+  double qq = ci < d ? q[ci] : 0.0;
+  int j = 0;
+  for (; j + 16 <= nj; j += 16) {
+    double g[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) g[u] = col[(i64)(j + u) * d];
+#pragma unroll
+    for (int u = 0; u < 16; u++) qq = fma(dlbuf[j + u], g[u], qq);
+  }
+  for (; j < nj; j++) qq = fma(dlbuf[j], col[(i64)j * d], qq);
+  if (ci < d) q[ci] = qq;
+}
+
+__global__ __launch_bounds__(1024) void k_cd_sb_stop(CdArgs a, int k, const double* __restrict__ prev, int* __restrict__ halt) {
+  __shared__ double sh_mx[16], sh_md[16];
+  __shared__ int sh_nan[16];
+  if (*halt) return;
+  const int d = a.d, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* cur = a.hist + (i64)k * d;
+  double max_x = 0.0, max_delta = 0.0; int isnan_ = 0;
+  for (int i = threadIdx.x; i < d; i += 1024) {
+    const double tn = cur[i];
+    isnan_ |= (tn != tn) ? 1 : 0;
+    max_x = fmax(max_x, fabs(tn));
+    max_delta = fmax(max_delta, fabs(tn - prev[i]));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    max_x = fmax(max_x, __shfl_xor(max_x, o, 64));
+    max_delta = fmax(max_delta, __shfl_xor(max_delta, o, 64));
+    isnan_ |= __shfl_xor(isnan_, o, 64);
+  }
+  if (lane == 0) { sh_mx[w] = max_x; sh_md[w] = max_delta; sh_nan[w] = isnan_; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double mx = 0.0, md = 0.0; int nn = 0;
+    for (int t = 0; t < 16; t++) { mx = fmax(mx, sh_mx[t]); md = fmax(md, sh_md[t]); nn |= sh_nan[t]; }
+    double delta; int stop;
+    if (nn) { delta = nan(""); stop = 1; }
+    else {
+      delta = (mx != 0.0) ? md / mx : md;
+      stop = ((mx != 0.0 && md / mx <= a.eps) || (mx == 0.0 && md == 0.0)) ? 1 : 0;
+    }
+    a.delta[k] = delta; a.stopf[k] = stop; *a.ndone = k + 1;
+    if (stop) *halt = 1;
+  }
+}
 #undef CDB_STEP
 
 // q = G theta (zero coefficients skipped, k ascending: the same sums as the in-kernel loop), a wavefront per 64
@@ -1097,8 +1247,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const size_t lds_small = (size_t)4 * d * sizeof(double);
   const size_t lds_big = lds_small + (size_t)d * d * sizeof(double);
   const size_t LDS_MAX = 160 * 1024 - 1024;
-  if (lds_small > LDS_MAX)
-    return klr_fail(ctx, KLR_EINVAL, "%d selected features exceed the device solver's limit (%zu)", d - 1, LDS_MAX / 32 - 1);
+  if (d > 16384)
+    return klr_fail(ctx, KLR_EINVAL, "%d selected features exceed the device solver's limit (16383)", d - 1);
   const int g_in_lds = lds_big <= LDS_MAX;
   const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
   // wave variant: packed per-coordinate operands (4 per coordinate), theta (+ G) in LDS
@@ -1144,7 +1294,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
   // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
-  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16 + (size_t)d * 8;
+  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16 + (size_t)d * 8
+                           + (size_t)d * 8 + SBW * 64 * 8 + 8;
   KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
   double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d; double* hist = thd + d;
   double* delta = hist + (size_t)KSPEC * d; double* losses = delta + KSPEC; double* gsc = losses + KSPEC;
@@ -1152,6 +1303,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   unsigned long long* fin_ctl = (unsigned long long*)(stopf + KSPEC + 8);     // {ticket, max bits} of k_irls_finish
   KLR_HIP(ctx, hipMemsetAsync(fin_ctl, 0, 16, st));
   double* q_dev = (double*)(fin_ctl + 2);                                      // q = G theta between batches (k_cd_wave)
+  double* sb_th0 = q_dev + d; double* sb_dl = sb_th0 + d; int* sb_halt = (int*)(sb_dl + SBW * 64);   // super-block solver
   const size_t report_bytes = ((size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 1) * sizeof(int);
   char* pin_report;
   KLR_TRY(pin_get(ctx, report_bytes, (void**)&pin_report));
@@ -1269,8 +1421,22 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false, true>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 1024 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<1>, dim3(1), dim3(1024), 0, st, a);
       else if (d <= 2048 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<2>, dim3(1), dim3(1024), 0, st, a);
-      else if (d <= 3072 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<3>, dim3(1), dim3(1024), 0, st, a);
-      else if (d <= 5120 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<5>, dim3(1), dim3(1024), 0, st, a);
+      else if (!getenv("KLR_CD_SWEEPS") || lds_small > LDS_MAX) {
+        // super-blocks: two launches per 512 coordinates, one per sweep for the stop rule; a halted batch's later
+        // launches return at once
+        const int S = (d + 63) / 64, NSB = (S + SBW - 1) / SBW;
+        KLR_HIP(ctx, hipMemsetAsync(sb_halt, 0, 8, st));
+        KLR_HIP(ctx, hipMemsetAsync(ndone, 0, sizeof(int), st));
+        KLR_HIP(ctx, hipMemcpyAsync(sb_th0, thd, (size_t)d * 8, hipMemcpyDeviceToDevice, st));
+        for (int k = 0; k < Kb; k++) {
+          for (int sb = 0; sb < NSB; sb++) {
+            hipLaunchKernelGGL(k_cd_sb_steps, dim3(1), dim3(1024), 0, st, a, k, sb, (const int*)sb_halt, sb_dl);
+            hipLaunchKernelGGL(k_cd_sb_update, dim3((unsigned)ceil_div((i64)S, (i64)4)), dim3(256), 0, st, (const double*)G, d, sb,
+                               (const double*)sb_dl, q_dev, (const int*)sb_halt);
+          }
+          hipLaunchKernelGGL(k_cd_sb_stop, dim3(1), dim3(1024), 0, st, a, k, (const double*)(k == 0 ? sb_th0 : hist + (size_t)(k - 1) * d), sb_halt);
+        }
+      }
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
         // iterates staged in LDS only while that is cheaper than reading them where they are: a block of 32 rows

@@ -432,10 +432,11 @@ def test_full_size_properties(ctx):
 
 
 @pytest.mark.parametrize("gram_path", [None, "lds", "global"])
-@pytest.mark.parametrize("N", [40, 150, 300, 560, 1100])
+@pytest.mark.parametrize("N", [40, 150, 300, 560, 1100, 2100])
 def test_cd_solve_solver_variants(ctx, N, gram_path, monkeypatch):
-    """d = N+1 selects the solver kernel: one wavefront with 2/4/8 q values per lane, or the workgroup
-    version; all must follow the oracle's iterate sequence.  gram_path forces the Gram build: privatised in LDS
+    """d = N+1 selects the solver kernel: one wavefront (Gram in LDS, or 4/8 q values per lane with rows from L2),
+    blocked Gauss-Seidel over 16 wavefronts (d > 512), super-blocks with a multi-workgroup update (d > 2048);
+    all must follow the oracle's iterate sequence.  gram_path forces the Gram build: privatised in LDS
     (d <= 128: whole, d <= 1024: tile pairs) or global integer atomics -- the default picks by the number of pairs."""
     if gram_path:
         monkeypatch.setenv("KLR_GRAM_PATH", gram_path)
