@@ -978,29 +978,35 @@ __global__ __launch_bounds__(1024) void k_cd_sb_stop(CdArgs a, int k, const doub
 }
 #undef CDB_STEP
 
-// q = G theta (zero coefficients skipped, k ascending: the same sums as the in-kernel loop), a wavefront per 64
-// coordinates instead of one wavefront for all of them
-__global__ __launch_bounds__(64) void k_gtheta(const double* __restrict__ G, const double* __restrict__ theta, int d,
-                                               double* __restrict__ q) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+// q = G theta (zero coefficients skipped), a workgroup per 64 coordinates: four wavefronts each sum a quarter of the
+// rows (k ascending inside a quarter), the quarters are added in a fixed order.  (One wavefront per 64 coordinates
+// walking all d rows took 370 us at d = 5001.)
+__global__ __launch_bounds__(256) void k_gtheta(const double* __restrict__ G, const double* __restrict__ theta, int d,
+                                                double* __restrict__ q) {
+  __shared__ double sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
   const int ic = i < d ? i : d - 1;
+  const int per = (d + 3) / 4, k0 = w * per, k1 = k0 + per < d ? k0 + per : d;
   double s = 0.0;
-  // loads unconditional and eight in flight (a load behind the `t != 0` branch is one L2 round trip per k: 147 us at
-  // d = 501); the zero coefficients are still skipped in the sum
-  int k = 0;
-  for (; k + 8 <= d; k += 8) {
+  // loads unconditional and eight in flight (a load behind the `t != 0` branch is one L2 round trip per k); the zero
+  // coefficients are still skipped in the sum
+  int k = k0;
+  for (; k + 8 <= k1; k += 8) {
     double g[8], t[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) { g[u] = G[(i64)(k + u) * d + ic]; t[u] = theta[k + u]; }
 #pragma unroll
     for (int u = 0; u < 8; u++) { const double v = s + g[u] * t[u]; s = t[u] != 0.0 ? v : s; }
   }
-  for (; k < d; k++) {
+  for (; k < k1; k++) {
     const double t = theta[k];
     const double v = s + G[(i64)k * d + ic] * t;
     s = t != 0.0 ? v : s;
   }
-  if (i < d) q[i] = s;
+  sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < d) q[i] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // d <= 128: the same wave-synchronous sweeps with every operand in LDS at padded strides, so that a step is its
@@ -1408,7 +1414,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       a.q_io = nullptr; a.q_load = 0;
       if (d > 128) {
         a.q_io = q_dev; a.q_load = 1;
-        if (q_stale) hipLaunchKernelGGL(k_gtheta, dim3((unsigned)ceil_div((i64)d, (i64)64)), dim3(64), 0, st, G, thd, d, q_dev);
+        if (q_stale) hipLaunchKernelGGL(k_gtheta, dim3((unsigned)ceil_div((i64)d, (i64)64)), dim3(256), 0, st, G, thd, d, q_dev);
         q_stale = false;
       }
       if (d <= 128) {

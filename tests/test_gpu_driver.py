@@ -108,6 +108,37 @@ def test_allreduce_hook_f64_and_int64(ctx):
     assert 0 in seen and 1 in seen
 
 
+@pytest.mark.parametrize("N", [150, 600])
+def test_allreduce_hook_large_selection(ctx, N, monkeypatch):
+    """The same emulated second rank for the solver paths of larger selections: tiled Gram partials reduced to the
+    integer Gram, all-reduced and assembled around the hook (128 < d <= 1024), q = G theta carried between batches,
+    the wave (d <= 512) and blocked (d > 512) sweeps."""
+    hip = C.CDLL("libamdhip64.so")
+
+    def hook(buf, count, dtype, stream):
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        host = np.empty(count, dtype=np.int64 if dtype == 1 else np.float64)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(buf), C.c_size_t(count * 8), 2) == 0
+        host *= 2
+        assert hip.hipMemcpy(C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), C.c_size_t(count * 8), 1) == 0
+
+    monkeypatch.setenv("KLR_GRAM_PATH", "lds")
+    x, labels = O.synth_csr(13, 0, 3000, 3000, 8192, 400, 2 * N)
+    cw = O.class_weights(labels)
+    base = K.Context(0)
+    m1 = K.Matrix.from_csr(base, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    r1 = K.sweep_select(base, m1, None, None, np.zeros(1), cw, N)
+    cols = np.nonzero(r1["b"])[0]
+    c2 = K.Context(0)
+    c2.set_allreduce(hook, 0, 2)
+    m2 = K.Matrix.from_csr(c2, x.n, x.dim, x.rowptr, x.col, x.val, labels, n_total=2 * x.n)
+    t1, rec1 = K.cd_solve(base, m1.select_columns(cols), np.zeros(len(cols)), cw=cw, l1reg=r1["lam"] * x.n, max_iter=40)
+    t2, rec2 = K.cd_solve(c2, m2.select_columns(cols), np.zeros(len(cols)), cw=cw, l1reg=r1["lam"] * 2 * x.n, max_iter=40)
+    assert len(rec1) == len(rec2)
+    np.testing.assert_allclose(t2, t1, rtol=1e-6, atol=1e-10)
+    m1.close(); m2.close(); c2.close(); base.close()
+
+
 def test_active_row_masks_on_gpu(ctx):
     """klr_mat_set_active_rows: masked sums equal the oracle on the filtered rows (tiled and plain layouts)."""
     for shape in ((6000, 6000, 4096, 250, 16), (500, 500, 300, 60, 8)):
