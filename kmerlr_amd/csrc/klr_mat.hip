@@ -801,6 +801,150 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
   for (i64 e = o + lane; e < de; e += 64) { rcrow[e] = 0u; rcval[e] = 0.0; }
 }
 
+// ---- row-block binned variant (<= 256 selected columns): no global atomics, no scattered stores, no scan launches --
+// The flat kernels above spend their time on random 8-byte writes (1M atomicOr in 27 us, 2M scattered stores in 29 us
+// at configs[2]).  Here a workgroup owns RB_ROWS consecutive rows: the part of every selected column that falls in
+// its rows is found by binary search (the rows of a column ascend), the row masks are built with LDS atomics, and the
+// rows' entries are placed in an LDS image of the block's CSR segment that is written out in one coalesced pass.
+//   k_red_bin_a: searches, reduced CSC copy, masks -> global masks, per-block entry totals, segment table
+//   k_red_bin_b: block base = sum of the totals before it, row offsets by a block scan, CSR segment via LDS
+#define RB_ROWS 1024
+#define RB_WMAX 4                       // mask words per row (<= 256 columns)
+#define RB_CMAX 256
+#define RB_TCAP 8192                    // entries of a block staged in LDS (more: scattered stores for that block)
+
+__device__ __forceinline__ u32 rb_lower_bound(const u32* __restrict__ a, u32 len, u32 key) {   // first index with a[i] >= key
+  u32 lo = 0, hi = len;
+  while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(1024) void k_red_bin_a(const i64* __restrict__ src_colptr, const u32* __restrict__ crow,
+                                                    const VT* __restrict__ cval, const i64* __restrict__ sel,
+                                                    const i64* __restrict__ dst_colptr, const u32* __restrict__ dst_len, int c1,
+                                                    const double* __restrict__ scale, i64 n, int W,
+                                                    u32* __restrict__ rcrow, double* __restrict__ rcval,
+                                                    unsigned long long* __restrict__ gmask, u32* __restrict__ blocktot,
+                                                    u32* __restrict__ seg /* nblk x c1 x 2 */) {
+  __shared__ unsigned long long smask[RB_ROWS * RB_WMAX];
+  __shared__ u32 s_lo[RB_CMAX], s_pre[RB_CMAX + 1];
+  __shared__ u32 s_wsum[16];
+  const int tid = threadIdx.x;
+  const i64 r0 = (i64)blockIdx.x * RB_ROWS;
+  const int nr = (int)(n - r0 < RB_ROWS ? n - r0 : RB_ROWS);
+  for (int t = tid; t < RB_ROWS * W; t += 1024) smask[t] = 0ull;
+  if (tid < c1) {
+    const i64 sb = src_colptr[sel[tid]];
+    const u32 len = dst_len[tid];
+    const u32 lo = rb_lower_bound(crow + sb, len, (u32)r0);
+    const u32 hi = rb_lower_bound(crow + sb, len, (u32)(r0 + nr));
+    s_lo[tid] = lo; s_pre[tid] = hi - lo;
+    seg[((size_t)blockIdx.x * c1 + tid) * 2] = lo; seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1] = hi - lo;
+  }
+  __syncthreads();
+  if (tid == 0) {                                      // exclusive prefix of the segment lengths (c1 <= 256)
+    u32 acc = 0;
+    for (int p = 0; p < c1; p++) { const u32 v = s_pre[p]; s_pre[p] = acc; acc += v; }
+    s_pre[c1] = acc;
+  }
+  __syncthreads();
+  const u32 T = s_pre[c1];
+  for (u32 e = tid; e < T; e += 1024) {
+    int lo = 0, hi = c1;                               // column: largest p with s_pre[p] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; }
+    const int p = lo;
+    const u32 off = s_lo[p] + (e - s_pre[p]);
+    const i64 sb = src_colptr[sel[p]];
+    const u32 r = crow[sb + off];
+    const i64 de = dst_colptr[p] + off;
+    rcrow[de] = r; rcval[de] = (double)cval[sb + off] * (scale ? scale[p] : 1.0);
+    atomicOr(&smask[(size_t)(r - (u32)r0) * W + (p >> 6)], 1ull << (p & 63));
+  }
+  // padding of the reduced CSC columns (to multiples of 4 entries): block 0
+  if (blockIdx.x == 0 && tid < c1) {
+    const i64 db = dst_colptr[tid], de = dst_colptr[tid + 1];
+    for (i64 e = db + dst_len[tid]; e < de; e++) { rcrow[e] = 0u; rcval[e] = 0.0; }
+  }
+  __syncthreads();
+  u32 cntr = 0;
+  if (tid < nr) for (int w = 0; w < W; w++) cntr += (u32)__popcll(smask[(size_t)tid * W + w]);
+  for (int t = tid; t < nr * W; t += 1024) gmask[(size_t)r0 * W + t] = smask[t];
+  for (int o = 32; o > 0; o >>= 1) cntr += __shfl_xor(cntr, o, 64);
+  if ((tid & 63) == 0) s_wsum[tid >> 6] = cntr;
+  __syncthreads();
+  if (tid == 0) { u32 acc = 0; for (int w = 0; w < 16; w++) acc += s_wsum[w]; blocktot[blockIdx.x] = acc; }
+}
+
+__global__ __launch_bounds__(1024) void k_red_bin_b(const i64* __restrict__ dst_colptr, int c1, i64 n, int W,
+                                                    const u32* __restrict__ rcrow, const double* __restrict__ rcval,
+                                                    const unsigned long long* __restrict__ gmask, const u32* __restrict__ blocktot,
+                                                    const u32* __restrict__ seg, i64* __restrict__ rrowptr,
+                                                    u32* __restrict__ rcol, double* __restrict__ rval) {
+  extern __shared__ unsigned char rb_lds[];
+  unsigned long long* smask = reinterpret_cast<unsigned long long*>(rb_lds);              // RB_ROWS * W
+  double* sval = reinterpret_cast<double*>(smask + (size_t)RB_ROWS * W);                  // RB_TCAP
+  u32* scol = reinterpret_cast<u32*>(sval + RB_TCAP);                                     // RB_TCAP
+  u32* s_off = scol + RB_TCAP;                                                            // RB_ROWS + 1: row offsets inside the block
+  __shared__ u32 s_lo[RB_CMAX], s_pre[RB_CMAX + 1];
+  __shared__ u32 s_wsum[17];
+  __shared__ i64 s_base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const i64 r0 = (i64)blockIdx.x * RB_ROWS;
+  const int nr = (int)(n - r0 < RB_ROWS ? n - r0 : RB_ROWS);
+  // block base: entries of all blocks before this one
+  if (w == 0) {
+    i64 acc = 0;
+    for (int b = lane; b < (int)blockIdx.x; b += 64) acc += blocktot[b];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) s_base = acc;
+  }
+  for (int t = tid; t < nr * W; t += 1024) smask[t] = gmask[(size_t)r0 * W + t];
+  if (tid < c1) { s_lo[tid] = seg[((size_t)blockIdx.x * c1 + tid) * 2]; s_pre[tid] = seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1]; }
+  __syncthreads();
+  if (tid == 0) {
+    u32 acc = 0;
+    for (int p = 0; p < c1; p++) { const u32 v = s_pre[p]; s_pre[p] = acc; acc += v; }
+    s_pre[c1] = acc;
+  }
+  // exclusive scan of the row counts over the block (one row per thread)
+  u32 cntr = 0;
+  if (tid < nr) for (int ww = 0; ww < W; ww++) cntr += (u32)__popcll(smask[(size_t)tid * W + ww]);
+  u32 incl = cntr;
+  for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  if (tid == 0) { u32 acc = 0; for (int t = 0; t < 16; t++) { const u32 v = s_wsum[t]; s_wsum[t] = acc; acc += v; } s_wsum[16] = acc; }
+  __syncthreads();
+  const u32 excl = s_wsum[w] + incl - cntr;
+  const u32 T = s_wsum[16];
+  const i64 base = s_base;
+  s_off[tid] = excl;                                   // tid < RB_ROWS always (1024 threads)
+  if (tid < nr) rrowptr[r0 + tid] = base + excl;
+  if (r0 + nr == n && tid == 0) rrowptr[n] = base + T;
+  __syncthreads();
+  const bool staged = T <= RB_TCAP;
+  const u32 TE = s_pre[c1];                            // == T
+  for (u32 e = tid; e < TE; e += 1024) {
+    int lo = 0, hi = c1;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; }
+    const int p = lo;
+    const i64 de = dst_colptr[p] + s_lo[p] + (e - s_pre[p]);
+    const u32 rl = rcrow[de] - (u32)r0;
+    const unsigned long long* mr = smask + (size_t)rl * W;
+    int below = 0;
+    for (int ww = 0; ww < (p >> 6); ww++) below += __popcll(mr[ww]);
+    below += __popcll(mr[p >> 6] & ((1ull << (p & 63)) - 1ull));
+    const u32 slot = s_off[rl] + (u32)below;
+    if (staged) { scol[slot] = (u32)p; sval[slot] = rcval[de]; }
+    else { rcol[base + slot] = (u32)p; rval[base + slot] = rcval[de]; }
+  }
+  if (staged) {
+    __syncthreads();
+    for (u32 t = tid; t < T; t += 1024) { rcol[base + t] = scol[t]; rval[base + t] = sval[t]; }
+  }
+}
+
 // in-row insertion sort by (distinct) reduced column id -> deterministic, ascending rows
 __global__ __launch_bounds__(256) void k_sort_rows(const i64* __restrict__ rrowptr, i64 n, u32* __restrict__ rcol,
                                                    double* __restrict__ rval) {
@@ -978,7 +1122,39 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
     } else {
       // row marks: bit masks (sorted rows for free) when they are small, else counters + cursor + in-row sort
       const int W = (int)ceil_div(c1, (i64)64);
-      const bool use_mask = W <= RED_MASK_WORDS_MAX && !getenv("KLR_SUBSELECT_SORT");
+      const char* ss_env = getenv("KLR_SUBSELECT");         // bin | flat | sort (tests); default: the first that applies
+      const bool use_bin = !any_zero && n > 0 && c1 <= RB_CMAX && n < ((i64)1 << 32) && !getenv("KLR_SUBSELECT_SORT") &&
+                           (!ss_env || ss_env[0] == 'b');
+      if (use_bin) {
+        const i64 nblk = ceil_div(n, (i64)RB_ROWS);
+        char* wsb;
+        const size_t m_bytes = al(nn * (size_t)W * 8), t_bytes = al((size_t)nblk * 4), s_bytes = al((size_t)nblk * c1 * 8);
+        if ((rc = ws_get(ctx, WS_TMP1, m_bytes + t_bytes + s_bytes, (void**)&wsb))) break;
+        unsigned long long* gmask = (unsigned long long*)wsb;
+        u32* blocktot = (u32*)(wsb + m_bytes);
+        u32* seg = (u32*)(wsb + m_bytes + t_bytes);
+        const size_t ldsb = (size_t)RB_ROWS * W * 8 + (size_t)RB_TCAP * 12 + (size_t)(RB_ROWS + 1) * 4;
+        static bool attr = false;
+        if (!attr) {
+          hipError_t ea = hipFuncSetAttribute((const void*)k_red_bin_b, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)((size_t)RB_ROWS * RB_WMAX * 8 + (size_t)RB_TCAP * 12 + (size_t)(RB_ROWS + 1) * 4));
+          if (ea != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns: %s", hipGetErrorString(ea)); break; }
+          attr = true;
+        }
+        if (full->val_f64)
+          hipLaunchKernelGGL(k_red_bin_a<double>, dim3((unsigned)nblk), dim3(1024), 0, st, full->colptr, full->crow, (const double*)full->cval,
+                             d_sel, r->colptr, d_dstlen, (int)c1, scp, n, W, r->crow, (double*)r->cval, gmask, blocktot, seg);
+        else
+          hipLaunchKernelGGL(k_red_bin_a<float>, dim3((unsigned)nblk), dim3(1024), 0, st, full->colptr, full->crow, (const float*)full->cval,
+                             d_sel, r->colptr, d_dstlen, (int)c1, scp, n, W, r->crow, (double*)r->cval, gmask, blocktot, seg);
+        hipLaunchKernelGGL(k_red_bin_b, dim3((unsigned)nblk), dim3(1024), ldsb, st, r->colptr, (int)c1, n, W, r->crow,
+                           (const double*)r->cval, (const unsigned long long*)gmask, (const u32*)blocktot, (const u32*)seg, r->rowptr,
+                           r->col, (double*)r->val);
+        e = hipGetLastError();
+        if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns launch failed: %s", hipGetErrorString(e)); break; }
+        break;
+      }
+      const bool use_mask = W <= RED_MASK_WORDS_MAX && !getenv("KLR_SUBSELECT_SORT") && !(ss_env && ss_env[0] == 's');
       u32* cnt; unsigned long long* mask = nullptr;
       const size_t cnt_bytes = al(nn * sizeof(u32));
       if ((rc = ws_get(ctx, WS_TMP1, cnt_bytes + (use_mask ? nn * (size_t)W * 8 : 0), (void**)&cnt))) break;

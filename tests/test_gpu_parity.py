@@ -76,15 +76,17 @@ def test_roundtrip_and_select_columns(ctx, synth_small):
         np.testing.assert_array_equal(val, ro.val)         # same single multiply -> bit-exact
 
 
-@pytest.mark.parametrize("ncols,sort_path", [(1, False), (40, True), (700, False), (1500, False)])
-def test_select_columns_paths_and_block_reuse(ctx, synth_small, monkeypatch, ncols, sort_path):
-    """Bit-mask ranks (<= 1024 columns), counters + in-row sort (more columns, or KLR_SUBSELECT_SORT), and the pooled
-    block of a released reduced matrix handed to the next sub-select: same CSR as featureSelection.Data + Transform
-    (oracle), same column sums through the reduced CSC."""
+@pytest.mark.parametrize("ncols,mode", [(1, None), (40, "sort"), (40, "flat"), (40, None), (200, None), (256, None),
+                                        (700, None), (1500, None)])
+def test_select_columns_paths_and_block_reuse(ctx, synth_small, monkeypatch, ncols, mode):
+    """Row-block binning in LDS (<= 256 columns, the default), flat kernels with bit-mask ranks (<= 1024 columns, or
+    KLR_SUBSELECT=flat), counters + in-row sort (more columns, or KLR_SUBSELECT=sort), and the pooled block of a
+    released reduced matrix handed to the next sub-select: same CSR as featureSelection.Data + Transform (oracle),
+    same column sums through the reduced CSC."""
     x, labels = synth_small
     m = upload(ctx, x, labels)
-    if sort_path:
-        monkeypatch.setenv("KLR_SUBSELECT_SORT", "1")
+    if mode:
+        monkeypatch.setenv("KLR_SUBSELECT", mode)
     rng = np.random.default_rng(ncols)
     for rep in range(3):                                   # released blocks are reused by the next call
         k = max(0, ncols - 1 - 7 * rep)
