@@ -808,10 +808,10 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
 // rows' entries are placed in an LDS image of the block's CSR segment that is written out in one coalesced pass.
 //   k_red_bin_a: searches, reduced CSC copy, masks -> global masks, per-block entry totals, segment table
 //   k_red_bin_b: block base = sum of the totals before it, row offsets by a block scan, CSR segment via LDS
-#define RB_ROWS 1024
+#define RB_ROWS 512                     // 196 workgroups at n = 100k: half the trips per workgroup of 1024 rows
 #define RB_WMAX 4                       // mask words per row (<= 256 columns)
 #define RB_CMAX 256
-#define RB_TCAP 8192                    // entries of a block staged in LDS (more: scattered stores for that block)
+#define RB_TCAP 6144                    // entries of a block staged in LDS (more: scattered stores for that block)
 
 __device__ __forceinline__ u32 rb_lower_bound(const u32* __restrict__ a, u32 len, u32 key) {   // first index with a[i] >= key
   u32 lo = 0, hi = len;
@@ -829,6 +829,8 @@ __global__ __launch_bounds__(1024) void k_red_bin_a(const i64* __restrict__ src_
                                                     u32* __restrict__ seg /* nblk x c1 x 2 */) {
   __shared__ unsigned long long smask[RB_ROWS * RB_WMAX];
   __shared__ u32 s_lo[RB_CMAX], s_pre[RB_CMAX + 1];
+  __shared__ i64 s_src[RB_CMAX], s_dst[RB_CMAX];       // source / destination offset of the segment's first entry
+  __shared__ double s_sc[RB_CMAX];
   __shared__ u32 s_wsum[16];
   const int tid = threadIdx.x;
   const i64 r0 = (i64)blockIdx.x * RB_ROWS;
@@ -840,6 +842,7 @@ __global__ __launch_bounds__(1024) void k_red_bin_a(const i64* __restrict__ src_
     const u32 lo = rb_lower_bound(crow + sb, len, (u32)r0);
     const u32 hi = rb_lower_bound(crow + sb, len, (u32)(r0 + nr));
     s_lo[tid] = lo; s_pre[tid] = hi - lo;
+    s_src[tid] = sb + lo; s_dst[tid] = dst_colptr[tid] + lo; s_sc[tid] = scale ? scale[tid] : 1.0;
     seg[((size_t)blockIdx.x * c1 + tid) * 2] = lo; seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1] = hi - lo;
   }
   __syncthreads();
@@ -854,11 +857,10 @@ __global__ __launch_bounds__(1024) void k_red_bin_a(const i64* __restrict__ src_
     int lo = 0, hi = c1;                               // column: largest p with s_pre[p] <= e
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; }
     const int p = lo;
-    const u32 off = s_lo[p] + (e - s_pre[p]);
-    const i64 sb = src_colptr[sel[p]];
-    const u32 r = crow[sb + off];
-    const i64 de = dst_colptr[p] + off;
-    rcrow[de] = r; rcval[de] = (double)cval[sb + off] * (scale ? scale[p] : 1.0);
+    const u32 k = e - s_pre[p];                        // every per-column quantity from LDS: one round trip per entry
+    const i64 se = s_src[p] + k, de = s_dst[p] + k;
+    const u32 r = crow[se];
+    rcrow[de] = r; rcval[de] = (double)cval[se] * s_sc[p];
     atomicOr(&smask[(size_t)(r - (u32)r0) * W + (p >> 6)], 1ull << (p & 63));
   }
   // padding of the reduced CSC columns (to multiples of 4 entries): block 0
@@ -886,7 +888,8 @@ __global__ __launch_bounds__(1024) void k_red_bin_b(const i64* __restrict__ dst_
   double* sval = reinterpret_cast<double*>(smask + (size_t)RB_ROWS * W);                  // RB_TCAP
   u32* scol = reinterpret_cast<u32*>(sval + RB_TCAP);                                     // RB_TCAP
   u32* s_off = scol + RB_TCAP;                                                            // RB_ROWS + 1: row offsets inside the block
-  __shared__ u32 s_lo[RB_CMAX], s_pre[RB_CMAX + 1];
+  __shared__ u32 s_pre[RB_CMAX + 1];
+  __shared__ i64 s_dst[RB_CMAX];
   __shared__ u32 s_wsum[17];
   __shared__ i64 s_base;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(1024) void k_red_bin_b(const i64* __restrict__ dst_
     if (lane == 0) s_base = acc;
   }
   for (int t = tid; t < nr * W; t += 1024) smask[t] = gmask[(size_t)r0 * W + t];
-  if (tid < c1) { s_lo[tid] = seg[((size_t)blockIdx.x * c1 + tid) * 2]; s_pre[tid] = seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1]; }
+  if (tid < c1) { s_dst[tid] = dst_colptr[tid] + seg[((size_t)blockIdx.x * c1 + tid) * 2]; s_pre[tid] = seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1]; }
   __syncthreads();
   if (tid == 0) {
     u32 acc = 0;
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(1024) void k_red_bin_b(const i64* __restrict__ dst_
   const u32 excl = s_wsum[w] + incl - cntr;
   const u32 T = s_wsum[16];
   const i64 base = s_base;
-  s_off[tid] = excl;                                   // tid < RB_ROWS always (1024 threads)
+  if (tid < RB_ROWS) s_off[tid] = excl;
   if (tid < nr) rrowptr[r0 + tid] = base + excl;
   if (r0 + nr == n && tid == 0) rrowptr[n] = base + T;
   __syncthreads();
@@ -929,15 +932,16 @@ __global__ __launch_bounds__(1024) void k_red_bin_b(const i64* __restrict__ dst_
     int lo = 0, hi = c1;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= e) lo = mid; else hi = mid; }
     const int p = lo;
-    const i64 de = dst_colptr[p] + s_lo[p] + (e - s_pre[p]);
+    const i64 de = s_dst[p] + (e - s_pre[p]);
+    const double v = rcval[de];
     const u32 rl = rcrow[de] - (u32)r0;
     const unsigned long long* mr = smask + (size_t)rl * W;
     int below = 0;
     for (int ww = 0; ww < (p >> 6); ww++) below += __popcll(mr[ww]);
     below += __popcll(mr[p >> 6] & ((1ull << (p & 63)) - 1ull));
     const u32 slot = s_off[rl] + (u32)below;
-    if (staged) { scol[slot] = (u32)p; sval[slot] = rcval[de]; }
-    else { rcol[base + slot] = (u32)p; rval[base + slot] = rcval[de]; }
+    if (staged) { scol[slot] = (u32)p; sval[slot] = v; }
+    else { rcol[base + slot] = (u32)p; rval[base + slot] = v; }
   }
   if (staged) {
     __syncthreads();
