@@ -808,15 +808,29 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
 // rows' entries are placed in an LDS image of the block's CSR segment that is written out in one coalesced pass.
 //   k_red_bin_a: searches, reduced CSC copy, masks -> global masks, per-block entry totals, segment table
 //   k_red_bin_b: block base = sum of the totals before it, row offsets by a block scan, CSR segment via LDS
-#define RB_ROWS 512                     // 196 workgroups at n = 100k: half the trips per workgroup of 1024 rows
+#define RB_ROWS 256
 #define RB_WMAX 4                       // mask words per row (<= 256 columns)
 #define RB_CMAX 256
-#define RB_TCAP 6144                    // entries of a block staged in LDS (more: scattered stores for that block)
+#define RB_TCAP 3584                    // entries of a block staged in LDS (more: scattered stores for that block)
 
 __device__ __forceinline__ u32 rb_lower_bound(const u32* __restrict__ a, u32 len, u32 key) {   // first index with a[i] >= key
   u32 lo = 0, hi = len;
   while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
   return lo;
+}
+
+// exclusive prefix of a[0 .. c) in place, a[c] = total; one wavefront, four consecutive values per lane (c <= 256).
+// (One thread walking 101 values through LDS was 6 us of a 24 us kernel.)
+__device__ __forceinline__ void rb_prefix(u32* a, int c, int lane) {
+  u32 v[4], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = lane * 4 + u; v[u] = i < c ? a[i] : 0u; sum += v[u]; }
+  u32 incl = sum;
+  for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  u32 acc = incl - sum;
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const int i = lane * 4 + u; if (i < c) a[i] = acc; acc += v[u]; }
+  if (lane == 63) a[c] = incl;
 }
 
 template <typename VT>
@@ -846,11 +860,7 @@ __global__ __launch_bounds__(1024) void k_red_bin_a(const i64* __restrict__ src_
     seg[((size_t)blockIdx.x * c1 + tid) * 2] = lo; seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1] = hi - lo;
   }
   __syncthreads();
-  if (tid == 0) {                                      // exclusive prefix of the segment lengths (c1 <= 256)
-    u32 acc = 0;
-    for (int p = 0; p < c1; p++) { const u32 v = s_pre[p]; s_pre[p] = acc; acc += v; }
-    s_pre[c1] = acc;
-  }
+  if (tid < 64) rb_prefix(s_pre, c1, tid);             // exclusive prefix of the segment lengths (c1 <= 256)
   __syncthreads();
   const u32 T = s_pre[c1];
   for (u32 e = tid; e < T; e += 1024) {
@@ -905,11 +915,7 @@ __global__ __launch_bounds__(1024) void k_red_bin_b(const i64* __restrict__ dst_
   for (int t = tid; t < nr * W; t += 1024) smask[t] = gmask[(size_t)r0 * W + t];
   if (tid < c1) { s_dst[tid] = dst_colptr[tid] + seg[((size_t)blockIdx.x * c1 + tid) * 2]; s_pre[tid] = seg[((size_t)blockIdx.x * c1 + tid) * 2 + 1]; }
   __syncthreads();
-  if (tid == 0) {
-    u32 acc = 0;
-    for (int p = 0; p < c1; p++) { const u32 v = s_pre[p]; s_pre[p] = acc; acc += v; }
-    s_pre[c1] = acc;
-  }
+  if (tid < 64) rb_prefix(s_pre, c1, tid);             // exclusive prefix of the segment lengths (c1 <= 256)
   // exclusive scan of the row counts over the block (one row per thread)
   u32 cntr = 0;
   if (tid < nr) for (int ww = 0; ww < W; ww++) cntr += (u32)__popcll(smask[(size_t)tid * W + ww]);
