@@ -801,7 +801,7 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
   for (i64 e = o + lane; e < de; e += 64) { rcrow[e] = 0u; rcval[e] = 0.0; }
 }
 
-// ---- row-block binned variant (<= 256 selected columns): no global atomics, no scattered stores, no scan launches --
+// ---- row-block binned variant (<= 1024 selected columns): no global atomics, no scattered stores, no scan launches --
 // The flat kernels above spend their time on random 8-byte writes (1M atomicOr in 27 us, 2M scattered stores in 29 us
 // at configs[2]).  Here a workgroup owns RB_ROWS consecutive rows: the part of every selected column that falls in
 // its rows is found by binary search (the rows of a column ascend), the row masks are built with LDS atomics, and the
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
 //   k_red_bin_a: searches, reduced CSC copy, masks -> global masks, per-block entry totals, segment table
 //   k_red_bin_b: block base = sum of the totals before it, row offsets by a block scan, CSR segment via LDS
 #define RB_ROWS 256
-#define RB_WMAX 4                       // mask words per row (<= 256 columns)
-#define RB_CMAX 256
+#define RB_WMAX 16                      // mask words per row
+#define RB_CMAX 1024                    // selected columns (one search thread each)
 #define RB_TCAP 3584                    // entries of a block staged in LDS (more: scattered stores for that block)
 
 __device__ __forceinline__ u32 rb_lower_bound(const u32* __restrict__ a, u32 len, u32 key) {   // first index with a[i] >= key
@@ -819,17 +819,17 @@ __device__ __forceinline__ u32 rb_lower_bound(const u32* __restrict__ a, u32 len
   return lo;
 }
 
-// exclusive prefix of a[0 .. c) in place, a[c] = total; one wavefront, four consecutive values per lane (c <= 256).
-// (One thread walking 101 values through LDS was 6 us of a 24 us kernel.)
+// exclusive prefix of a[0 .. c) in place, a[c] = total; one wavefront, RB_CMAX / 64 consecutive values per lane
 __device__ __forceinline__ void rb_prefix(u32* a, int c, int lane) {
-  u32 v[4], sum = 0;
+  constexpr int PL = RB_CMAX / 64;
+  u32 v[PL], sum = 0;
 #pragma unroll
-  for (int u = 0; u < 4; u++) { const int i = lane * 4 + u; v[u] = i < c ? a[i] : 0u; sum += v[u]; }
+  for (int u = 0; u < PL; u++) { const int i = lane * PL + u; v[u] = i < c ? a[i] : 0u; sum += v[u]; }
   u32 incl = sum;
   for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
   u32 acc = incl - sum;
 #pragma unroll
-  for (int u = 0; u < 4; u++) { const int i = lane * 4 + u; if (i < c) a[i] = acc; acc += v[u]; }
+  for (int u = 0; u < PL; u++) { const int i = lane * PL + u; if (i < c) a[i] = acc; acc += v[u]; }
   if (lane == 63) a[c] = incl;
 }
 

@@ -77,10 +77,10 @@ def test_roundtrip_and_select_columns(ctx, synth_small):
 
 
 @pytest.mark.parametrize("ncols,mode", [(1, None), (40, "sort"), (40, "flat"), (40, None), (200, None), (256, None),
-                                        (700, None), (1500, None)])
+                                        (700, None), (700, "flat"), (1024, None), (1500, None)])
 def test_select_columns_paths_and_block_reuse(ctx, synth_small, monkeypatch, ncols, mode):
-    """Row-block binning in LDS (<= 256 columns, the default), flat kernels with bit-mask ranks (<= 1024 columns, or
-    KLR_SUBSELECT=flat), counters + in-row sort (more columns, or KLR_SUBSELECT=sort), and the pooled block of a
+    """Row-block binning in LDS (<= 1024 columns, the default), flat kernels with bit-mask ranks (KLR_SUBSELECT=flat),
+    counters + in-row sort (more columns, or KLR_SUBSELECT=sort), and the pooled block of a
     released reduced matrix handed to the next sub-select: same CSR as featureSelection.Data + Transform (oracle),
     same column sums through the reduced CSC."""
     x, labels = synth_small
