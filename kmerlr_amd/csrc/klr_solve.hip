@@ -1173,18 +1173,19 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
 // iterate -- so the exp / log1p of the KSPEC iterates of a row run side by side instead of one after the other (a
 // thread per row spent most of its 30 us there); the entries of a row are same-address loads for its 8 lanes; the
 // iterates are staged in LDS as [column][k].  32 rows per block, block partials in a fixed order.
-#define LM_ROWS (256 / KSPEC)
+#define LM_THREADS 1024                 // 128 rows per block: the iterates are staged once per 128 rows
+#define LM_ROWS (LM_THREADS / KSPEC)
 template <bool LDS>
-__global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+__global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                     const double* __restrict__ val, const uint8_t* __restrict__ labels,
                                                     const uint8_t* __restrict__ active,
                                                     i64 n, int d, const double* __restrict__ hist, const int* __restrict__ ndone,
                                                     double cw0, double cw1, double* __restrict__ blk) {
   extern __shared__ double lm_lds[];            // KSPEC * d iterates, layout [column][k]
-  __shared__ double sh[KSPEC][4];
+  __shared__ double sh[KSPEC][LM_THREADS / 64];
   const int K = *ndone;
   if (LDS) {
-    for (int t = threadIdx.x; t < KSPEC * d; t += 256) {
+    for (int t = threadIdx.x; t < KSPEC * d; t += LM_THREADS) {
       const int c = t / KSPEC, k = t % KSPEC;
       lm_lds[t] = k < K ? hist[(i64)k * d + c] : 0.0;
     }
@@ -1209,8 +1210,11 @@ __global__ __launch_bounds__(256) void k_loss_multi(const i64* __restrict__ rowp
   for (int o = 32; o >= KSPEC; o >>= 1) v += __shfl_xor(v, o, 64);
   if ((threadIdx.x & 63) < KSPEC) sh[k][threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x < KSPEC) blk[(i64)blockIdx.x * KSPEC + threadIdx.x] =
-      (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+  if (threadIdx.x < KSPEC) {
+    double acc = 0.0;
+    for (int ww = 0; ww < LM_THREADS / 64; ww++) acc += sh[threadIdx.x][ww];
+    blk[(i64)blockIdx.x * KSPEC + threadIdx.x] = acc;
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_sum_partials_multi(const double* __restrict__ blk, i64 nb, double* __restrict__ out) {
@@ -1445,13 +1449,13 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       }
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
       if (eval_loss) {
-        // iterates staged in LDS only while that is cheaper than reading them where they are: a block of 32 rows
+        // iterates staged in LDS only while that is cheaper than reading them where they are: a block of LM_ROWS rows
         // stages KSPEC * d values but uses ~KSPEC * 32 * (row length) of them
-        if ((double)d <= 32.0 * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024)
-          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nb), dim3(256), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
+        if ((double)d <= (double)LM_ROWS * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024)
+          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nb), dim3(LM_THREADS), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
         else
-          hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nb), dim3(256), 0, st, red->rowptr, red->col,
+          hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nb), dim3(LM_THREADS), 0, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
         hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
         KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
