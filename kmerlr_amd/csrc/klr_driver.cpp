@@ -134,12 +134,18 @@ static void adopt_selection(klr_estimator* e, const std::vector<uint8_t>& b) {
   std::vector<int64_t> nc;
   std::vector<double> nt;
   size_t q = 0;
-  for (int64_t j = 0; j < (int64_t)b.size(); j++) {
-    if (!b[j]) continue;
-    while (q < e->cols.size() && e->cols[q] < j) q++;
-    double t = 0.0;
-    if (q < e->cols.size() && e->cols[q] == j) t = e->theta[q];
-    nc.push_back(j); nt.push_back(t);
+  // the mask has a million entries at configs[3] and ~N set ones: skip the empty 8-byte words
+  const int64_t nb = (int64_t)b.size();
+  for (int64_t j0 = 0; j0 < nb; j0 += 8) {
+    if (j0 + 8 <= nb) { uint64_t wd; memcpy(&wd, b.data() + j0, 8); if (wd == 0) continue; }
+    const int64_t j1 = std::min(nb, j0 + 8);
+    for (int64_t j = j0; j < j1; j++) {
+      if (!b[j]) continue;
+      while (q < e->cols.size() && e->cols[q] < j) q++;
+      double t = 0.0;
+      if (q < e->cols.size() && e->cols[q] == j) t = e->theta[q];
+      nc.push_back(j); nt.push_back(t);
+    }
   }
   e->cols.swap(nc); e->theta.swap(nt);
 }
