@@ -1148,9 +1148,12 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
   if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
   CdlLane c; double q0, q1;
   cdl_init(a, lane, Gl, pk, c, q0, q1);
+  const int i0 = lane, i1 = 64 + lane;
+  // a later batch of the same inner loop continues with the q it left (re-forming q = G theta from theta rounds
+  // differently: the results would depend on where the batches end)
+  if (a.q_load) { q0 = i0 < d ? a.q_io[i0] : 0.0; q1 = i1 < d ? a.q_io[i1] : 0.0; }
   int zero_v;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));      // opaque: keeps the operand pointer in a vector register
-  const int i0 = lane, i1 = 64 + lane;
   int done = 0;
   for (int k = 0; k < a.K; k++) {
     double told0, told1, tn0, tn1, delta; int stop, nz;
@@ -1162,8 +1165,8 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
     done = k + 1;
     if (stop) break;
   }
-  if (i0 < d) a.theta[i0] = pk[4 * i0 + 3];
-  if (i1 < d) a.theta[i1] = pk[4 * i1 + 3];
+  if (i0 < d) { a.theta[i0] = pk[4 * i0 + 3]; if (a.q_io) a.q_io[i0] = q0; }
+  if (i1 < d) { a.theta[i1] = pk[4 * i1 + 3]; if (a.q_io) a.q_io[i1] = q1; }
   if (lane == 0) *a.ndone = done;
 }
 
@@ -1422,6 +1425,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         q_stale = false;
       }
       if (d <= 128) {
+        a.q_io = q_dev; a.q_load = q_stale ? 0 : 1;       // formed in the kernel (Gram in LDS) when theta or G changed
+        q_stale = false;
         CdTheta t0; t0.n = 0;
         if (thd_stale) { t0.n = d; memcpy(t0.v, th.data(), (size_t)d * 8); thd_stale = false; }   // the kernel writes thd
         hipLaunchKernelGGL(k_cd_lds2, dim3(1), dim3(1024), (size_t)(d + 1) * (CDL_STRIDE + 4) * sizeof(double), st, a, t0);
