@@ -187,3 +187,44 @@ def test_crossvalidation_on_gpu_matches_oracle_driver(ctx):
     np.testing.assert_allclose(rg["predictions"], ro["predictions"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(rg["loss_train"], ro["loss_train"], rtol=1e-8)
     np.testing.assert_allclose(rg["loss_test"], ro["loss_test"], rtol=1e-8)
+
+
+def test_full_size_estimate_kkt_and_reproducibility(ctx, monkeypatch):
+    """The whole leapfrog run at BASELINE configs[2] size (100k x 65,536, --lambda-auto=100), without the oracle (it would
+    take minutes): the classifier has exactly N nonzero coefficients, satisfies the KKT conditions of the L1 problem at
+    its lambda (|g_j| = lambda with the opposite sign on the support, bias gradient 0) to the accuracy the loss rule stops
+    at, is bit-identical from run to run, and does not depend on how the sweeps are batched."""
+    from kmerlr_amd import _driver
+    n, m, N = 100000, 65536, 100
+    rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
+    full = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels, n)
+
+    def run():
+        est = _driver.hip_estimator(ctx)
+        est.estimate(full._h, [N])
+        cl = est.classifiers()[0]
+        ep = est.epochs()
+        est.close()
+        return cl, ep
+
+    cl, ep = run()
+    cols, theta, lam = cl["cols"], cl["theta"], cl["lam"]
+    assert int(np.count_nonzero(theta[1:])) == N and len(cols) >= N + 1
+    red = full.select_columns(cols)
+    g = K.gradient_dense(ctx, red, theta, full.class_weights())
+    nz = theta[1:] != 0
+    assert abs(g[0]) < 1e-5
+    assert np.max(np.abs(np.abs(g[1:][nz]) - lam)) < 1e-3 * lam
+    assert np.all(np.sign(g[1:][nz]) == -np.sign(theta[1:][nz]))
+    if (~nz).any():
+        assert np.max(np.abs(g[1:][~nz])) <= lam * (1 + 1e-3)
+    cl2, ep2 = run()
+    np.testing.assert_array_equal(cl2["cols"], cols)
+    np.testing.assert_array_equal(cl2["theta"], theta)
+    assert ep2 == ep
+    monkeypatch.setenv("KLR_CD_BATCH", "3")
+    monkeypatch.setenv("KLR_CD_FIRST_BATCH", "8")
+    cl3, ep3 = run()
+    np.testing.assert_array_equal(cl3["cols"], cols)
+    np.testing.assert_array_equal(cl3["theta"], theta)
+    red.close(); full.close()
