@@ -421,7 +421,7 @@ __device__ __forceinline__ uint4 coo_load(const uint4* __restrict__ ent4, u32 q)
 template <int THREADS, int UNROLL, bool NT, int ABL, int FMT>
 __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ ent, const uint4* __restrict__ piece,
                                                        const uint4* __restrict__ wgrec, const u32* __restrict__ tileq,
-                                                       u32 nrt, u32 nct_or0, u32 RT, i64 n, const i64* __restrict__ S,
+                                                       u32 nrt, u32 nct_or0, u32 RT, u32 ntile, i64 n, const i64* __restrict__ S,
                                                        i64* __restrict__ part) {
   static_assert(FMT == FMT_U32 || UNROLL <= 2, "unit entries: one load per lane and trip (UNROLL 2 = ping-pong prefetch)");
   constexpr bool U24 = FMT == FMT_U24;
@@ -444,17 +444,26 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
     const u32 pq0 = d.y, pq1 = d.z;
     __syncthreads();                                    // previous piece written out
     for (u32 i = tid; i < TILE_DIM; i += THREADS) sG[i] = 0ull;
-    // walk down the piece: one s tile per row tile
+    // walk down the piece: one s tile per row tile.  A workgroup with many short tiles (a 1M-column shard: ~16 tiles of
+    // ~16k entries each) used to pay three dependent round trips per tile -- tile offsets, s tile, first stream load;
+    // the offsets of the NEXT tile are now requested a tile ahead (tq_a / tq_b) and, in the loop without a prefetch
+    // ring, the first stream load is issued before the s tile is fetched.
+    u32 tq_a = tileq[min(d.w + 1u, ntile)], tq_b = tileq[min(d.w + 2u, ntile)];        // offsets of tile d.w + 1
     for (u32 t = d.w; ; t++) {
       u32 q0, q1, rt;
       if (p == p0 && t == d.w) { q0 = pq0; q1 = w1.w; rt = w0.w; }
       else {
-        const u32 tq0 = tileq[t], tq1 = tileq[t + 1];
+        u32 tq0, tq1;
+        if (t == d.w) { tq0 = tileq[t]; tq1 = tq_a; }
+        else { tq0 = tq_a; tq1 = tq_b; tq_a = tq_b; tq_b = tileq[min(t + 2u, ntile)]; }
         if (tq0 >= pq1) break;
         q0 = max(pq0, tq0); q1 = min(pq1, tq1);
         if (q0 >= q1) continue;                         // empty tile
         rt = nct_or0 ? t / nct_or0 : t % nrt;           // row-tile major / column-tile major
       }
+      // r64 without the prefetch ring: the first quad pair of the tile is requested now, beside the s tile
+      uint4 Apre = make_uint4(0u, 0u, 0u, 0u);
+      if (FMT == FMT_R64 && UNROLL == 1) Apre = coo_load<NT>(reinterpret_cast<const uint4*>(ent), min(q0 + tid, q1 - 1));
       if (rt != cur_rt) {
         const i64 r0 = (i64)rt * RT;                    // RT is even: 16-byte aligned
         __syncthreads();                                // the previous s tile is no longer read
@@ -499,7 +508,8 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
             q += 2 * THREADS;
           }
         } else {
-          for (; q < q1; q += THREADS) { A = coo_load<NT>(ent4, q); EATR(A, true); }
+          EATR(Apre, q < q1);
+          for (q += THREADS; q < q1; q += THREADS) { A = coo_load<NT>(ent4, q); EATR(A, true); }
         }
 #undef EATR
       } else if (U24 && UNROLL == 2 && ABL == 0) {
@@ -601,7 +611,7 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
   // hipEventRecord puts two barrier packets around the kernel and costs ~15 us per step
   hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL, FMT>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
                         (const u32*)mat->t_ent, (const uint4*)mat->t_piece, (const uint4*)mat->t_wgpiece, (const u32*)mat->t_tileq, mat->nrt,
-                        mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->n, S, part);
+                        mat->rt_major ? mat->nct : 0u, mat->tile_r, mat->nrt * mat->nct, mat->n, S, part);
   return KLR_OK;
 }
 
