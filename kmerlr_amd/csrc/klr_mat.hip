@@ -806,6 +806,8 @@ __global__ __launch_bounds__(64) void k_gather_cols_nz(const i64* __restrict__ s
 // at configs[2]).  Here a workgroup owns RB_ROWS consecutive rows: the part of every selected column that falls in
 // its rows is found by binary search (the rows of a column ascend), the row masks are built with LDS atomics, and the
 // rows' entries are placed in an LDS image of the block's CSR segment that is written out in one coalesced pass.
+// (Needs the rows of a CSC column in ascending order: both ingest routes give that -- the host build walks the rows
+// in order, the device build sorts (column, entry) pairs with a stable radix sort.)
 //   k_red_bin_a: searches, reduced CSC copy, masks -> global masks, per-block entry totals, segment table
 //   k_red_bin_b: block base = sum of the totals before it, row offsets by a block scan, CSR segment via LDS
 #define RB_ROWS 256

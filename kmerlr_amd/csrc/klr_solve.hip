@@ -22,10 +22,6 @@
 #define KSPEC 8          // sweeps per launch
 #define CD_THREADS 1024
 
-__global__ __launch_bounds__(256) void k_mul(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o, i64 n) {
-  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) o[i] = a[i] * b[i];
-}
 
 // Gram scale: 2^E with max_{j>=1} G_jj * 2^E < 2^61 (|G_jk| <= max diag by Cauchy-Schwarz).  Computed on
 // the device from the ALL-REDUCED diagonal, so every rank uses the same power of two.
@@ -1431,7 +1427,6 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         if (thd_stale) { t0.n = d; memcpy(t0.v, th.data(), (size_t)d * 8); thd_stale = false; }   // the kernel writes thd
         hipLaunchKernelGGL(k_cd_lds2, dim3(1), dim3(1024), (size_t)(d + 1) * (CDL_STRIDE + 4) * sizeof(double), st, a, t0);
       }
-      else if (d <= 128) hipLaunchKernelGGL((k_cd_wave<2, false>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false, true>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false, true>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 1024 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<1>, dim3(1), dim3(1024), 0, st, a);
