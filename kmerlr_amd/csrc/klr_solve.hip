@@ -133,26 +133,48 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
   const double s0 = sc[0];
   const int lane = threadIdx.x & 15;
   const i64 grp0 = ((i64)blockIdx.x * 1024 + threadIdx.x) >> 4, ngrp = ((i64)gridDim.x * 1024) >> 4;
-  for (i64 i = grp0; i < n; i += ngrp) {
-    const i64 b = rowptr[i] + 1, e = rowptr[i + 1];            // skip the bias entry
-    const double wi = w[i] * s0;
-    for (i64 a0 = b; a0 < e; a0 += 16) {
-      const bool ha = a0 + lane < e;
-      const int ja = ha ? (int)col[a0 + lane] : 0;
-      const double wa = ha ? wi * val[a0 + lane] : 0.0;
-      for (i64 c0 = a0; c0 < e; c0 += 16) {
-        const bool hc = c0 + lane < e;
-        const int jc_own = hc ? (int)col[c0 + lane] : -1;
-        const double vc_own = hc ? val[c0 + lane] : 0.0;
+  // two rows per trip: their offsets, then their first 16 entries, are requested together (a row is otherwise two
+  // dependent round trips to L2 with nothing else in flight)
+  constexpr int RB = 2;
+  for (i64 i0 = grp0; i0 < n; i0 += RB * ngrp) {
+    i64 rb[RB], re[RB]; double rw[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const i64 i = i0 + r * ngrp;
+      const bool ok = i < n;
+      rb[r] = ok ? rowptr[i] + 1 : 0;                           // skip the bias entry
+      re[r] = ok ? rowptr[i + 1] : 0;
+      rw[r] = ok ? w[i] : 0.0;
+    }
+    int fj[RB]; double fv[RB];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const bool h = rb[r] + lane < re[r];
+      fj[r] = h ? (int)col[rb[r] + lane] : -1;
+      fv[r] = h ? val[rb[r] + lane] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const i64 b = rb[r], e = re[r];
+      const double wi = rw[r] * s0;
+      for (i64 a0 = b; a0 < e; a0 += 16) {
+        int ja_raw; double va_raw;
+        if (a0 == b) { ja_raw = fj[r]; va_raw = fv[r]; }
+        else { const bool h = a0 + lane < e; ja_raw = h ? (int)col[a0 + lane] : -1; va_raw = h ? val[a0 + lane] : 0.0; }
+        const bool ha = ja_raw >= 0;
+        const int ja = ha ? ja_raw : 0;
+        const double wa = ha ? wi * va_raw : 0.0;
         // the 16 lanes of a row are one DPP row: partners arrive by row rotations (VALU, no LDS round trip);
         // inside the same 16 entries only the rotations that reach 1 .. (longest row of the wavefront) - 1 places on
-        int nrot = 16;
-        if (c0 == a0) {
-          const unsigned long long hm = __ballot(ha);
-          const unsigned m16 = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xFFFFull);
-          nrot = 32 - __clz((int)m16);
+        const unsigned long long hm = __ballot(ha);
+        const unsigned m16 = (unsigned)((hm | (hm >> 16) | (hm >> 32) | (hm >> 48)) & 0xFFFFull);
+        dpp_pairs<0>(ha, ja, wa, ja_raw, va_raw, d, acc, 32 - __clz((int)m16));
+        for (i64 c0 = a0 + 16; c0 < e; c0 += 16) {
+          const bool hc = c0 + lane < e;
+          const int jc_own = hc ? (int)col[c0 + lane] : -1;
+          const double vc_own = hc ? val[c0 + lane] : 0.0;
+          dpp_pairs<0>(ha, ja, wa, jc_own, vc_own, d, acc, 16);
         }
-        dpp_pairs<0>(ha, ja, wa, jc_own, vc_own, d, acc, nrot);
       }
     }
   }
