@@ -1201,10 +1201,13 @@ __global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict
                                                     const double* __restrict__ val, const uint8_t* __restrict__ labels,
                                                     const uint8_t* __restrict__ active,
                                                     i64 n, int d, const double* __restrict__ hist, const int* __restrict__ ndone,
-                                                    double cw0, double cw1, double* __restrict__ blk) {
+                                                    double cw0, double cw1, double* __restrict__ blk, int kl_log2) {
+  // kl = 1 << kl_log2 lanes per row (the batch holds at most kl iterates): a probe batch of one sweep keeps every
+  // lane on a row of its own -- the exp / log1p chain costs a wavefront the same whether 1 or 8 of 8 lanes need it
   extern __shared__ double lm_lds[];            // KSPEC * d iterates, layout [column][k]
   __shared__ double sh[KSPEC][LM_THREADS / 64];
   const int K = *ndone;
+  const int kl = 1 << kl_log2;
   if (LDS) {
     for (int t = threadIdx.x; t < KSPEC * d; t += LM_THREADS) {
       const int c = t / KSPEC, k = t % KSPEC;
@@ -1212,8 +1215,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict
     }
     __syncthreads();
   }
-  const int k = threadIdx.x % KSPEC;
-  const i64 i = (i64)blockIdx.x * LM_ROWS + threadIdx.x / KSPEC;
+  const int k = threadIdx.x & (kl - 1);
+  const i64 i = (i64)blockIdx.x * (LM_THREADS >> kl_log2) + (threadIdx.x >> kl_log2);
   double term = 0.0;
   if (i < n && k < K && (!active || active[i])) {
     const i64 b = rowptr[i], e = rowptr[i + 1];
@@ -1226,14 +1229,14 @@ __global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict
     // y: -log sigma(r) = LogAdd(0,-r);  !y: LogAdd(0,r)
     term = y ? cw1 * (fmax(-rr, 0.0) + l1p) : cw0 * (fmax(rr, 0.0) + l1p);
   }
-  // rows of the wave: lanes k, k+8, ..., k+56
+  // rows of the wave: lanes k, k + kl, ...
   double v = term;
-  for (int o = 32; o >= KSPEC; o >>= 1) v += __shfl_xor(v, o, 64);
-  if ((threadIdx.x & 63) < KSPEC) sh[k][threadIdx.x >> 6] = v;
+  for (int o = 32; o >= kl; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((int)(threadIdx.x & 63) < kl) sh[k][threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x < KSPEC) {
     double acc = 0.0;
-    for (int ww = 0; ww < LM_THREADS / 64; ww++) acc += sh[threadIdx.x][ww];
+    if ((int)threadIdx.x < kl) for (int ww = 0; ww < LM_THREADS / 64; ww++) acc += sh[threadIdx.x][ww];
     blk[(i64)blockIdx.x * KSPEC + threadIdx.x] = acc;
   }
 }
@@ -1473,13 +1476,16 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (eval_loss) {
         // iterates staged in LDS only while that is cheaper than reading them where they are: a block of LM_ROWS rows
         // stages KSPEC * d values but uses ~KSPEC * 32 * (row length) of them
+        int kl_log2 = 0;
+        while ((1 << kl_log2) < Kb) kl_log2++;
+        const i64 nbl = std::max<i64>(1, ceil_div(n, (i64)(LM_THREADS >> kl_log2)));
         if ((double)d <= (double)LM_ROWS * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024)
-          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nb), dim3(LM_THREADS), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
-                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
+          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nbl), dim3(LM_THREADS), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
+                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
         else
-          hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nb), dim3(LM_THREADS), 0, st, red->rowptr, red->col,
-                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb);
-        hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nb, losses);
+          hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nbl), dim3(LM_THREADS), 0, st, red->rowptr, red->col,
+                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
+        hipLaunchKernelGGL(k_sum_partials_multi, dim3(KSPEC), dim3(1024), 0, st, lossb, nbl, losses);
         KLR_TRY(klr_allreduce(ctx, losses, KSPEC, KLR_F64));
       }
       KLR_HIP(ctx, hipGetLastError());
