@@ -1135,8 +1135,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
       // row marks: bit masks (sorted rows for free) when they are small, else counters + cursor + in-row sort
       const int W = (int)ceil_div(c1, (i64)64);
       const char* ss_env = getenv("KLR_SUBSELECT");         // bin | flat | sort (tests); default: the first that applies
-      const bool use_bin = !any_zero && n > 0 && c1 <= RB_CMAX && n < ((i64)1 << 32) && !getenv("KLR_SUBSELECT_SORT") &&
-                           (!ss_env || ss_env[0] == 'b');
+      const bool use_bin = !any_zero && n > 0 && c1 <= RB_CMAX && n < ((i64)1 << 32) && (!ss_env || ss_env[0] == 'b');
       if (use_bin) {
         const i64 nblk = ceil_div(n, (i64)RB_ROWS);
         char* wsb;
@@ -1166,7 +1165,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
         if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns launch failed: %s", hipGetErrorString(e)); break; }
         break;
       }
-      const bool use_mask = W <= RED_MASK_WORDS_MAX && !getenv("KLR_SUBSELECT_SORT") && !(ss_env && ss_env[0] == 's');
+      const bool use_mask = W <= RED_MASK_WORDS_MAX && !(ss_env && ss_env[0] == 's');
       u32* cnt; unsigned long long* mask = nullptr;
       const size_t cnt_bytes = al(nn * sizeof(u32));
       if ((rc = ws_get(ctx, WS_TMP1, cnt_bytes + (use_mask ? nn * (size_t)W * 8 : 0), (void**)&cnt))) break;
