@@ -58,6 +58,18 @@ def test_synthetic_leapfrog_path_on_gpu(ctx):
     assert len(cg[1]["cols"]) == 21
 
 
+def test_leapfrog_path_large_selections_on_gpu(ctx):
+    """The same path check where the reduced problems leave the LDS-resident solver: 151 coordinates (Gram rows from
+    L2, two steps ahead) and 601 (blocked sweep over 16 wavefronts), the sub-select binned over up to 1024 columns."""
+    x, labels = O.synth_csr(17, 0, 3000, 3000, 8192, 400, 1200)
+    # integer column sums tie by the hundred at 3000 rows, and the midpoint rule for lambda is discontinuous at a tie
+    # (DESIGN.md, "Selection at ties"): a generic per-column scale makes every |g_j| distinct
+    scale = np.r_[1.0, 1.0 + 0.5 * np.random.default_rng(5).random(x.dim - 1)]
+    eg, cg, eo, co = run_both(ctx, x, labels, [150, 600], scale=scale, max_iterations=4000)
+    assert_same_path(eg, cg, eo, co)
+    assert len(cg[0]["cols"]) >= 151 and len(cg[1]["cols"]) >= 601
+
+
 def test_fixed_lambda_and_scale_transform_on_gpu(ctx):
     x, labels = O.synth_csr(3, 0, 1500, 1500, 600, 100, 10)
     g = O.gradient(x, labels, np.zeros(x.dim))
