@@ -106,6 +106,7 @@ struct klr_mat {
   void*    arena = nullptr;
   size_t   arena_cap = 0;
   uint8_t* active_slot = nullptr;
+  u32*     d_collen = nullptr;   // reduced matrices: true column lengths on the device (dim)
   i64  n_total_all = 0;          // n_total without a mask
   i64  n_active_local = 0;       // active local rows (valid when active != nullptr)
   std::vector<uint8_t> h_labels; // host copy (class counts under a mask)

@@ -1085,6 +1085,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
     const double* d_off = (const double*)(dtab + t_off);
     const u32* d_srclen = (const u32*)(dtab + t_srclen);
     const u32* d_dstlen = (const u32*)(dtab + t_dstlen);
+    r->d_collen = (u32*)(dtab + t_dstlen);
     char* htab;
     if ((rc = stage_get(ctx, tab_bytes, (void**)&htab))) break;
     {

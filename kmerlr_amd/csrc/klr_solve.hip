@@ -250,6 +250,61 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag_tiled(const i64* __restri
   for (int t = threadIdx.x; t < GT * GT; t += 1024) out[t] = gl[t];
 }
 
+// Many columns (d > GRAM_ROWS_MIN): ONE ROW OF THE GRAM MATRIX PER WORKGROUP.  Workgroup a walks column a of the
+// reduced matrix (CSC: the rows that hold it) and, for each such row i, the entries of row i to the right of a (CSR):
+// every pair (a, b > a) of the row, i.e. exactly the cells of Gram row a -- accumulated with LDS atomics in a
+// d-entry int64 vector and written out once, complete: no partials, no reduce, no memory-side atomics (24M of them took
+// 700 us per re-linearisation at d = 5001), no tile passes.  Same addends as the other builds.  Each 16-lane group
+// takes one entry of the column and spreads over that row's entries.
+__global__ __launch_bounds__(1024) void k_gram_rows(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+                                                    const double* __restrict__ val, const i64* __restrict__ colptr,
+                                                    const u32* __restrict__ collen, const u32* __restrict__ crow,
+                                                    const double* __restrict__ cval, const double* __restrict__ w,
+                                                    int d, const double* __restrict__ sc, i64* __restrict__ Gi) {
+  extern __shared__ unsigned long long gl[];            // d accumulators: cells (a, .)
+  const int a = blockIdx.x;                             // column / Gram row (0 = bias: from the column sums, zeros here)
+  for (int t = threadIdx.x; t < d; t += 1024) gl[t] = 0ull;
+  __syncthreads();
+  if (a >= 1) {
+    const double s0 = sc[0];
+    const i64 cb = colptr[a];
+    const u32 len = collen[a];
+    const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    // two column entries per group and trip: their rows' offsets, then the rows' first 16 entries, in flight together
+    for (u32 e0 = grp; e0 < len; e0 += 128) {
+      u32 ee[2]; i64 rb[2], re[2]; double wa[2];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        ee[r] = e0 + 64u * r;
+        const bool ok = ee[r] < len;
+        const u32 i = ok ? crow[cb + ee[r]] : 0u;
+        const double va = ok ? cval[cb + ee[r]] : 0.0;
+        rb[r] = ok ? rowptr[i] + 1 : 0;                 // skip the bias entry
+        re[r] = ok ? rowptr[i + 1] : 0;
+        wa[r] = ok ? (w[i] * s0) * va : 0.0;
+      }
+      int fj[2]; double fv[2];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const bool h = rb[r] + lane < re[r];
+        fj[r] = h ? (int)col[rb[r] + lane] : -1;
+        fv[r] = h ? val[rb[r] + lane] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        if (fj[r] > a) atomicAdd(&gl[fj[r]], (unsigned long long)__double2ll_rn(wa[r] * fv[r]));
+        for (i64 p = rb[r] + 16 + lane; p < re[r]; p += 16) {
+          const int jb = (int)col[p];
+          if (jb > a) atomicAdd(&gl[jb], (unsigned long long)__double2ll_rn(wa[r] * val[p]));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  i64* out = Gi + (i64)a * d;
+  for (int t = threadIdx.x; t < d; t += 1024) out[t] = (i64)gl[t];
+}
+
 // cell (j, k), 1 <= j < k: the sum of its tile's partials in group order.  G != null (single rank): G[j][k] =
 // G[k][j] = sum * 2^-E and row / column 0 and the diagonal from the column sums; else Gi[j][k] = sum (all-reduced and
 // assembled by the caller).
@@ -1312,7 +1367,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
   // 128 < d <= 1024 with many pairs: tile pairs privatised in LDS (k_gram_offdiag_tiled)
   const int gram_nt = (d + GT - 1) / GT, gram_npairs = gram_nt * (gram_nt + 1) / 2;
-  const bool gram_tiled = !gram_lds && (size_t)d * d * 8 > 128 * 1024 && d <= 1024 && gram_many;
+  // one Gram row per workgroup once there are enough columns to fill the chip with workgroups (KLR_GRAM_ROWS_MIN)
+  const int gram_rows_min = getenv("KLR_GRAM_ROWS_MIN") ? atoi(getenv("KLR_GRAM_ROWS_MIN")) : 384;
+  const bool gram_rows = !gram_lds && d > 128 && d >= gram_rows_min && gram_many && (size_t)d * 8 <= 128 * 1024 && red->d_collen != nullptr;
+  const bool gram_tiled = !gram_lds && !gram_rows && (size_t)d * d * 8 > 128 * 1024 && d <= 1024 && gram_many;
   const unsigned gram_groups = gram_tiled ? (unsigned)std::max<i64>(1, std::min<i64>(std::max(1, ctx->n_cu / gram_npairs), ceil_div(n, 2 * 1024))) : 0u;
   if (gram_tiled) {
     static bool attr = false;
@@ -1391,7 +1449,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     }
     DBG_STEP("irls sums");
     // the LDS-privatised build writes whole partials and the reduce overwrites the result slot: nothing to zero
-    if ((!gram_lds && !gram_tiled) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
+    if ((!gram_lds && !gram_tiled && !gram_rows) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     bool assembled = false;
     if (n) {
       if (gram_lds) {
@@ -1404,6 +1462,11 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         } else
           hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
                              d * d, (int)gram_blocks);
+      } else if (gram_rows) {
+        static bool attr = false;
+        if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr = true; }
+        hipLaunchKernelGGL(k_gram_rows, dim3((unsigned)d), dim3(1024), (size_t)d * 8, st, red->rowptr, red->col, (const double*)red->val,
+                           red->colptr, red->d_collen, red->crow, (const double*)red->cval, w, d, gsc, Gi);
       } else if (gram_tiled) {
         unsigned long long* gpart = (unsigned long long*)(Gi + (size_t)d * d);
         hipLaunchKernelGGL(k_gram_offdiag_tiled, dim3(gram_groups, (unsigned)gram_npairs), dim3(1024), (size_t)GT * GT * 8, st,
