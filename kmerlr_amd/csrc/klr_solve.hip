@@ -747,6 +747,18 @@ __global__ __launch_bounds__(256) void k_cd_wave(CdArgs a) {
     pj += 4;                                                                                                   \
   }
 
+// rows `first`, first + step, ... of the 64 x 64 diagonal block of block Bn into dst (one wavefront per call; the
+// helpers of a block share the 64 rows so that each waits for one round trip, not eight)
+__device__ __forceinline__ void cdb_stage_diag(const double* __restrict__ G, int d, int Bn, int lane, int first, int step,
+                                               double* __restrict__ dst) {
+  const int c0 = Bn * 64 + lane, cc = c0 < d ? c0 : d - 1;
+#pragma unroll 5
+  for (int r = first; r < 64; r += step) {
+    const int row = Bn * 64 + r < d ? Bn * 64 + r : d - 1;
+    dst[r * 64 + lane] = G[(i64)row * d + cc];
+  }
+}
+
 template <int QW>
 __global__ __launch_bounds__(1024) void k_cd_blocked(CdArgs a) {
   __shared__ double Gd[2][CDB_ROWS * 64];            // diagonal blocks, double buffered
@@ -769,14 +781,7 @@ __global__ __launch_bounds__(1024) void k_cd_blocked(CdArgs a) {
   }
   if (threadIdx.x < 64) { Gd[0][64 * 64 + lane] = 0.0; Gd[1][64 * 64 + lane] = 0.0; }
   if (threadIdx.x < 8) { pk[0][64 * 4 + (threadIdx.x & 3)] = 0.0; pk[1][64 * 4 + (threadIdx.x & 3)] = 0.0; }
-  // diagonal block of block 0
-  if (w == 0) {
-#pragma unroll 8
-    for (int r = 0; r < 64; r++) {
-      const int row = r < d ? r : d - 1, cc = lane < d ? lane : d - 1;
-      Gd[0][r * 64 + lane] = G[(i64)row * d + cc];
-    }
-  }
+  cdb_stage_diag(G, d, 0, lane, w, 16, Gd[0]);           // diagonal block of block 0, four rows per wavefront
   __syncthreads();
   int zero_v;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
@@ -818,16 +823,10 @@ __global__ __launch_bounds__(1024) void k_cd_blocked(CdArgs a) {
         const double thn = pkb[4 * lane + 3];
 #pragma unroll
         for (int t = 0; t < QW; t++) if (B == ow + 16 * t) { q[t] = qb; th[t] = thn; }
-      } else if (w == ((ow + 1) & 15)) {
-        // ---- meanwhile: stage the diagonal block of the next block (block 0 of the next sweep after the last) ----
-        const int Bn = B + 1 == S ? 0 : B + 1;
-        double* dst = Gd[bb ^ 1];
-        const int c0 = Bn * 64 + lane, cc = c0 < d ? c0 : d - 1;
-#pragma unroll 8
-        for (int r = 0; r < 64; r++) {
-          const int row = Bn * 64 + r < d ? Bn * 64 + r : d - 1;
-          dst[r * 64 + lane] = G[(i64)row * d + cc];
-        }
+      } else {
+        // ---- meanwhile the fifteen others stage the diagonal block of the next block (block 0 of the next sweep after
+        // the last), four or five rows each ----
+        cdb_stage_diag(G, d, B + 1 == S ? 0 : B + 1, lane, (w - ow - 1) & 15, 15, Gd[bb ^ 1]);
       }
       __syncthreads();                                                  // deltas of block B visible
       // ---- every wavefront: its own slots += sum_j delta_j G[64 B + j][slot], j ascending ----
@@ -923,14 +922,7 @@ __global__ __launch_bounds__(1024) void k_cd_sb_steps(CdArgs a, int k, int sb, c
   const double inv = 1.0 / (dg + a.l2reg);
   if (threadIdx.x < 64) { Gd[0][64 * 64 + lane] = 0.0; Gd[1][64 * 64 + lane] = 0.0; }
   if (threadIdx.x < 8) { pk[0][64 * 4 + (threadIdx.x & 3)] = 0.0; pk[1][64 * 4 + (threadIdx.x & 3)] = 0.0; }
-  if (w == 15) {                                                       // diagonal block of the first block
-    const int c0 = B0 * 64 + lane, cc = c0 < d ? c0 : d - 1;
-#pragma unroll 8
-    for (int r = 0; r < 64; r++) {
-      const int row = B0 * 64 + r < d ? B0 * 64 + r : d - 1;
-      Gd[0][r * 64 + lane] = G[(i64)row * d + cc];
-    }
-  }
+  cdb_stage_diag(G, d, B0, lane, w, 16, Gd[0]);          // diagonal block of the first block, four rows per wavefront
   __syncthreads();
   int zero_v;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
@@ -962,16 +954,9 @@ __global__ __launch_bounds__(1024) void k_cd_sb_steps(CdArgs a, int k, int sb, c
       if (lane >= nbk) pkb[4 * lane] = 0.0;
       dlbuf[bl * 64 + lane] = pkb[4 * lane];                           // for k_cd_sb_update
       q = qb; th = pkb[4 * lane + 3];
-    } else if (w == bl + 1 && bl + 1 < nbl) {
-      // the owner of the next block stages its diagonal block meanwhile
-      const int Bn = B + 1;
-      double* dst = Gd[bb ^ 1];
-      const int c0 = Bn * 64 + lane, cc = c0 < d ? c0 : d - 1;
-#pragma unroll 8
-      for (int r = 0; r < 64; r++) {
-        const int row = Bn * 64 + r < d ? Bn * 64 + r : d - 1;
-        dst[r * 64 + lane] = G[(i64)row * d + cc];
-      }
+    } else if (bl + 1 < nbl) {
+      // the fifteen others stage the next block's diagonal block meanwhile
+      cdb_stage_diag(G, d, B + 1, lane, (w - bl - 1) & 15, 15, Gd[bb ^ 1]);
     }
     __syncthreads();
     if (w < nbl && w != bl) {                                          // the other slots of the super-block
