@@ -3,18 +3,24 @@
 
 One "step" = one leapfrog epoch's full-width pass (klr_sweep_select): X.theta / sigmoid / log-loss
 over the rows (from the reduced matrix of the current theta), the per-feature gradient sweep
-g = X'(cw (sigma - y))/n over the full CSC k-mer matrix, ONE all-reduce of [g | loss] across ranks,
+g = X'(cw (sigma - y))/n over the packed k-mer count stream, ONE all-reduce of [g | loss] across ranks,
 and the top-2N |g| selection + lambda rule.  Inputs are resident in HBM before the timed region.
 
 Workload (BASELINE.json configs[2]): synthetic 100k sequences x 65,536 8-mers per GPU (weak
-scaling: rows grow with N), --lambda-auto=100, theta on 100 selected columns.
+scaling: rows grow with N), --lambda-auto=100, theta on 100 selected columns.  At N = 8 (or with
+--configs3) the line also carries configs[3]: 125,000 x 1,048,576 per GPU, --lambda-auto=500.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py ...` as a child before anything here
+touches the GPU, relays its output (rank 0 prints the one JSON line) and exits with its return code.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,9 +31,10 @@ sys.path.insert(0, ROOT)
 
 SEED = 20261004
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+EVICT_BYTES = 1 << 30      # written + copied between the steps of the cold-stream leg (Infinity Cache: 256 MiB)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -41,40 +48,191 @@ def parse():
     ap.add_argument("--cd-sweeps", type=int, default=64, help="reduced-problem CD sweeps timed for cd_sweeps_per_s")
     ap.add_argument("--force-comm", action="store_true",
                     help="set up the process group and the library's RCCL communicator even for one rank (plumbing check)")
-    return ap.parse_args()
+    ap.add_argument("--configs3", action="store_true",
+                    help="also run BASELINE configs[3]'s per-GPU shard (125,000 x 1,048,576, --lambda-auto=500); default at 8 GPUs")
+    ap.add_argument("--no-configs3", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal on the CPU (gloo): no GPU work, the line says dry_run")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_children(args, argv):
+    """N > 1 without a launcher: start one, as a child.  Nothing in this process has touched HIP or torch.cuda."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
     import torch
     import torch.distributed as dist
-    import kmerlr_amd as K
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dt = 1e-3 * (rank + 1)
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "samples_x_features_per_s", "value": 0.0, "unit": "samples*features/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "launcher rehearsal (gloo, no GPU work)"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+class Rank:
+    """One process = one GPU: context, communicator, timing helpers."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        import kmerlr_amd as K
+        self.torch, self.dist, self.K, self.args = torch, dist, K, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        self.comm = self.world > 1 or args.force_comm
+        if self.comm:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+        self.ctx = K.Context(self.local_rank)
+        if self.comm:
+            # RCCL communicator owned by the library: one all-reduce per sweep on the library's stream
+            ids = [K.rccl_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            self.ctx.init_rccl(ids[0], self.rank, self.world)
+
+    def fence(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+        if self.comm:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def timed_steps(self, step, warmup, steps):
+        """W untimed steps, then exactly K steps between two fences; HIP-event time of the sweep kernel inside."""
+        for _ in range(warmup):
+            step()
+        self.fence()
+        self.ctx.prof_enable(True)
+        self.ctx.prof_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        launches, kern_ms = self.ctx.prof_read(reset=True)
+        self.ctx.prof_enable(False)
+        return self.max_over_ranks(dt), launches, kern_ms
+
+    def cold_kernel_ms(self, step, steps):
+        """The same steps with the packed stream evicted from the Infinity Cache before each one (1 GiB written and
+        copied on the library's stream); only the sweep kernel's own HIP events are read."""
+        self.ctx.prof_enable(True)
+        self.ctx.prof_read(reset=True)
+        for _ in range(steps):
+            self.ctx.evict(EVICT_BYTES)
+            step()
+        self.ctx.synchronize()
+        launches, kern_ms = self.ctx.prof_read(reset=True)
+        self.ctx.prof_enable(False)
+        return kern_ms / max(launches, 1)
+
+    def close(self):
+        self.ctx.close()
+        if self.comm:
+            self.dist.destroy_process_group()
+
+
+def alg_bytes_of(lay, n_local, nnz, m):
+    """ALGORITHMIC bytes of one launch of the sweep kernel for the layout in HBM."""
+    if lay["tiled"]:
+        # one pass over the packed stream (2, 3 or 4 bytes per padded unit entry) + one int64 vector per (strip, workgroup)
+        # piece written + s read once (re-reads of s tiles are cache hits and not counted) + side tables
+        return (3.0 + lay["value_bytes"]) * lay["padded_entries"] + lay["nseg"] * lay["piece_bytes"] + 8.0 * n_local + lay["table_bytes"]
+    # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column
+    return (4.0 + lay["value_bytes"]) * nnz + 12.0 * lay["nseg"] + 8.0 * n_local + 8.0 * (m + 1)
+
+
+def roofline_of(lay, alg_bytes, kern_avg_ms, launches, cold_avg_ms, n_local, nnz, m, traffic=None, traffic_source=None):
+    def rate(ms):
+        return alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
+    achieved = rate(kern_avg_ms)
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+         "kernel": lay["kernel"], "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
+         "algorithmic_bytes_per_launch": alg_bytes,
+         "resident": {"kernel_avg_ms": round(kern_avg_ms, 4), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                      "note": "the timed region: back-to-back steps, a stream that fits the 256 MiB Infinity Cache stays in it"},
+         "survey_two_pass_bytes": two_pass_bytes,
+         "survey_two_pass_equiv_gbs": round(two_pass_bytes / (kern_avg_ms * 1e-3) / 1e9, 1) if kern_avg_ms > 0 else 0.0}
+    if cold_avg_ms is not None:
+        r["cold"] = {"kernel_avg_ms": round(cold_avg_ms, 4), "achieved": round(rate(cold_avg_ms), 1),
+                     "frac": round(rate(cold_avg_ms) / HBM_PEAK_GBS, 4),
+                     "note": "same steps, 1 GiB written and copied before each one: the stream comes from HBM"}
+        r["frac_cold"] = r["cold"]["frac"]
+    return r
+
+
+def load_traffic(lay, nnz, m):
+    """HBM traffic of the sweep kernel from the committed PMC passes (profiles/): valid for this exact workload only."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            w = pj["workload"]
+            if (lay["tiled"] and w["nnz"] == nnz and w["features"] == m and w.get("format") == lay.get("format", w.get("format"))
+                    and w.get("entry_bytes") == 3 + lay["value_bytes"]):
+                k = pj["kernels"][pj.get("kernel", "k_sweep_coo")]
+                return k["hbm_traffic_bytes_per_launch"], "profiles/%s (%s)" % (name, pj.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"))
+        except Exception:
+            continue
+    return None, None
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_children(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
-    comm = world > 1 or args.force_comm
-    if comm:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    args.gpus = world
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
+    R = Rank(args)
+    K, ctx = R.K, R.ctx
     n_local, m, draws, N = args.rows_per_gpu, args.features, args.draws, args.lambda_auto
     n_total = n_local * world
     S = 2 * N
-
-    ctx = K.Context(local_rank)
-    if comm:
-        # RCCL communicator owned by the library: one all-reduce per sweep on the library's stream
-        ids = [K.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.init_rccl(ids[0], rank, world)
 
     # ---- synthetic shard, generated on the host and moved to HBM once -------------------------------
     t0 = time.time()
@@ -84,6 +242,7 @@ def main():
     full = K.Matrix.from_csr(ctx, n_local, m + 1, rowptr, col, val, labels, n_total)
     ctx.synchronize()
     t_up = time.time() - t0
+    del rowptr, col, val
     nnz = full.nnz
     cw = full.class_weights()
 
@@ -97,107 +256,53 @@ def main():
     n_sweeps_solve = len(recs)
 
     stepper = K.SweepStep(ctx, full, red, cols, theta, cw, N, lambda_prev=r0["lam"] * n_total)
-    step = stepper.run
-
-    for _ in range(args.warmup):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if comm:
-        dist.barrier()
-        torch.cuda.synchronize()
-    ctx.prof_enable(True)
-    ctx.prof_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    dt, launches, kern_ms = R.timed_steps(stepper.run, args.warmup, args.steps)
     out = stepper.result()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if comm:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    launches, kern_ms = ctx.prof_read(reset=True)
-    ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    cold_ms = R.cold_kernel_ms(stepper.run, min(args.steps, 20))
 
-    # ---- reduced-problem CD sweep rate (sweeps/s): incremental cost of 64 more sweeps (soft threshold + loss
-    # pass + stop checks each) inside one re-weighting, i.e. without the IRLS/Gram set-up
-    def timed_solve(iters):
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            _, rr = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=r0["lam"] * n_total, eps=0.0, eps_loss=0.0,
-                               eval_loss=True, max_iter=iters)
-            best = min(best, time.perf_counter() - t0)
-        return best, len(rr)
-    t_a, n_a = timed_solve(8)
-    t_b, n_b = timed_solve(8 + args.cd_sweeps)
-    cd_sweeps_per_s = (n_b - n_a) / (t_b - t_a) if t_b > t_a and n_b > n_a else 0.0
+    # ---- reduced-problem CD sweep rate (sweeps/s), from the device timestamps of the sweep kernels themselves
+    # (klr_cd_solve's own HIP events: soft-threshold sweeps only, no loss pass, no IRLS set-up, no host turnaround)
+    cd = K.cd_sweep_rate(ctx, red, cw, r0["lam"] * n_total, sweeps=args.cd_sweeps)
 
     # ---- the whole leapfrog run the steps above are part of (KmerLrEstimator.Estimate, --lambda-auto=N from a cold
     # model: every epoch = one step + column sub-select + reduced solve), best of 3; reported beside the metric
-    estimate = None
-    if world == 1:
+    def estimate_leg(mat, lam_auto, reps):
         from kmerlr_amd import _driver
         best = None
-        for _ in range(3):
+        for _ in range(reps):
             est = _driver.hip_estimator(ctx, save_trace=1)
+            R.fence()
             t0 = time.perf_counter()
-            est.estimate(full._h, [N])
-            te = time.perf_counter() - t0
+            est.estimate(mat._h, lam_auto)
+            te = R.max_over_ranks(time.perf_counter() - t0)
             lam_e, _nz = est.epochs()
             cl = est.classifiers()
             rec = {"seconds": round(te, 5), "epochs": len(lam_e), "cd_iterations": len(est.trace()),
-                   "nonzero": int(np.count_nonzero(cl[0]["theta"][1:])), "lambda": cl[0]["lam"]}
+                   "nonzero": int(np.count_nonzero(cl[-1]["theta"][1:])), "lambda": cl[-1]["lam"]}
             est.close()
             if best is None or rec["seconds"] < best["seconds"]:
                 best = rec
-        estimate = best
+        return best
+    estimate = estimate_leg(full, [N], 3)
 
     ms_per_step = dt / args.steps * 1e3
     value = float(n_total) * float(m) / (dt / args.steps)          # samples x features / s, whole job
 
-    # ---- roofline of the dominant kernel (column sweep k_xt_s), per launch ----------------------------
     lay = full.layout()
-    if lay["tiled"]:
-        # single pass over the 2-D tiled packed stream: 2 B per unit entry (8-byte quads row:12 | 4 x col:12, a row's
-        # run padded to 4 columns), 3 B (col:12|row:12) or 4 B (count:8|col:12|row:12) per entry, whichever the
-        # ingest chose (value_bytes -1 / 0 / 1), padding included; one 32 KiB vector of int64 column sums written per
-        # (tile, workgroup) piece,
-        # s read once (the per-piece s tiles are L2 hits and not counted)
-        alg_bytes = (3.0 + lay["value_bytes"]) * lay["padded_entries"] + lay["nseg"] * 4096.0 * 8 + 8.0 * n_local
-        kname = "k_sweep_coo"
-    else:
-        # plain CSC: 4 B row id + 4|8 B value per stored nonzero, chunk table, s once per row, g once per column
-        alg_bytes = (4.0 + lay["value_bytes"]) * nnz + 12.0 * lay["nseg"] + 8.0 * n_local + 8.0 * (m + 1)
-        kname = "k_xt_s<%d>" % lay["lanes_per_segment"]
-    # HBM traffic of the dominant kernel from the committed PMC passes (profiles/): valid for this exact workload
-    traffic = None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if (lay["tiled"] and pj["workload"]["nnz"] == nnz and pj["workload"]["features"] == m
-                and pj["workload"].get("entry_bytes") == 3 + lay["value_bytes"]):
-            traffic = pj["kernels"]["k_sweep_coo"]["hbm_traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    kern_avg_ms = kern_ms / max(launches, 1)
-    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-    two_pass_bytes = 16.0 * nnz + 8.0 * (n_local + 1) + 8.0 * (m + 1) + 9.0 * n_local + 8.0 * (m + 1)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 for 16 B/lane loads per MI355X_MICROARCH.md; Infinity-Cache hits are counted)" if traffic else None,
-                "kernel": kname, "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "survey_two_pass_bytes": two_pass_bytes,
-                "survey_two_pass_equiv_gbs": round(two_pass_bytes / (kern_avg_ms * 1e-3) / 1e9, 1) if kern_avg_ms > 0 else 0.0}
+    alg_bytes = alg_bytes_of(lay, n_local, nnz, m)
+    traffic, traffic_source = load_traffic(lay, nnz, m)
+    roofline = roofline_of(lay, alg_bytes, kern_ms / max(launches, 1), launches, cold_ms, n_local, nnz, m, traffic, traffic_source)
+    info = ctx.comm_info()
+    ar_ms = ctx.allreduce_time(m + 6, dtype=1, iters=20) if R.comm else 0.0
+
+    configs3 = None
+    if (world == 8 or args.configs3) and not args.no_configs3:
+        full.close(); red.close()
+        full = red = None
+        configs3 = configs3_leg(R, estimate_leg)
 
     cpu_baseline = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_leg(args, theta, cols, cw)
 
     if rank == 0:
@@ -212,44 +317,98 @@ def main():
                        "selected": int(len(cols) - 1), "parallelism": "row-shards x%d, 1 RCCL all-reduce of m+6 int64 per sweep" % world},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
-            "cd_sweeps_per_s": round(cd_sweeps_per_s, 1),
+            "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
+                     "allreduce_elements": m + 6 if R.comm else 0},
+            "cd_sweeps_per_s": cd["sweeps_per_s"], "cd_sweeps": cd,
             "cd_solve": {"sweeps_to_converge": n_sweeps_solve, "seconds": round(t_solve, 4), "nonzero": int(np.count_nonzero(theta[1:]))},
             "estimate_lambda_auto": estimate,
             "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]},
             "setup_s": {"generate": round(t_gen, 2), "ingest_upload": round(t_up, 2)},
         }
+        if configs3 is not None:
+            line["configs3"] = configs3
         print(json.dumps(line), flush=True)
-    if comm:
-        dist.barrier()
+    if R.comm:
+        R.dist.barrier()
+    if full is not None:
+        full.close(); red.close()
+    R.close()
+
+
+def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, warmup=3, steps=10):
+    """BASELINE configs[3]: synthetic 1M x 1M over 8 GPUs = 125,000 x 1,048,576 per GPU (weak: rows grow with the
+    number of ranks here), --lambda-auto=500.  Same step, same timing rules; the all-reduce is timed apart."""
+    K, ctx, world, rank = R.K, R.ctx, R.world, R.rank
+    n_total = n_local * world
+    rowptr, col, val, labels = K.synth_csr(SEED, rank * n_local, n_local, n_total, m, draws, 2 * N)
+    full = K.Matrix.from_csr(ctx, n_local, m + 1, rowptr, col, val, labels, n_total)
+    del rowptr, col, val
+    nnz = full.nnz
+    cw = full.class_weights()
+    r0 = K.sweep_select(ctx, full, None, None, np.zeros(1), cw, N)
+    cols = np.nonzero(r0["b"])[0]
+    red = full.select_columns(cols)
+    theta, recs = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=r0["lam"] * n_total, eps_loss=1e-8)
+    stepper = K.SweepStep(ctx, full, red, cols, theta, cw, N, lambda_prev=r0["lam"] * n_total)
+    dt, launches, kern_ms = R.timed_steps(stepper.run, warmup, steps)
+    out = stepper.result()
+    cold_ms = R.cold_kernel_ms(stepper.run, steps)
+    lay = full.layout()
+    alg_bytes = alg_bytes_of(lay, n_local, nnz, m)
+    traffic, traffic_source = load_traffic(lay, nnz, m)
+    roofline = roofline_of(lay, alg_bytes, kern_ms / max(launches, 1), launches, cold_ms, n_local, nnz, m, traffic, traffic_source)
+    ar_ms = ctx.allreduce_time(m + 6, dtype=1, iters=10) if R.comm else 0.0
+    est = estimate_leg(full, [N], 1)
+    info = ctx.comm_info()
     full.close(); red.close()
-    ctx.close()
-    if comm:
-        dist.destroy_process_group()
+    return {"config": {"workload": "synthetic %d seqs/GPU x %d k-mer columns, %d draws/row, --lambda-auto=%d (BASELINE configs[3]: "
+                                   "1M x 1M over 8 GPUs)" % (n_local, m, draws, N),
+                       "rows_per_gpu": n_local, "rows_total": n_total, "features": m, "nnz_per_gpu": nnz, "selected": int(len(cols) - 1)},
+            "value": float(n_total) * float(m) / (dt / steps), "unit": "samples*features/s", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "scaling": "weak",
+            "roofline": roofline,
+            "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
+                     "allreduce_elements": m + 6 if R.comm else 0},
+            "estimate_lambda_auto": est,
+            "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]}}
 
 
 def cpu_baseline_leg(args, theta, cols, cw):
-    """Times the CPU restatement of the reference path (oracle/, plain C, 1 core, reference loop
-    order and 16 B/nnz row layout) on a bounded sample of the same workload: the first rows of the
-    same synthetic matrix, same theta; one step = Gradient (a4) + Select (a6/a7)."""
+    """Times the CPU restatement of the reference path (oracle/, plain C, reference loop order and 16 B/nnz row
+    layout) on a bounded sample of the same workload: the first rows of the same synthetic matrix, same theta; one
+    step = Gradient (a4) + Select (a6/a7).  `value` is the faithful single-thread figure (the reference's loops are
+    single-threaded, kmerLr_logistic_regression.go:166,258); `all_cores` is the same loop over row blocks on every
+    host core (OpenMP, per-thread gradients summed) -- what a multi-threaded port of the reference would reach."""
     from oracle import oracle as O
     nr = args.cpu_baseline_rows
     m, draws, N = args.features, args.draws, args.lambda_auto
     x, labels = O.synth_csr(SEED, 0, nr, nr, m, draws, 2 * N)
     th = np.zeros(m + 1)
     th[cols] = theta
-    reps, t_tot = 0, 0.0
-    while t_tot < 12.0 and reps < 1000:
-        t0 = time.perf_counter()
-        g = O.gradient(x, labels, th, cw=cw)
-        b = np.zeros(m + 1, dtype=np.uint8); b[0] = 1
-        O.select(g[1:], b, 0, N)
-        t_tot += time.perf_counter() - t0
-        reps += 1
-    per = t_tot / reps
-    return {"value": float(nr) * float(m) / per, "unit": "samples*features/s", "cores": 1, "kind": "port",
+    try:
+        ncores = len(os.sched_getaffinity(0))          # the cores this process may use (the box's CPU share)
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+
+    def timed(threads, budget):
+        reps, t_tot = 0, 0.0
+        while t_tot < budget and reps < 1000:
+            t0 = time.perf_counter()
+            g = O.gradient(x, labels, th, cw=cw, threads=threads)
+            b = np.zeros(m + 1, dtype=np.uint8); b[0] = 1
+            O.select(g[1:], b, 0, N)
+            t_tot += time.perf_counter() - t0
+            reps += 1
+        return t_tot / reps, reps
+    per1, reps1 = timed(1, 10.0)
+    perN, repsN = timed(ncores, 6.0)
+    return {"value": float(nr) * float(m) / per1, "unit": "samples*features/s", "cores": 1, "kind": "port",
             "sample": "first %d rows of the same synthetic matrix (%d nnz), %d repetitions of Gradient+Select, "
-                      "CPU restatement of the Go loops (oracle/klr_oracle.c), 1 thread" % (nr, x.nnz, reps),
-            "ms_per_step_sample": per * 1e3}
+                      "CPU restatement of the Go loops (oracle/klr_oracle.c), 1 thread" % (nr, x.nnz, reps1),
+            "ms_per_step_sample": per1 * 1e3,
+            "all_cores": {"value": float(nr) * float(m) / perN, "cores": ncores, "nproc": ncores, "repetitions": repsN,
+                          "ms_per_step_sample": perN * 1e3,
+                          "note": "same loops, rows split over all host cores with OpenMP (per-thread g, summed)"}}
 
 
 if __name__ == "__main__":

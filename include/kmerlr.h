@@ -65,6 +65,10 @@ int         klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* user,
 int         klr_rccl_unique_id(void* id128);
 int         klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int nranks);
 
+/* what the ctx will reduce over: rank / nranks as given to the setters above; rccl_ranks = ncclCommCount of the built-in
+ * communicator (0 when there is none).  Any output may be NULL. */
+int         klr_ctx_comm_info(const klr_ctx* ctx, int* rank, int* nranks, int* rccl_ranks);
+
 /* ---- sparse k-mer / score matrix ------------------------------------------------------- */
 /* Replaces the []ConstVector the reference hands to SetSparseData (kmerLr_estimator.go:152)
  * and to featureSelector.gradient (kmerLr_feature_selection.go:221-229).
@@ -81,10 +85,10 @@ int  klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int64_t* seq_o
                             int revcomp, int binarize, const uint8_t* labels, int64_t n_total, klr_mat** out);
 void klr_mat_destroy(klr_mat* mat);
 int  klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total);
-/* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the 2-D tiled packed COO stream
- * (4 B per stored nonzero, count data) is in use, with its tile edge, number of (tile, workgroup)
- * pieces, stored entries incl. padding; tiled = 0: plain CSC (u32 row + f32|f64 value) with its chunk
- * count and lanes per chunk. */
+/* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the packed integer stream (count data; 2, 3 or
+ * 4 bytes per stored unit entry) is in use, with its tile height, number of (column strip,
+ * workgroup) pieces, stored entries incl. padding and value_bytes = bytes per padded entry - 3; tiled = 0: plain CSC
+ * (u32 row + f32|f64 value) with its chunk count, lanes per chunk and value_bytes = 4|8. */
 int  klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows, int64_t* nseg,
                     int64_t* padded_entries, int* lanes_per_segment, int* value_bytes);
 /* copy a (reduced) matrix back in the reference layout; any output pointer may be NULL.
@@ -170,8 +174,8 @@ int  klr_mat_select_columns(klr_ctx* ctx, const klr_mat* full, const int64_t* co
  * only, first epoch).  red_cols[c_plus_1] maps reduced columns to full columns.  With a data transform
  * the reduced matrix already holds transformed values (klr_mat_select_columns) and scale/offset finish
  * the full-width gradient on the fly (kmerLr_logistic_regression.go:196-222).
- * Outputs as klr_select; picked_out (length >= min(m,2N)) receives the sorted candidate
- * columns (0-based feature ids), loss_out the mean log-loss without penalty. */
+ * Outputs as klr_select; loss_out = the mean log-loss without penalty; g_out (nullable, host, length dim) = the
+ * gradient the selection saw, i.e. with scale/offset applied like klr_gradient's. */
 int  klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat* reduced,
                       const int64_t* red_cols, const double* theta_red, int64_t c_plus_1,
                       const double cw[2], int64_t N, double lambda_prev, double eps_lambda,
@@ -213,6 +217,19 @@ int  klr_synth_csr(uint64_t seed, int64_t row0, int64_t n_local, int64_t n_total
  * accumulated since the last reset.  Events are recorded only while enabled. */
 int  klr_prof_enable(klr_ctx* ctx, int on);
 int  klr_prof_read(klr_ctx* ctx, int64_t* launches, double* total_ms, int reset);
+/* while enabled, klr_cd_solve also records HIP events around the coordinate-descent sweep kernels of every batch
+ * (soft-threshold sweeps only: no IRLS set-up, loss pass or host turnaround): sweeps executed, batches, their time. */
+int  klr_prof_read_cd(klr_ctx* ctx, int64_t* sweeps, int64_t* batches, double* total_ms, int reset);
+/* writes and copies `bytes` of scratch on the ctx stream so that whatever sat in the 256 MiB Infinity Cache is gone:
+ * the next sweep reads its stream from HBM (bench.py's cold-stream figure). */
+int  klr_prof_evict(klr_ctx* ctx, int64_t bytes);
+/* the packed stream of a tiled matrix: format (0 u32, 1 u24, 2 r64, 3 q64/12, 4 q64/13), bytes of the stream, bytes of
+ * one piece vector the sweep writes, bytes of the side tables the sweep reads.  Zeros for a plain matrix. */
+int  klr_mat_stream_info(const klr_mat* mat, int* format, int64_t* stream_bytes, int64_t* piece_bytes, int64_t* table_bytes);
+
+/* average milliseconds of the installed all-reduce hook alone on `count` elements of dtype (scratch buffer, ctx stream,
+ * HIP events around `iters` calls); 0 without a hook.  Collective: every rank must call it. */
+int  klr_allreduce_time(klr_ctx* ctx, int64_t count, int dtype, int iters, double* ms_avg);
 
 const char* klr_version(void);
 

@@ -33,6 +33,8 @@ SIGNATURES = {
     "klr_ctx_set_allreduce": (_int, [_vp, ALLREDUCE_FN, _vp, _int, _int]),
     "klr_rccl_unique_id": (_int, [_vp]),
     "klr_ctx_init_rccl": (_int, [_vp, _vp, _int, _int]),
+    "klr_ctx_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
+    "klr_allreduce_time": (_int, [_vp, _i64, _int, _int, C.POINTER(_dbl)]),
     "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
     "klr_mat_from_sequences": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _i64, _PVP]),
     "klr_mat_destroy": (None, [_vp]),
@@ -60,6 +62,9 @@ SIGNATURES = {
     "klr_synth_csr": (_int, [C.c_uint64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int]),
     "klr_prof_enable": (_int, [_vp, _int]),
     "klr_prof_read": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl), _int]),
+    "klr_prof_read_cd": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_dbl), _int]),
+    "klr_prof_evict": (_int, [_vp, _i64]),
+    "klr_mat_stream_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "klr_version": (C.c_char_p, []),
 }
 
@@ -144,6 +149,16 @@ class Context:
         buf = C.create_string_buffer(unique_id, 128)
         self.check(lib().klr_ctx_init_rccl(self._h, buf, rank, nranks))
 
+    def comm_info(self):
+        r, n, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.check(lib().klr_ctx_comm_info(self._h, C.byref(r), C.byref(n), C.byref(c)))
+        return dict(rank=r.value, nranks=n.value, rccl_ranks=c.value)
+
+    def allreduce_time(self, count, dtype=1, iters=20):
+        ms = C.c_double(0.0)
+        self.check(lib().klr_allreduce_time(self._h, int(count), int(dtype), int(iters), C.byref(ms)))
+        return ms.value
+
     def prof_enable(self, on=True):
         self.check(lib().klr_prof_enable(self._h, int(on)))
 
@@ -151,6 +166,15 @@ class Context:
         n, ms = C.c_int64(0), C.c_double(0.0)
         self.check(lib().klr_prof_read(self._h, C.byref(n), C.byref(ms), int(reset)))
         return n.value, ms.value
+
+
+    def prof_read_cd(self, reset=True):
+        sw, nb, ms = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        self.check(lib().klr_prof_read_cd(self._h, C.byref(sw), C.byref(nb), C.byref(ms), int(reset)))
+        return sw.value, nb.value, ms.value
+
+    def evict(self, nbytes=1 << 30):
+        self.check(lib().klr_prof_evict(self._h, int(nbytes)))
 
 
 def rccl_unique_id():
@@ -209,8 +233,15 @@ class Matrix:
         r, ns, pe = C.c_int64(), C.c_int64(), C.c_int64()
         self.ctx.check(lib().klr_mat_layout(self._h, C.byref(t), C.byref(r), C.byref(ns), C.byref(pe), C.byref(g),
                                             C.byref(vb)))
+        fmt = C.c_int()
+        sb, pb, tb = C.c_int64(), C.c_int64(), C.c_int64()
+        self.ctx.check(lib().klr_mat_stream_info(self._h, C.byref(fmt), C.byref(sb), C.byref(pb), C.byref(tb)))
+        names = {0: "u32", 1: "u24", 2: "r64", 3: "q64c12", 4: "q64c13"}
+        kern = {0: "k_sweep_coo", 1: "k_sweep_coo", 2: "k_sweep_coo", 3: "k_sweep_q64", 4: "k_sweep_q64"}
         return dict(tiled=bool(t.value), tile_rows=r.value, nseg=ns.value, padded_entries=pe.value,
-                    lanes_per_segment=g.value, value_bytes=vb.value)
+                    lanes_per_segment=g.value, value_bytes=vb.value, format=names.get(fmt.value, "csc"),
+                    kernel=kern.get(fmt.value, "k_xt_s<%d>" % g.value), stream_bytes=sb.value, piece_bytes=pb.value,
+                    table_bytes=tb.value)
 
     def to_csr(self):
         rowptr = np.zeros(self.n + 1, dtype=np.int64)
@@ -372,6 +403,27 @@ def cd_solve(ctx, red, theta, cw=(1.0, 1.0), l1reg=0.0, l2reg=0.0, eps=0.0, eps_
     out = [dict(iteration=r.iteration, nonzero=r.nonzero, change=r.change, lambda_=r.lambda_, loss=r.loss,
                 seconds=r.seconds) for r in recs[:min(n_recs.value, recs_cap)]]
     return theta, out
+
+
+def cd_sweep_rate(ctx, red, cw, l1reg, sweeps=64):
+    """Coordinate-descent sweeps per second from the device timestamps of the sweep kernels themselves: `sweeps`
+    soft-threshold sweeps inside ONE re-weighting (eps = eps_loss = 0: nothing stops them), timed by the HIP events
+    klr_cd_solve puts around every batch while profiling is on.  Best of 3."""
+    best = None
+    for _ in range(3):
+        ctx.prof_enable(True)
+        ctx.prof_read_cd(reset=True)
+        cd_solve(ctx, red, np.zeros(red.dim), cw=cw, l1reg=l1reg, eps=0.0, eps_loss=0.0, eval_loss=True, max_iter=sweeps)
+        sw, nb, ms = ctx.prof_read_cd(reset=True)
+        ctx.prof_read(reset=True)
+        ctx.prof_enable(False)
+        if sw > 0 and ms > 0 and (best is None or ms / sw < best[2] / best[0]):
+            best = (sw, nb, ms)
+    if best is None:
+        return dict(sweeps_per_s=0.0, sweeps=0, batches=0, device_ms=0.0, coordinates=int(red.dim))
+    return dict(sweeps_per_s=round(best[0] / (best[2] * 1e-3), 1), sweeps=best[0], batches=best[1], device_ms=round(best[2], 4),
+                us_per_sweep=round(best[2] * 1e3 / best[0], 3), coordinates=int(red.dim),
+                how="HIP events around the CD sweep kernels of each batch (klr_prof_read_cd)")
 
 
 def synth_csr(seed, row0, n_local, n_total, m, draws, S, threads=0):

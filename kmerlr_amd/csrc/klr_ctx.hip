@@ -67,22 +67,46 @@ struct RcclState {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ Id128, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 
 static int rccl_load(RcclState* st) {
   if (st->lib) return KLR_OK;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* nm : names) {
-    st->lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+  // 1. an RCCL this process has already mapped (a torch host bundles its own copy next to its HIP runtime: use that one,
+  //    not a second library against another runtime); 2. the ROCm installation by absolute path (a Go / C host has
+  //    nothing mapped and may have no library path set); 3. the loader's search path.
+  std::string tried;
+  const char* loaded[] = {"librccl.so.1", "librccl.so"};
+  for (const char* nm : loaded) {
+    st->lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
     if (st->lib) break;
   }
-  if (!st->lib) return klr_fail(nullptr, KLR_ECOMM, "cannot load librccl: %s", dlerror());
+  if (!st->lib) {
+    std::vector<std::string> paths;
+    if (const char* rp = getenv("ROCM_PATH")) { paths.push_back(std::string(rp) + "/lib/librccl.so.1"); paths.push_back(std::string(rp) + "/lib/librccl.so"); }
+    paths.push_back("/opt/rocm/lib/librccl.so.1");
+    paths.push_back("/opt/rocm/lib/librccl.so");
+    paths.push_back("librccl.so.1");
+    paths.push_back("librccl.so");
+    for (const std::string& pth : paths) {
+      st->lib = dlopen(pth.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (st->lib) break;
+      const char* de = dlerror();
+      tried += pth + ": " + (de ? de : "?") + "; ";
+    }
+  }
+  if (!st->lib) return klr_fail(nullptr, KLR_ECOMM, "cannot load librccl (%s)", tried.c_str());
   st->GetUniqueId = (int (*)(void*))dlsym(st->lib, "ncclGetUniqueId");
   st->CommInitRank = (int (*)(void**, int, Id128, int))dlsym(st->lib, "ncclCommInitRank");
   st->AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(st->lib, "ncclAllReduce");
+  st->ReduceScatter = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(st->lib, "ncclReduceScatter");
+  st->AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(st->lib, "ncclAllGather");
   st->CommDestroy = (int (*)(void*))dlsym(st->lib, "ncclCommDestroy");
+  st->CommCount = (int (*)(void*, int*))dlsym(st->lib, "ncclCommCount");
   st->GetErrorString = (const char* (*)(int))dlsym(st->lib, "ncclGetErrorString");
   if (!st->GetUniqueId || !st->CommInitRank || !st->AllReduce || !st->CommDestroy)
     return klr_fail(nullptr, KLR_ECOMM, "librccl lacks the expected nccl* symbols");
@@ -136,6 +160,47 @@ extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* us
   ctx->ar_user = user;
   ctx->rank = rank;
   ctx->nranks = nranks;
+  return KLR_OK;
+}
+
+extern "C" int klr_ctx_comm_info(const klr_ctx* ctx, int* rank, int* nranks, int* rccl_ranks) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  if (rank) *rank = ctx->rank;
+  if (nranks) *nranks = ctx->nranks;
+  if (rccl_ranks) {
+    *rccl_ranks = 0;                                  // 0: no RCCL communicator (no hook, or a caller-supplied hook)
+    const RcclState* st = (const RcclState*)ctx->rccl;
+    if (st && st->comm && st->CommCount) { int c = 0; if (st->CommCount(st->comm, &c) == 0) *rccl_ranks = c; }
+  }
+  return KLR_OK;
+}
+
+// average time of the all-reduce hook alone on `count` elements (a scratch buffer on the ctx stream, HIP events around
+// `iters` back-to-back calls after one untimed call): what bench.py reports beside the step it is part of
+extern "C" int klr_allreduce_time(klr_ctx* ctx, int64_t count, int dtype, int iters, double* ms_avg) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, count >= 1 && iters >= 1 && ms_avg != nullptr && (dtype == KLR_F64 || dtype == KLR_I64));
+  *ms_avg = 0.0;
+  if (!ctx->ar_fn) return KLR_OK;
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  void* buf;
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)count * 8, &buf));
+  KLR_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)count * 8, ctx->stream));
+  KLR_TRY(klr_allreduce(ctx, buf, count, dtype));
+  hipEvent_t e0, e1;
+  KLR_HIP(ctx, hipEventCreate(&e0));
+  KLR_HIP(ctx, hipEventCreate(&e1));
+  KLR_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  int rc = KLR_OK;
+  for (int i = 0; i < iters && rc == KLR_OK; i++) rc = klr_allreduce(ctx, buf, count, dtype);
+  hipError_t he = hipEventRecord(e1, ctx->stream);
+  if (he == hipSuccess) he = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc != KLR_OK) return rc;
+  if (he != hipSuccess) return klr_fail(ctx, KLR_EHIP, "timing the all-reduce failed: %s", hipGetErrorString(he));
+  *ms_avg = (double)ms / iters;
   return KLR_OK;
 }
 
@@ -212,6 +277,8 @@ extern "C" void klr_ctx_destroy(klr_ctx* ctx) {
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
   for (auto& pr : ctx->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pr : ctx->prof_cd) { (void)hipEventDestroy(pr.e0); (void)hipEventDestroy(pr.e1); }
+  if (ctx->evict_buf) (void)hipFree(ctx->evict_buf);
   for (int i = 0; i < WS_COUNT; i++) if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   if (ctx->rccl) {
@@ -319,6 +386,44 @@ extern "C" int klr_prof_read(klr_ctx* ctx, int64_t* launches, double* total_ms, 
     for (auto& pr : ctx->prof_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     ctx->prof_ev.clear();
   }
+  return KLR_OK;
+}
+
+extern "C" int klr_prof_read_cd(klr_ctx* ctx, int64_t* sweeps, int64_t* batches, double* total_ms, int reset) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0; int64_t sw = 0;
+  for (auto& pr : ctx->prof_cd) {
+    float ms = 0.f;
+    KLR_HIP(ctx, hipEventElapsedTime(&ms, pr.e0, pr.e1));
+    tot += (double)ms; sw += pr.sweeps;
+  }
+  if (sweeps) *sweeps = sw;
+  if (batches) *batches = (int64_t)ctx->prof_cd.size();
+  if (total_ms) *total_ms = tot;
+  if (reset) {
+    for (auto& pr : ctx->prof_cd) { (void)hipEventDestroy(pr.e0); (void)hipEventDestroy(pr.e1); }
+    ctx->prof_cd.clear();
+  }
+  return KLR_OK;
+}
+
+// Pushes the resident data out of the 256 MiB Infinity Cache: `bytes` written and then copied (read + written) inside a
+// scratch buffer on the ctx stream.  bench.py's cold-stream leg calls it between steps.
+extern "C" int klr_prof_evict(klr_ctx* ctx, int64_t bytes) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, bytes >= 2);
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->evict_cap < (size_t)bytes) {
+    KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->evict_buf) (void)hipFree(ctx->evict_buf);
+    ctx->evict_buf = nullptr; ctx->evict_cap = 0;
+    KLR_TRY(dev_alloc(ctx, &ctx->evict_buf, (size_t)bytes));
+    ctx->evict_cap = (size_t)bytes;
+  }
+  const size_t half = (size_t)bytes / 2;
+  KLR_HIP(ctx, hipMemsetAsync(ctx->evict_buf, 0x5a, (size_t)bytes, ctx->stream));
+  KLR_HIP(ctx, hipMemcpyAsync((char*)ctx->evict_buf + half, ctx->evict_buf, half, hipMemcpyDeviceToDevice, ctx->stream));
   return KLR_OK;
 }
 

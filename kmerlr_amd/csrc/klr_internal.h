@@ -62,6 +62,11 @@ struct klr_ctx {
   // profiling of the column sweep
   bool         prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  // ... and of the reduced-problem CD sweep kernels: (start, stop, sweeps executed) per batch of klr_cd_solve
+  struct CdProf { hipEvent_t e0, e1; int sweeps; };
+  std::vector<CdProf> prof_cd;
+  void*        evict_buf = nullptr;          // scratch of klr_prof_evict
+  size_t       evict_cap = 0;
   int          n_cu = 256;
   void*        sel_hist_zeroed = nullptr;   // selection histogram known to be all zero
   // device blocks of released reduced matrices (one block per matrix), reused in stream order by the next
@@ -119,7 +124,9 @@ struct klr_mat {
   i64  total4 = 0;               // quads (4 entries) incl. per-tile padding
   i64  stored_entries = 0;       // entries before padding
   double col_abs_max = 0.0;      // max over non-bias columns of sum_i |x_ij| (local rows)
-  double col_abs_max_global = -1.0;   // bound over all ranks (lazily all-reduced)
+  double col_abs_max_global = -1.0;   // bound over all ranks (sweep_protocol)
+  int    sweep_int = -1;         // protocol of the full-width sweep agreed by all ranks: 1 integer stream + int64 all-reduce,
+                                 // 0 plain CSC + f64 all-reduce, -1 not negotiated yet (sweep_protocol, klr_sweep.hip)
   u32* t_ent = nullptr;          // total4*4 packed entries
   u32* t_piece = nullptr;        // npiece * 4: {column tile, quad begin, quad end, first tile index}
   u32* t_tileq = nullptr;        // ntile+1 quad offsets of the tiles (column-tile major: tile = ct*nrt + rt)
@@ -201,6 +208,7 @@ int   sweep_all(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const doub
 // count data, fused form used by klr_sweep_select: the row pass writes the fixed-point weights itself
 // (sweep_fix_begin gives it scale/S/acc), the conversion back to f64 also emits the selection keys and
 // their coarse histogram (keys/hist from sel_prepare; may be NULL).
+int   sweep_protocol(klr_ctx* ctx, const klr_mat* mat, bool* use_int);
 int   sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double* scale_out, i64** S_out,
                       unsigned long long** acc_out);
 // selection candidates and the control block of the fast path (klr_select.hip)

@@ -62,6 +62,17 @@ extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows
   return KLR_OK;
 }
 
+extern "C" int klr_mat_stream_info(const klr_mat* mat, int* format, int64_t* stream_bytes, int64_t* piece_bytes, int64_t* table_bytes) {
+  if (!mat) return klr_fail(nullptr, KLR_EINVAL, "mat is NULL");
+  const bool t = mat->tiled;
+  if (format) *format = t ? mat->fmt : -1;
+  if (stream_bytes) *stream_bytes = t ? mat->total4 * (mat->fmt == FMT_U24 ? 12 : 16) : 0;
+  if (piece_bytes) *piece_bytes = t ? (int64_t)TILE_DIM * 8 : 0;
+  // read by the sweep: piece records (16 B), one 32-byte record per workgroup, tile offsets (4 B per tile)
+  if (table_bytes) *table_bytes = t ? (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 32 + ((int64_t)mat->nrt * mat->nct + 2) * 4 : 0;
+  return KLR_OK;
+}
+
 static int pick_group(double avg_len) {
   int g = 4;
   while (g < 64 && 4.0 * g < avg_len) g *= 2;
@@ -391,7 +402,12 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
   if (n_total == 0) n_total = n;
   KLR_ARG(ctx, n_total >= n);
   const i64 nnz = rowptr[n];
-  KLR_ARG(ctx, nnz == 0 || (col != nullptr && val != nullptr));
+  KLR_ARG(ctx, nnz >= 0 && (nnz == 0 || (col != nullptr && val != nullptr)));
+  // the row pointers are checked before anything is read or written through them
+  for (i64 i = 0; i < n; i++)
+    if (rowptr[i] < 0 || rowptr[i] > rowptr[i + 1] || rowptr[i + 1] > nnz)
+      return klr_fail(ctx, KLR_EINVAL, "rowptr must be non-decreasing within [0, rowptr[n]] (row %lld: %lld, %lld; nnz %lld)",
+                      (long long)i, (long long)rowptr[i], (long long)rowptr[i + 1], (long long)nnz);
   KLR_HIP(ctx, hipSetDevice(ctx->device));
 
   // ---- validate + per-column counts (threads own contiguous row blocks) ----------------------

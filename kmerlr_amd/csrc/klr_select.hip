@@ -672,6 +672,8 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   // restoreNonzero (:194-219): b[0] = 1 and b[j] = 1 where theta_j != 0; c = count
   i64 c_prev = 0;
   bool theta_inline = false;
+  bool use_int;                                        // integer stream on EVERY rank, or the f64 protocol on every rank
+  KLR_TRY(sweep_protocol(ctx, full, &use_int));
   memset(b, 0, (size_t)dim);
   b[0] = 1;
   if (reduced) {
@@ -682,12 +684,12 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
     // count data and a small reduced problem: theta rides in the row pass's kernel arguments (a 1 KB upload
     // is a 5 us blit kernel of its own)
-    theta_inline = full->tiled && c_plus_1 <= 128;
+    theta_inline = use_int && c_plus_1 <= 128;
     if (!theta_inline) KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
   }
   bool keys_ready = false;
   u64 hint_tau = 0;
-  if (full->tiled) {
+  if (use_int) {
     // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
     // all-reduce of [g | bias | loss]; conversion to f64 emits the selection keys + histogram
     double scale_fx; i64* S; unsigned long long* acc; u64* keys; u32* hist;
@@ -713,8 +715,9 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     else         KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, nullptr, gbuf + dim));
     KLR_TRY(sweep_all(ctx, full, cw, s, nullptr, gbuf));
   }
-  if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (scale || offset) KLR_TRY(apply_transform_dev(ctx, gbuf, dim, scale, offset));
+  // g_out is the gradient the selection sees (transformed like klr_gradient's), kmerLr_logistic_regression.go:196-222
+  if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 
   double loss_sum = NAN;
   KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready,

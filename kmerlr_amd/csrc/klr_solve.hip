@@ -1493,6 +1493,11 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         if (q_stale) hipLaunchKernelGGL(k_gtheta, dim3((unsigned)ceil_div((i64)d, (i64)64)), dim3(256), 0, st, G, thd, d, q_dev);
         q_stale = false;
       }
+      hipEvent_t pe0 = nullptr, pe1 = nullptr;           // klr_prof_*: device time of the sweep kernels of this batch
+      if (ctx->prof_on) {
+        KLR_HIP(ctx, hipEventCreate(&pe0)); KLR_HIP(ctx, hipEventCreate(&pe1));
+        KLR_HIP(ctx, hipEventRecord(pe0, st));
+      }
       if (d <= 128) {
         a.q_io = q_dev; a.q_load = q_stale ? 0 : 1;       // formed in the kernel (Gram in LDS) when theta or G changed
         q_stale = false;
@@ -1521,6 +1526,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         }
       }
       else               hipLaunchKernelGGL(k_cd_sweeps, dim3(1), dim3(CD_THREADS), lds_bytes, st, a);
+      if (pe0) KLR_HIP(ctx, hipEventRecord(pe1, st));
       if (eval_loss) {
         // iterates staged in LDS only while that is cheaper than reading them where they are: a block of LM_ROWS rows
         // stages KSPEC * d values but uses ~KSPEC * 32 * (row length) of them
@@ -1548,6 +1554,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         memcpy(hstop.data(), pr + (size_t)KSPEC * d + 2 * KSPEC + 2, (KSPEC + 1) * sizeof(int));
       }
       const int nd = hstop[KSPEC];
+      if (pe0) ctx->prof_cd.push_back({pe0, pe1, nd});
       bool cut = false;     // stopped before the end of the batch -> device theta must be rewound
       for (int k = 0; k < nd; k++) {
         th.assign(hhist.begin() + (size_t)k * d, hhist.begin() + (size_t)(k + 1) * d);

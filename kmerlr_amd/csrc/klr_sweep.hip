@@ -844,23 +844,38 @@ static double coo_scale(double smax, double amax) {
   return std::ldexp(1.0, E);
 }
 
+// Which protocol the full-width sweep of this matrix runs -- decided ONCE per matrix and TOGETHER by all ranks.
+// Every rank builds the tiled integer stream on its own (count data, n >= 2048, nnz >= 2^20); a shard that falls on
+// the other side of that test (a short last shard, one non-count value) would otherwise post an f64 all-reduce of
+// dim+1 elements against its neighbours' int64 all-reduce of dim+5.  So the first sweep on a matrix all-reduces
+// [column-sum bound | 1 if this shard has no stream]: the integer protocol is used only if EVERY shard has the stream,
+// else every rank runs the plain CSC sweep with the f64 all-reduce (all matrices keep their CSC).  The same
+// collective carries the bound on the column sums the fixed-point scale needs (sum of the per-rank maxima).
+int sweep_protocol(klr_ctx* ctx, const klr_mat* mat, bool* use_int) {
+  klr_mat* mm = const_cast<klr_mat*>(mat);
+  if (mm->sweep_int < 0) {
+    double v[2] = {mat->tiled ? mat->col_abs_max : 0.0, mat->tiled ? 0.0 : 1.0};
+    if (ctx->ar_fn) {
+      double* t;
+      KLR_TRY(ws_get(ctx, WS_BLK, 64, (void**)&t));
+      KLR_TRY(h2d(ctx, t, v, 2 * sizeof(double)));
+      KLR_TRY(klr_allreduce(ctx, t, 2, KLR_F64));
+      KLR_TRY(d2h_sync(ctx, v, t, 2 * sizeof(double)));
+    }
+    mm->col_abs_max_global = v[0];
+    mm->sweep_int = (mat->tiled && v[1] == 0.0) ? 1 : 0;
+  }
+  *use_int = mm->sweep_int == 1;
+  return KLR_OK;
+}
+
 // scale, S and the integer accumulator block of one count-data sweep
 int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double* scale_out, i64** S_out,
                     unsigned long long** acc_out) {
   const i64 n = mat->n, dim = mat->dim;
-  // global bound on the column sums: sum of the per-rank maxima (one collective per matrix)
-  klr_mat* mm = const_cast<klr_mat*>(mat);
-  if (mm->col_abs_max_global < 0.0) {
-    double a = mat->col_abs_max;
-    if (ctx->ar_fn) {
-      double* t;
-      KLR_TRY(ws_get(ctx, WS_BLK, 64, (void**)&t));
-      KLR_TRY(h2d(ctx, t, &a, sizeof(double)));
-      KLR_TRY(klr_allreduce(ctx, t, 1, KLR_F64));
-      KLR_TRY(d2h_sync(ctx, &a, t, sizeof(double)));
-    }
-    mm->col_abs_max_global = a;
-  }
+  bool use_int;
+  KLR_TRY(sweep_protocol(ctx, mat, &use_int));
+  if (!use_int) return klr_fail(ctx, KLR_EINVAL, "internal: integer sweep on a matrix negotiated to the f64 protocol");
   const double smax = std::max(std::fabs(cw[0]), std::fabs(cw[1])) / (double)mat->n_total;
   *scale_out = coo_scale(smax, mat->col_abs_max_global);
   i64 *S, *ibuf;
@@ -924,7 +939,9 @@ static int sweep_coo(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const
 // s_dev holds the per-row weights; lterm_dev (count data) or gbuf[dim] (otherwise) the loss partials.
 int sweep_all(klr_ctx* ctx, const klr_mat* mat, const double cw[2], const double* s_dev, const double* lterm_dev,
               double* gbuf) {
-  if (mat->tiled) return sweep_coo(ctx, mat, cw, s_dev, lterm_dev, gbuf);
+  bool use_int;
+  KLR_TRY(sweep_protocol(ctx, mat, &use_int));
+  if (use_int) return sweep_coo(ctx, mat, cw, s_dev, lterm_dev, gbuf);
   KLR_TRY(launch_xt_s(ctx, mat, s_dev, gbuf, false));          // leaves gbuf[dim] (loss partial) untouched
   KLR_TRY(klr_allreduce(ctx, gbuf, mat->dim + 1, KLR_F64));
   return KLR_OK;

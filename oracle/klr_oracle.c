@@ -5,6 +5,9 @@
  * Every function cites the reference file:line (relative to /root/reference) whose
  * behaviour it restates.  Nothing here is copied from the reference (which is Go).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "klr_oracle.h"
 
 #include <math.h>
@@ -125,6 +128,47 @@ int klo_gradient(const klo_csr* x, const uint8_t* labels, const double* theta,
       if (theta[j] < 0) g[j] -= lambda; else if (theta[j] > 0) g[j] += lambda;
     }
   }
+  return 0;
+}
+
+/* The same loop (kmerLr_logistic_regression.go:166-182, no transform) with the rows split over `threads` OpenMP
+ * threads, every thread adding into a gradient vector of its own, the vectors summed in thread order afterwards.
+ * NOT what the reference does (its loop is single-threaded): bench.py's "all_cores" figure, i.e. what a
+ * multi-threaded port of the reference's loop reaches on the host.  Sum order differs from klo_gradient by the
+ * blocking, so results agree to rounding, not bit for bit. */
+int klo_gradient_mt(const klo_csr* x, const uint8_t* labels, const double* theta,
+                    const double cw[2], double* g, int threads) {
+  const int64_t n = x->n, dim = x->dim;
+  if (n == 0) return 1;
+  if (threads < 1) threads = 1;
+  const double nn = eff_n(n);
+  double* gt = (double*)calloc((size_t)threads * (size_t)dim, sizeof(double));
+  if (!gt) return 2;
+#pragma omp parallel num_threads(threads)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+    const int t = 0, T = 1;
+#endif
+    double* gl = gt + (size_t)t * (size_t)dim;
+    const int64_t r0 = n * t / T, r1 = n * (t + 1) / T;
+    for (int64_t i = r0; i < r1; i++) {
+      const double r = klo_class_log_pdf(x, i, theta, NULL, NULL, 1);
+      const int64_t  b = x->rowptr[i], q = x->rowptr[i + 1] - b;
+      const int64_t* ci = x->col + b;
+      const double*  cv = x->val + b;
+      const double w = labels[i] ? 1.0 / nn * cw[1] * (exp(r) - 1.0) : 1.0 / nn * cw[0] * (exp(r));
+      for (int64_t j = 0; j < q; j++) gl[ci[j]] += w * cv[j];
+    }
+  }
+  for (int64_t j = 0; j < dim; j++) {
+    double v = 0.0;
+    for (int t = 0; t < threads; t++) v += gt[(size_t)t * (size_t)dim + (size_t)j];
+    g[j] = v;
+  }
+  free(gt);
+  ar(g, dim);
   return 0;
 }
 

@@ -64,6 +64,9 @@ double klo_class_log_pdf(const klo_csr* x, int64_t i, const double* theta,
                          const double* scale, const double* offset, int y);
 void   klo_class_weights(const uint8_t* labels, int64_t n, double cw[2]);
 
+/* bench.py's all-core figure only: the Gradient loop with rows split over OpenMP threads (no transform) */
+int    klo_gradient_mt(const klo_csr* x, const uint8_t* labels, const double* theta,
+                       const double cw[2], double* g, int threads);
 int    klo_gradient(const klo_csr* x, const uint8_t* labels, const double* theta,
                     const double cw[2], double lambda,
                     const double* scale, const double* offset, double* g);

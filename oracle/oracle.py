@@ -49,6 +49,8 @@ def lib():
         L.klo_class_weights.argtypes = [vp, i64, vp]
         L.klo_gradient.restype = C.c_int
         L.klo_gradient.argtypes = [C.POINTER(_Csr), vp, vp, vp, C.c_double, vp, vp, vp]
+        L.klo_gradient_mt.restype = C.c_int
+        L.klo_gradient_mt.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, C.c_int]
         L.klo_loss.restype = C.c_double
         L.klo_loss.argtypes = [C.POINTER(_Csr), vp, vp, vp, C.c_double, vp, vp]
         L.klo_sort_abs_desc.argtypes = [vp, i64, vp]
@@ -152,11 +154,17 @@ def class_weights(labels):
     return cw
 
 
-def gradient(x, labels, theta, cw=(1.0, 1.0), lam=0.0, scale=None, offset=None):
+def gradient(x, labels, theta, cw=(1.0, 1.0), lam=0.0, scale=None, offset=None, threads=1):
+    """threads > 1: klo_gradient_mt (rows over OpenMP threads; bench.py's all-core figure), no transform / lambda."""
     labels = np.ascontiguousarray(labels, dtype=np.uint8)
     theta, scale, offset, cw = _f64(theta), _f64(scale), _f64(offset), _f64(cw)
     assert theta.shape == (x.dim,)
     g = np.zeros(x.dim)
+    if threads > 1:
+        assert scale is None and offset is None and lam == 0.0
+        rc = lib().klo_gradient_mt(x.ref, _p(labels), _p(theta), _p(cw), _p(g), int(threads))
+        assert rc == 0
+        return g
     lib().klo_gradient(x.ref, _p(labels), _p(theta), _p(cw), lam, _p(scale), _p(offset), _p(g))
     return g
 

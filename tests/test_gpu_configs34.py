@@ -1,0 +1,252 @@
+"""GPU: BASELINE configs[3] / configs[4] at their per-GPU shard shape -- 125,000 rows x 1,048,576 k-mer columns,
+993 draws per row (1M x 1M over 8 GPUs) -- through the C ABI.  The oracle would take minutes at this size, so
+the checks are the size-independent properties the domain offers: at theta = 0 the gradient is an exact function
+of integer column sums; the selection is the N largest |g| under the documented tie rule; lambda is the midpoint
+between the N-th value and the next DISTINCT one; a solved classifier has exactly N nonzero coefficients and
+satisfies the KKT conditions of the L1 problem; everything is bitwise reproducible and independent of how the
+sweeps are batched.  The d = 5001 solver point of configs[4] is held to the oracle on a small-n matrix."""
+import numpy as np
+import pytest
+
+import kmerlr_amd as K
+from oracle import oracle as O
+from tests import oracle_driver as OD
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20261004
+N_ROWS, M_COLS, DRAWS = 125000, 1048576, 993
+FORMATS = ("r64", "u24", "u32")                       # entry formats of the packed stream (KLR_ENTRY_FORMAT)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+def exact_theta0(rowptr, col, val, n, m):
+    """d_j = (bg column sum) - (fg column sum) as exact integers; at theta = 0, cw = (1,1): g_j = d_j / (2n)."""
+    rows_fg = int(rowptr[n // 2])
+    fg = np.bincount(col[:rows_fg], weights=val[:rows_fg], minlength=m + 1)
+    bg = np.bincount(col[rows_fg:], weights=val[rows_fg:], minlength=m + 1)
+    return (bg - fg).astype(np.int64)
+
+
+def expected_selection(d, N):
+    """Select (kmerLr_feature_selection.go:78-134) from an empty model under the tie rule |g| descending, column
+    ascending, and computeLambda (:179-192) on exact values: v = N-th largest |d|, w = largest |d| below v."""
+    a = np.abs(d[1:])
+    order = np.lexsort((np.arange(len(a)), -a))
+    picked = np.sort(order[:N])
+    v = a[order[N - 1]]
+    below = a[a < v]
+    w = below.max() if len(below) else 0
+    return picked, int(v), int(w)
+
+
+@pytest.fixture(scope="module")
+def shard_c3(ctx):
+    """configs[3]'s per-GPU shard: S = 2 x 500 planted motif columns."""
+    rowptr, col, val, labels = K.synth_csr(SEED, 0, N_ROWS, N_ROWS, M_COLS, DRAWS, 1000)
+    mat = K.Matrix.from_csr(ctx, N_ROWS, M_COLS + 1, rowptr, col, val, labels)
+    d = exact_theta0(rowptr, col, val, N_ROWS, M_COLS)
+    nnz = int(rowptr[-1])
+    del rowptr, col, val
+    yield mat, d, labels, nnz
+    mat.close()
+
+
+def test_c3_shard_sweep_exact_and_selection(ctx, shard_c3):
+    mat, d, labels, nnz = shard_c3
+    lay = mat.layout()
+    assert lay["tiled"], lay
+    N = 500
+    r = K.sweep_select(ctx, mat, None, None, np.zeros(1), (1.0, 1.0), N, want_g=True)
+    g_exact = d / (2.0 * N_ROWS)
+    assert np.max(np.abs(r["g"][1:] - g_exact[1:])) <= 1e-12 * np.max(np.abs(g_exact[1:]))
+    assert abs(r["g"][0] - 0.0) <= 1e-15 and abs(r["loss"] - np.log(2.0)) < 1e-12
+    # equal integer sums give equal gradients, bit for bit: ties on count data are exact ties
+    a = np.abs(d[1:]); ga = np.abs(r["g"][1:])
+    some = np.nonzero(a == np.bincount(a).argmax())[0]
+    assert len(some) > 1000 and np.all(ga[some] == ga[some[0]])
+    picked, v, w = expected_selection(d, N)
+    np.testing.assert_array_equal(np.nonzero(r["b"])[0][1:] - 1, picked)
+    assert r["c"] == N and r["ok"]
+    lam = (v / (2.0 * N_ROWS) + w / (2.0 * N_ROWS)) / 2.0
+    assert abs(r["lam"] - lam) <= 1e-12 * lam
+    # run to run: bitwise
+    r2 = K.sweep_select(ctx, mat, None, None, np.zeros(1), (1.0, 1.0), N, want_g=True)
+    np.testing.assert_array_equal(r["g"], r2["g"]); np.testing.assert_array_equal(r["b"], r2["b"])
+    assert r["lam"] == r2["lam"]
+    # linearity in the class weights (a different fixed-point scale, the same exact sums)
+    rows_fg = N_ROWS // 2
+    ra = K.sweep_select(ctx, mat, None, None, np.zeros(1), (2.0, 0.5), N, want_g=True)
+    assert abs(ra["g"][0] - (2.0 * (N_ROWS - rows_fg) - 0.5 * rows_fg) / (2.0 * N_ROWS)) < 1e-12
+
+
+def test_c3_shard_entry_formats_agree(ctx, monkeypatch):
+    """Every entry format of the packed stream gives the same integer sums on the 1M-column shape (bitwise equal g)."""
+    n = 20000                                            # 20k rows keep the three extra ingests short; same column geometry
+    rowptr, col, val, labels = K.synth_csr(SEED, 0, n, n, M_COLS, DRAWS, 1000)
+    gs = {}
+    for fmt in FORMATS:
+        monkeypatch.setenv("KLR_ENTRY_FORMAT", fmt)
+        mat = K.Matrix.from_csr(ctx, n, M_COLS + 1, rowptr, col, val, labels)
+        assert mat.layout()["tiled"]
+        theta_cols = np.array([0, 17, 4242, 1000003])
+        red = mat.select_columns(theta_cols)
+        gs[fmt] = K.sweep_select(ctx, mat, red, theta_cols, np.array([0.1, 0.3, -0.2, 0.05]), (1.0, 1.0), 50, want_g=True)
+        red.close(); mat.close()
+    for fmt in FORMATS[1:]:
+        np.testing.assert_array_equal(gs[fmt]["g"], gs[FORMATS[0]]["g"])
+        np.testing.assert_array_equal(gs[fmt]["b"], gs[FORMATS[0]]["b"])
+        assert gs[fmt]["lam"] == gs[FORMATS[0]]["lam"]
+
+
+def kkt_check(ctx, full, cl, N):
+    cols, theta, lam = cl["cols"], cl["theta"], cl["lam"]
+    assert int(np.count_nonzero(theta[1:])) == N and len(cols) >= N + 1
+    red = full.select_columns(cols)
+    g = K.gradient_dense(ctx, red, theta, full.class_weights())
+    red.close()
+    nz = theta[1:] != 0
+    assert abs(g[0]) < 1e-5
+    assert np.max(np.abs(np.abs(g[1:][nz]) - lam)) < 2e-3 * lam
+    assert np.all(np.sign(g[1:][nz]) == -np.sign(theta[1:][nz]))
+    if (~nz).any():
+        assert np.max(np.abs(g[1:][~nz])) <= lam * (1 + 2e-3)
+
+
+def test_c3_estimate_lambda_auto_500(ctx, shard_c3):
+    from kmerlr_amd import _driver
+    mat, d, labels, nnz = shard_c3
+    est = _driver.hip_estimator(ctx)
+    cls = est.estimate(mat._h, [500])
+    lam_e, nz_e = est.epochs()
+    est.close()
+    kkt_check(ctx, mat, cls[0], 500)
+    assert nz_e[-1] == 501 and all(a <= b for a, b in zip(nz_e, nz_e[1:]))     # the path only grows (leapfrog)
+    est = _driver.hip_estimator(ctx)
+    cls2 = est.estimate(mat._h, [500])
+    est.close()
+    np.testing.assert_array_equal(cls2[0]["cols"], cls[0]["cols"])
+    np.testing.assert_array_equal(cls2[0]["theta"], cls[0]["theta"])
+
+
+@pytest.fixture(scope="module")
+def shard_c4(ctx):
+    """configs[4]'s data: the same shape with S = 2 x 5000 planted motif columns."""
+    rowptr, col, val, labels = K.synth_csr(SEED, 0, N_ROWS, N_ROWS, M_COLS, DRAWS, 10000)
+    mat = K.Matrix.from_csr(ctx, N_ROWS, M_COLS + 1, rowptr, col, val, labels)
+    del rowptr, col, val
+    yield mat, labels
+    mat.close()
+
+
+def test_c4_leapfrog_path_50_200_1000_5000(ctx, shard_c4, monkeypatch):
+    from kmerlr_amd import _driver
+    mat, labels = shard_c4
+    path = [50, 200, 1000, 5000]
+
+    def run():
+        est = _driver.hip_estimator(ctx)
+        cls = est.estimate(mat._h, path)
+        ep = est.epochs()
+        est.close()
+        return cls, ep
+    cls, ep = run()
+    assert len(cls) == 4
+    for cl, N in zip(cls, path):
+        kkt_check(ctx, mat, cl, N)
+    for a, b in zip(cls, cls[1:]):                        # every classifier of the path contains the one before it
+        sa = set(a["cols"][a["theta"] != 0]); sb = set(b["cols"])
+        assert sa <= sb
+    lam = [c["lam"] for c in cls]
+    assert all(x > y for x, y in zip(lam, lam[1:]))
+    cls2, ep2 = run()
+    for a, b in zip(cls, cls2):
+        np.testing.assert_array_equal(a["cols"], b["cols"]); np.testing.assert_array_equal(a["theta"], b["theta"])
+    assert ep2 == ep
+    monkeypatch.setenv("KLR_CD_BATCH", "3")
+    monkeypatch.setenv("KLR_CD_FIRST_BATCH", "8")
+    cls3, ep3 = run()
+    for a, b in zip(cls, cls3):
+        np.testing.assert_array_equal(a["cols"], b["cols"]); np.testing.assert_array_equal(a["theta"], b["theta"])
+
+
+def test_c4_five_fold_cv(ctx, shard_c4):
+    from kmerlr_amd import _driver
+    mat, labels = shard_c4
+    path = [50, 200, 1000, 5000]
+    est = _driver.hip_estimator(ctx, balance=1)
+    r = est.crossvalidate(mat._h, N_ROWS, 5, path, seed=1)
+    est.close()
+    groups = r["groups"]
+    assert groups.shape == (N_ROWS,) and set(np.unique(groups)) == set(range(5))
+    sizes = np.bincount(groups)
+    assert sizes.max() - sizes.min() <= 1
+    pred = r["predictions"]                              # [lambda][row]: log sigma of the held-out fold's classifier
+    assert pred.shape == (len(path), N_ROWS) and np.all(np.isfinite(pred)) and np.all(pred <= 0.0)
+    lt, lv = np.asarray(r["loss_train"]), np.asarray(r["loss_test"])
+    assert lt.shape == (len(path), 5) and lv.shape == (len(path), 5)             # [lambda][fold]
+    assert np.all(lt < np.log(2.0)) and np.all(lv < np.log(2.0))                 # the planted signal is found ...
+    assert np.all(lt[-1] < lt[0])                                                # ... and more features fit the training folds better
+    # held-out accuracy: the classifier of a row's fold predicts its label
+    acc = np.mean((pred[0] > np.log(0.5)) == (labels == 1))
+    assert acc > 0.9
+    for k, cl in enumerate(r["classifiers"]):
+        assert int(np.count_nonzero(cl["theta"][1:])) == path[k % len(path)]
+    est = _driver.hip_estimator(ctx, balance=1)
+    r2 = est.crossvalidate(mat._h, N_ROWS, 5, path, seed=1)
+    est.close()
+    np.testing.assert_array_equal(r2["predictions"], pred)
+    np.testing.assert_array_equal(r2["groups"], groups)
+
+
+def test_d5001_solver_follows_oracle(ctx):
+    """configs[4]'s last path point on a 1M-column matrix small enough for the oracle: 5001 coordinates -- the
+    super-block sweep (k_cd_sb_*) over a Gram matrix built one row per workgroup (k_gram_rows) -- must follow the
+    oracle's iterate sequence (same sweeps, same nonzero counts, theta within 1e-6)."""
+    n, N = 6000, 5000
+    x, labels = O.synth_csr(SEED, 0, n, n, M_COLS, DRAWS, 2 * N)
+    m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    cw = O.class_weights(labels)
+    r = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, N, want_g=True)
+    g = O.gradient(x, labels, np.zeros(x.dim), cw=cw)
+    assert np.max(np.abs(r["g"] - g)) <= 1e-11 * np.max(np.abs(g))
+    cols = np.nonzero(r["b"])[0]
+    assert len(cols) == N + 1
+    red = m.select_columns(cols); redo = O.select_columns(x, cols)
+    th, recs = K.cd_solve(ctx, red, np.zeros(N + 1), cw=cw, l1reg=r["lam"] * n, eps_loss=1e-9, max_iter=40)
+    tho, reco = O.cd_solve(redo, labels, np.zeros(N + 1), cw=cw, l1reg=r["lam"] * n, eps_loss=1e-9, max_iter=40)
+    assert [a["iteration"] for a in recs] == [a["iteration"] for a in reco]
+    assert [a["nonzero"] for a in recs] == [a["nonzero"] for a in reco]
+    np.testing.assert_allclose([a["loss"] for a in recs], [a["loss"] for a in reco], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(th, tho, rtol=1e-6, atol=1e-11)
+    red.close(); m.close()
+
+
+def test_d5001_whole_path_vs_oracle_driver(ctx):
+    """The leapfrog driver up to 5000 features on a 1M-column matrix, HIP backend against the oracle backend: identical
+    selected columns and path sequence, theta within 1e-6.  A generic per-column scale keeps |g_j| distinct (the tie
+    contract has its own test, test_gpu_ties.py)."""
+    n = 3000
+    x, labels = O.synth_csr(SEED + 1, 0, n, n, M_COLS, DRAWS, 10000)
+    scale = np.r_[1.0, 1.0 + 0.5 * np.random.default_rng(9).random(x.dim - 1)]
+    m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    eg = K.hip_estimator(ctx, max_iterations=4000)
+    cg = eg.estimate(m._h, [1000, 5000], scale=scale)
+    h = OD.matrix(x, labels)
+    eo = OD.estimator(max_iterations=4000)
+    co = eo.estimate(h, [1000, 5000], scale=scale)
+    OD.free_matrix(h)
+    lg, ng = eg.epochs(); lo, no = eo.epochs()
+    assert list(ng) == list(no)
+    np.testing.assert_allclose(lg, lo, rtol=1e-6)
+    for a, b in zip(cg, co):
+        np.testing.assert_array_equal(a["cols"], b["cols"])
+        np.testing.assert_allclose(a["theta"], b["theta"], rtol=1e-6, atol=1e-10)
+    assert len(cg[1]["cols"]) >= 5001
+    eg.close(); eo.close(); m.close()
