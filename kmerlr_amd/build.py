@@ -19,6 +19,10 @@ HEADERS = [os.path.join(CSRC, "klr_internal.h"), os.path.join(HERE, "..", "inclu
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
          "-Wno-unused-result", "-fno-gpu-rdc"]
+# KLR_ABLATIONS=1 python -m kmerlr_amd.build --force: a development build that also holds the A/B variants and the
+# timing-only ablations of the sweep kernels (tools/ab_sweep.py, tools/ab_formats.py); never the shipped library
+if os.environ.get("KLR_ABLATIONS"):
+    FLAGS.append("-DKLR_ABLATIONS")
 
 
 def hipcc():

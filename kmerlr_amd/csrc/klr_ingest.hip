@@ -291,6 +291,115 @@ __global__ __launch_bounds__(256) void k_r64_pad(const i64* __restrict__ rq_pref
   if (quads & 1) { const i64 qp = tile_unit[t] * 2 + quads; ent[qp] = r64_null_quad(4095u, (u32)qp); }
 }
 
+// ---- q64: row-streamed quads (k_sweep_q64): column strips only, rows ascending inside a strip, a quad =
+// row:(64 - 4 CB) | 4 x col:CB with the row relative to the first row of its 64-unit block -------------------------------
+// quads of both strip widths in one pass over the rows (the ingest picks the fewer bytes): out[0] CB = 12, out[1] CB = 13
+__global__ __launch_bounds__(256) void k_q64_totals(const i64* __restrict__ rowptr, const u32* __restrict__ col, const float* __restrict__ val,
+                                                    i64 n, u32 CT12, u32 CT13, unsigned long long* __restrict__ out) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long q12 = 0, q13 = 0;
+  if (i < n) {
+    u32 c12 = 0xFFFFFFFFu, c13 = 0xFFFFFFFFu, r12 = 0, r13 = 0;
+    for (i64 a = rowptr[i] + 1; a < rowptr[i + 1]; a++) {                  // entry 0 is the bias
+      const u32 c = col[a], v = (u32)val[a];
+      const u32 t12 = c / CT12, t13 = c / CT13;
+      if (t12 != c12) { q12 += (r12 + 3u) / 4u; c12 = t12; r12 = 0; }
+      if (t13 != c13) { q13 += (r13 + 3u) / 4u; c13 = t13; r13 = 0; }
+      r12 += v; r13 += v;
+    }
+    q12 += (r12 + 3u) / 4u; q13 += (r13 + 3u) / 4u;
+  }
+  for (int o = 32; o > 0; o >>= 1) { q12 += __shfl_xor(q12, o, 64); q13 += __shfl_xor(q13, o, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], q12); atomicAdd(&out[1], q13); }
+}
+
+// quads of every (row, strip) run -> rq[strip * n + row]
+__global__ __launch_bounds__(256) void k_q64_count(const i64* __restrict__ rowptr, const u32* __restrict__ col, const float* __restrict__ val,
+                                                   i64 n, u32 CT, u32* __restrict__ rq) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u32 cur = 0xFFFFFFFFu, run = 0;
+  for (i64 a = rowptr[i] + 1; a < rowptr[i + 1]; a++) {
+    const u32 t = col[a] / CT;
+    if (t != cur) { if (cur != 0xFFFFFFFFu) rq[(size_t)cur * n + i] = (run + 3u) / 4u; cur = t; run = 0; }
+    run += (u32)val[a];
+  }
+  if (cur != 0xFFFFFFFFu) rq[(size_t)cur * n + i] = (run + 3u) / 4u;
+}
+
+// 16-byte units of every strip, rounded up to whole 64-unit blocks (a wavefront never straddles two strips)
+__global__ __launch_bounds__(256) void k_q64_strip_units(const i64* __restrict__ rq_prefix, i64 n, u32 nct, u32* __restrict__ units) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nct) return;
+  const i64 quads = rq_prefix[(size_t)(t + 1) * n] - rq_prefix[(size_t)t * n];
+  units[t] = (u32)(((quads + 1) / 2 + 63) / 64 * 64);
+}
+
+__device__ __forceinline__ unsigned long long q64_null_quad(int CB, u32 pos) {
+  const unsigned long long d = ((1ull << CB) - 64ull) + (pos & 63u);          // row field 0: the block's first row
+  return d | (d << CB) | (d << (2 * CB)) | (d << (3 * CB));
+}
+
+__global__ __launch_bounds__(256) void k_q64_fill_null(unsigned long long* __restrict__ ent, i64 nquads, int CB) {
+  const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (q < nquads) ent[q] = q64_null_quad(CB, (u32)q);
+}
+
+// first row of every 64-unit (128-quad) block: the quad at a block's first position names it (rows ascend inside a
+// strip, strips are whole blocks); blocks of padding only keep row 0
+__global__ __launch_bounds__(256) void k_q64_blkrow(const i64* __restrict__ rowptr, const u32* __restrict__ col, const float* __restrict__ val,
+                                                    i64 n, u32 CT, const i64* __restrict__ rq_prefix, const i64* __restrict__ strip_unit,
+                                                    u32* __restrict__ blkrow) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u32 cur = 0xFFFFFFFFu;
+  for (i64 a = rowptr[i] + 1; a < rowptr[i + 1]; a++) {
+    const u32 t = col[a] / CT;
+    if (t == cur) continue;
+    cur = t;
+    const i64 qs = strip_unit[t] * 2 + (rq_prefix[(size_t)t * n + i] - rq_prefix[(size_t)t * n]);
+    const i64 qe = qs + (rq_prefix[(size_t)t * n + i + 1] - rq_prefix[(size_t)t * n + i]);
+    for (i64 b = (qs + 127) & ~(i64)127; b < qe; b += 128) blkrow[b >> 7] = (u32)i;
+  }
+}
+
+// the quads themselves; every quad is written by exactly one thread.  A row further than the row field reaches from its
+// block's first row (only possible when thousands of consecutive rows are absent from a strip) raises `overflow`: the
+// ingest then falls back to the tiled formats.
+__global__ __launch_bounds__(256) void k_q64_fill(const i64* __restrict__ rowptr, const u32* __restrict__ col, const float* __restrict__ val,
+                                                  i64 n, u32 CT, int CB, const i64* __restrict__ rq_prefix, const i64* __restrict__ strip_unit,
+                                                  const u32* __restrict__ blkrow, unsigned long long* __restrict__ ent, u32* __restrict__ overflow) {
+  const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int rsh = 4 * CB;
+  const u32 rmax = (1u << (64 - rsh)) - 1u;
+  u32 cur = 0xFFFFFFFFu, p = 0;
+  i64 qpos = 0;
+  unsigned long long w = 0;
+  auto start_quad = [&]() {
+    const u32 rel = (u32)i - blkrow[qpos >> 7];
+    if (rel > rmax) atomicOr(overflow, 1u);
+    w = q64_null_quad(CB, (u32)qpos) | ((unsigned long long)(rel & rmax) << rsh);
+  };
+  for (i64 a = rowptr[i] + 1; a < rowptr[i + 1]; a++) {
+    const u32 c = col[a];
+    const u32 t = c / CT;
+    if (t != cur) {
+      if (cur != 0xFFFFFFFFu && (p & 3u)) ent[qpos++] = w;
+      qpos = strip_unit[t] * 2 + (rq_prefix[(size_t)t * n + i] - rq_prefix[(size_t)t * n]);
+      cur = t; p = 0;
+    }
+    const unsigned long long cl = (unsigned long long)(c - t * CT);
+    for (u32 v = (u32)val[a]; v > 0u; v--) {
+      if ((p & 3u) == 0u) start_quad();
+      const int sh = CB * (int)(p & 3u);
+      w = (w & ~(((1ull << CB) - 1ull) << sh)) | (cl << sh);
+      if ((++p & 3u) == 0u) ent[qpos++] = w;
+    }
+  }
+  if (cur != 0xFFFFFFFFu && (p & 3u)) ent[qpos++] = w;
+}
+
 // the stream pre-filled with null unit entries (row 4095, column 0): bytes FF 0F 00 repeating
 __global__ __launch_bounds__(256) void k_fill_u24_null(u32* __restrict__ w, i64 nwords) {
   const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -316,6 +425,158 @@ struct TmpPool {
 static int exscan64(klr_ctx* ctx, const u32* in, i64 n, i64* out) { return launch_exscan_u32(ctx, in, n, out); }
 
 int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& toff4, i64 nrt, i64 nct, bool rt_major);
+
+// pieces of a q64 stream: the 64-unit blocks are dealt to nwg workgroups in equal shares, a share snapped to a strip
+// boundary when one lies within a few percent of it; a share is cut into pieces where the strip changes
+static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64>& strip_unit, i64 nct) {
+  const u64 total_blk = (u64)strip_unit[(size_t)nct] / 64;
+  // one workgroup per CU (a piece vector written per (strip, workgroup): half as many as with two), KLR_Q64_WGS=2 for two
+  const int per_cu = getenv("KLR_Q64_WGS") ? std::max(1, std::min(2, atoi(getenv("KLR_Q64_WGS")))) : 1;
+  const u32 nwg = (u32)std::max(2, per_cu * ctx->n_cu);
+  std::vector<u64> sb((size_t)nct + 1);
+  for (i64 t = 0; t <= nct; t++) sb[(size_t)t] = (u64)strip_unit[(size_t)t] / 64;
+  std::vector<u64> cut((size_t)nwg + 1);
+  {
+    const char* sn = getenv("KLR_CUT_SNAP");
+    const double tolf = sn ? atof(sn) : 0.08;
+    i64 t = 0;
+    cut[0] = 0;
+    for (u32 w = 1; w <= nwg; w++) {
+      const u64 prev = cut[w - 1];
+      const u64 share = (total_blk - prev) / (u64)(nwg - w + 1);
+      const u64 ideal = prev + share;
+      const double tol = tolf * (double)share;
+      while (t < nct && sb[(size_t)t + 1] <= ideal) t++;
+      u64 c = ideal;
+      const u64 lo = sb[(size_t)t], hi = t < nct ? sb[(size_t)t + 1] : total_blk;
+      if (lo > prev && (double)(ideal - lo) <= tol && (ideal - lo) <= (hi - ideal)) c = lo;
+      else if ((double)(hi - ideal) <= tol) c = hi;
+      cut[w] = std::max(c, prev);
+    }
+    cut[nwg] = total_blk;
+  }
+  std::vector<u32> piece, wgp((size_t)nwg + 1);
+  {
+    i64 t = 0;
+    for (u32 w = 0; w < nwg; w++) {
+      wgp[w] = (u32)(piece.size() / 4);
+      u64 q = cut[w];
+      const u64 q1 = cut[w + 1];
+      while (q < q1) {
+        while (sb[(size_t)t + 1] <= q) t++;
+        const u64 e = std::min<u64>(q1, sb[(size_t)t + 1]);
+        piece.push_back((u32)t); piece.push_back((u32)(q * 64)); piece.push_back((u32)(e * 64)); piece.push_back(0u);
+        q = e;
+      }
+    }
+    wgp[nwg] = (u32)(piece.size() / 4);
+  }
+  const u32 npiece = (u32)(piece.size() / 4);
+  std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(std::max<u32>(npiece, 1));
+  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
+  for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
+  {
+    std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
+    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
+  }
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)std::max<u32>(npiece, 1) * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
+  KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
+  {
+    // per workgroup: {first piece, end piece, first unit, end unit of the first piece}
+    std::vector<u32> rec((size_t)nwg * 4, 0u);
+    for (u32 w = 0; w < nwg; w++) {
+      rec[(size_t)w * 4] = wgp[w]; rec[(size_t)w * 4 + 1] = wgp[w + 1];
+      if (wgp[w] < wgp[w + 1]) { rec[(size_t)w * 4 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 4 + 3] = piece[(size_t)wgp[w] * 4 + 2]; }
+    }
+    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 16, hipMemcpyHostToDevice));
+  }
+  KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
+  KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
+  m->rt_major = false; m->tiled = true; m->nrt = 1; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
+  m->total4 = strip_unit[(size_t)nct];
+  return KLR_OK;
+}
+
+// The row-streamed q64 stream (k_sweep_q64) from the device CSR of a count matrix: strips of 4032 (CB = 12) or 8128
+// (CB = 13) columns, whichever gives the fewer bytes (stream + the piece vectors the sweep writes); no sort -- a thread
+// per row walks its column-sorted entries.  KLR_ENTRY_FORMAT=q64c12|q64c13 forces a width, r64|u24|u32 the tiled
+// formats.  *built = false: the caller goes on with the tiled formats.
+static int build_q64(klr_ctx* ctx, klr_mat* m, TmpPool& tmp, bool* built) {
+  *built = false;
+  const char* ef = getenv("KLR_ENTRY_FORMAT");
+  if (ef && (!strcmp(ef, "r64") || !strcmp(ef, "u24") || !strcmp(ef, "u32"))) return KLR_OK;
+  hipStream_t st = ctx->stream;
+  const i64 n = m->n, dim = m->dim, nnz = m->nnz;
+  const float* val = (const float*)m->val;
+  auto geom = [&](int CB, i64* nct, u32* CT) {
+    const i64 W = ((i64)1 << CB) - 64;
+    *nct = std::max<i64>(1, ceil_div(dim, W));
+    *CT = (u32)std::max<i64>(1, ceil_div(dim, *nct));
+    *nct = ceil_div(dim, (i64)*CT);
+  };
+  i64 nct12, nct13; u32 CT12, CT13;
+  geom(12, &nct12, &CT12); geom(13, &nct13, &CT13);
+  unsigned long long* d_tot; KLR_TRY(tmp.get(ctx, &d_tot, 2));
+  KLR_HIP(ctx, hipMemsetAsync(d_tot, 0, 16, st));
+  hipLaunchKernelGGL(k_q64_totals, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT12, CT13, d_tot);
+  unsigned long long h_tot[2];
+  KLR_TRY(d2h_sync(ctx, h_tot, d_tot, 16));
+  const u32 nwg = (u32)std::max(2, 2 * ctx->n_cu);
+  const double bytes12 = 8.0 * (double)h_tot[0] + (double)(nwg + nct12) * 4096.0 * 8.0;
+  const double bytes13 = 8.0 * (double)h_tot[1] + (double)(nwg + nct13) * 8192.0 * 8.0;
+  int CB = bytes13 < bytes12 ? 13 : 12;
+  if (ef && !strcmp(ef, "q64c12")) CB = 12;
+  if (ef && !strcmp(ef, "q64c13")) CB = 13;
+  const i64 nct = CB == 13 ? nct13 : nct12;
+  const u32 CT = CB == 13 ? CT13 : CT12;
+  const u64 quads = CB == 13 ? h_tot[1] : h_tot[0];
+  if (quads == 0 || quads / 2 + (u64)nct * 64 >= 0x0FFFFF00ull) return KLR_OK;       // the sweep addresses the stream with 32-bit byte offsets
+  if ((u64)nct * (u64)n >= ((u64)1 << 32)) return KLR_OK;                              // the (strip, row) table is scanned with 32-bit counts
+  u32 *rq, *sunits; i64 *rq_prefix, *strip_unit;
+  KLR_TRY(tmp.get(ctx, &rq, (size_t)nct * n + 1)); KLR_TRY(tmp.get(ctx, &rq_prefix, (size_t)nct * n + 2));
+  KLR_TRY(tmp.get(ctx, &sunits, (size_t)nct + 1)); KLR_TRY(tmp.get(ctx, &strip_unit, (size_t)nct + 2));
+  KLR_HIP(ctx, hipMemsetAsync(rq, 0, ((size_t)nct * n + 1) * 4, st));
+  hipLaunchKernelGGL(k_q64_count, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT, rq);
+  KLR_TRY(exscan64(ctx, rq, nct * n, rq_prefix));
+  hipLaunchKernelGGL(k_q64_strip_units, dim3((unsigned)ceil_div(nct, 256)), dim3(256), 0, st, rq_prefix, n, (u32)nct, sunits);
+  KLR_TRY(exscan64(ctx, sunits, nct, strip_unit));
+  std::vector<i64> h_su((size_t)nct + 1);
+  KLR_TRY(d2h_sync(ctx, h_su.data(), strip_unit, (size_t)(nct + 1) * 8));
+  const u64 units = (u64)h_su[(size_t)nct];
+  if (units == 0 || units >= 0x0FFFFF00ull) return KLR_OK;
+  unsigned long long* ent64; u32 *blkrow, *d_flag;
+  KLR_TRY(dalloc(ctx, (u32**)&ent64, (size_t)units * 4));
+  KLR_TRY(dalloc(ctx, &blkrow, (size_t)(units / 64)));
+  KLR_TRY(tmp.get(ctx, &d_flag, 1));
+  KLR_HIP(ctx, hipMemsetAsync(d_flag, 0, 4, st));
+  KLR_HIP(ctx, hipMemsetAsync(blkrow, 0, (size_t)(units / 64) * 4, st));
+  hipLaunchKernelGGL(k_q64_fill_null, dim3((unsigned)ceil_div((i64)units * 2, 256)), dim3(256), 0, st, ent64, (i64)units * 2, CB);
+  hipLaunchKernelGGL(k_q64_blkrow, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT, rq_prefix, strip_unit, blkrow);
+  hipLaunchKernelGGL(k_q64_fill, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT, CB, rq_prefix, strip_unit,
+                     (const u32*)blkrow, ent64, d_flag);
+  KLR_HIP(ctx, hipGetLastError());
+  u32 h_flag = 0;
+  KLR_TRY(d2h_sync(ctx, &h_flag, d_flag, 4));
+  if (h_flag) {                                          // a row field overflowed: very sparse strips -- tiled formats instead
+    (void)hipFree(ent64); (void)hipFree(blkrow);
+    return KLR_OK;
+  }
+  m->t_ent = (u32*)ent64; m->t_blkrow = blkrow;
+  m->fmt = CB == 13 ? FMT_Q64C13 : FMT_Q64C12;
+  m->tile_r = (u32)std::min<i64>(n, 0xFFFFFFFFll); m->tile_c = CT;
+  unsigned long long* d_t1; KLR_TRY(tmp.get(ctx, &d_t1, 2));
+  KLR_HIP(ctx, hipMemsetAsync(d_t1, 0, 16, st));
+  hipLaunchKernelGGL(k_entry_totals, dim3((unsigned)std::min<i64>(ceil_div(nnz, 256), 2048)), dim3(256), 0, st, m->col, val, nnz, d_t1);
+  unsigned long long h_t1[2];
+  KLR_TRY(d2h_sync(ctx, h_t1, d_t1, 16));
+  m->stored_entries = (i64)h_t1[0];
+  KLR_TRY(q64_pieces_and_upload(ctx, m, h_su, nct));
+  *built = true;
+  return KLR_OK;
+}
 
 // CSC + tiles + host metadata from a device CSR (rowptr i64[n+1], col u32, val f32 counts, erow u32 row of entry)
 static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, TmpPool& tmp) {
@@ -366,8 +627,13 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   KLR_HIP(ctx, hipGetLastError());
   KLR_HIP(ctx, hipStreamSynchronize(st));
   KLR_TRY(mat_build_chunks_and_upload(ctx, m));
-  // ---- tiles
+  // ---- packed integer stream of the full-width sweep
   if (n < 2048 || nnz < (1 << 20)) return KLR_OK;
+  {
+    bool built = false;
+    KLR_TRY(build_q64(ctx, m, tmp, &built));
+    if (built) return KLR_OK;
+  }
   i64 nrt, nct;
   tile_geometry(n, dim, (u32)std::max(2, 2 * ctx->n_cu), &m->tile_r, &m->tile_c, &nrt, &nct);
   const i64 ntile = nrt * nct;

@@ -134,6 +134,7 @@ struct klr_mat {
   int  fmt = 0;                  // FMT_U32: 4-byte entries (count:8|col:12|row:12); FMT_U24: 3-byte unit entries (col:12|row:12);
                                  // FMT_R64: 8-byte quads (row:12 | 4 x col:12), a row's run padded to 4 columns: 2 bytes per unit entry
   u32 tile_r = 4096, tile_c = 4096;   // rows / columns per tile (<= TILE_DIM), chosen at ingest (tile_geometry)
+  u32* t_blkrow = nullptr;       // q64: first row of every 64-unit block of the stream (row fields are relative to it)
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile
   // ---- host metadata
@@ -255,7 +256,8 @@ int   build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, 
 static inline i64 ceil_div(i64 a, i64 b) { return (a + b - 1) / b; }
 
 // 2-D tiled packed COO (klr_mat.hip build_tiled, klr_sweep.hip k_sweep_coo)
-enum { FMT_U32 = 0, FMT_U24 = 1, FMT_R64 = 2 };
+enum { FMT_U32 = 0, FMT_U24 = 1, FMT_R64 = 2,      // tiled formats (k_sweep_coo)
+       FMT_Q64C12 = 3, FMT_Q64C13 = 4 };          // row-streamed quads, 4032 / 8128 columns per strip (k_sweep_q64)
 static const u32 TILE_BITS = 12;
 // an r64 quad with all four columns padding: the quad's position spreads them over the 64 spare slots
 static inline __host__ __device__ unsigned long long r64_null_quad(unsigned row, unsigned pos) {

@@ -33,7 +33,7 @@ void mat_free(klr_mat* m) {
   (void)hipDeviceSynchronize();
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
                 m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->active, m->t_ent, m->t_piece, m->t_wgpiece,
-                m->t_ctptr, m->t_ctlist, m->t_tileq};
+                m->t_ctptr, m->t_ctlist, m->t_tileq, m->t_blkrow};
   for (void* p : ps) if (p) (void)hipFree(p);
   delete m;
 }
@@ -55,9 +55,10 @@ extern "C" int klr_mat_layout(const klr_mat* mat, int* tiled, int64_t* tile_rows
   if (tiled) *tiled = mat->tiled ? 1 : 0;
   if (tile_rows) *tile_rows = mat->tiled ? (int64_t)mat->tile_r : mat->n;
   if (nseg) *nseg = mat->tiled ? (int64_t)mat->npiece : mat->nchunks;
-  if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * (mat->fmt == FMT_R64 ? 8 : 4) : mat->nnz_pad;
+  const bool quads = mat->fmt == FMT_R64 || mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13;     // 8 unit entries per 16-byte unit
+  if (padded_entries) *padded_entries = mat->tiled ? mat->total4 * (quads ? 8 : 4) : mat->nnz_pad;
   if (lanes_per_segment) *lanes_per_segment = mat->tiled ? 0 : mat->group;
-  // tiled: bytes per padded entry = 3 + value_bytes (u32: 1, u24: 0, r64: -1 -- four columns share one row field)
+  // tiled: bytes per padded entry = 3 + value_bytes (u32: 1, u24: 0, r64 / q64: -1 -- four columns share one row field)
   if (value_bytes) *value_bytes = mat->tiled ? (mat->fmt == FMT_U32 ? 1 : (mat->fmt == FMT_U24 ? 0 : -1)) : (mat->val_f64 ? 8 : 4);
   return KLR_OK;
 }
@@ -67,9 +68,12 @@ extern "C" int klr_mat_stream_info(const klr_mat* mat, int* format, int64_t* str
   const bool t = mat->tiled;
   if (format) *format = t ? mat->fmt : -1;
   if (stream_bytes) *stream_bytes = t ? mat->total4 * (mat->fmt == FMT_U24 ? 12 : 16) : 0;
-  if (piece_bytes) *piece_bytes = t ? (int64_t)TILE_DIM * 8 : 0;
-  // read by the sweep: piece records (16 B), one 32-byte record per workgroup, tile offsets (4 B per tile)
-  if (table_bytes) *table_bytes = t ? (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 32 + ((int64_t)mat->nrt * mat->nct + 2) * 4 : 0;
+  const bool q64 = mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13;
+  if (piece_bytes) *piece_bytes = t ? (mat->fmt == FMT_Q64C13 ? 8192 : (int64_t)TILE_DIM) * 8 : 0;
+  // read by the sweep: piece records (16 B) and -- tiled formats: one 32-byte record per workgroup, tile offsets (4 B per
+  // tile); q64: a 16-byte record per workgroup, the first row of every 64-unit block (4 B per KiB of stream)
+  if (table_bytes) *table_bytes = !t ? 0 : q64 ? (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 16 + mat->total4 / 64 * 4
+                                               : (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 32 + ((int64_t)mat->nrt * mat->nct + 2) * 4;
   return KLR_OK;
 }
 

@@ -365,15 +365,15 @@ static void xt_s_group(int g, dim3 grid, hipStream_t st, const klr_mat* m, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// tiled column sweep for k-mer count data (the roofline kernel)
+// tiled column sweep for k-mer count data (k_sweep_coo: the u32 / u24 / r64 entry formats; the row-streamed q64
+// formats have their own kernel, k_sweep_q64 below)
 //
 // Random 8-byte gathers of s from L2 move a whole cache line per stored nonzero and cap the plain CSC
-// kernel at ~20 % of HBM peak (profiles/r01_plain_csc.md).  Here both vectors the sweep touches at
-// random live in LDS: the matrix is cut into 4096 x 4096 tiles, a workgroup holds the tile's 4096
-// s values and 4096 column accumulators (32 KiB each), and the ONLY HBM stream is the packed entry
-// array, 4 bytes per stored nonzero, read with non-temporal 16-byte loads.  Occupancy, not unrolling, hides
-// the HBM latency: 1024-thread workgroups, two per CU (32 waves/CU), one load per lane per iteration
-// measured 10 % faster than 512 threads x 4 loads and 30 % faster than x 8 (tools/ab_sweep.py).
+// kernel at ~20 % of HBM peak (profiles/README.md).  Here both vectors the sweep touches at random live in LDS:
+// the matrix is cut into tiles of at most 4094 x 4032 (tile_geometry), a workgroup holds the tile's s values and
+// 4096 column accumulators (32 KiB each), and the ONLY HBM stream is the packed entry array -- 2, 3 or 4 bytes per
+// stored unit entry (formats below), read with 16-byte (12-byte) loads.  Occupancy hides the latency: 1024-thread
+// workgroups, two per CU (32 waves/CU), one load per lane and trip plus a ping-pong prefetch (tools/ab_sweep.py).
 //
 // Accumulation is exact: s is converted to int64 fixed point (scale 2^E chosen from max|s| and the
 // largest column sum so that no column sum can overflow), products are integer, and the column
@@ -599,6 +599,152 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// q64: the row-streamed packed stream (FMT_Q64C12 / FMT_Q64C13)
+//
+// The matrix is cut into column STRIPS only (2^CB - 64 columns wide, CB = 12 or 13); inside a strip the unit
+// entries of ALL rows follow each other in ascending row order, every (row, strip) run padded to 4 columns: an
+// 8-byte quad = row:(64 - 4 CB) | 4 x col:CB, two quads per 16-byte lane unit.  There are no row tiles: a quad's row
+// field is relative to the first row of its 64-unit block (blkrow, 4 bytes per KiB of stream), and the fixed-point
+// weight S[row] is NOT staged in LDS -- consecutive lanes hold consecutive rows, so the S reads are short
+// sequential global loads that hit L1/L2 (a few cache lines per wavefront and trip).  What that buys:
+//   * LDS holds only the 2^CB column accumulators (32 or 64 KiB): no s-tile load, no barrier, no drain anywhere
+//     in mid-stream -- a 1M-column shard (7,967 tiles of ~15.6k entries in the tiled layout, each paying
+//     barrier + s-tile reload) streams without a stop; the 16 wavefronts of a workgroup run on their own between
+//     the piece boundaries;
+//   * strips twice as wide at CB = 13: runs of a 1M-column shard are ~7.7 entries instead of ~3.9, padding
+//     19 % instead of 40 %;
+//   * every wavefront keeps three stream units (16 bytes per lane each) and one pair of S values in flight: a stream that
+//     comes from HBM rather than the Infinity Cache is still covered.
+// Accumulation as in k_sweep_coo: exact int64 LDS atomics, one 2^CB-wide partial vector per (strip, workgroup) piece.
+// ---------------------------------------------------------------------------------------------
+// ABL (timing-only ablations, builds with -DKLR_ABLATIONS; results wrong by construction): 1 no write-out,
+// 2 no atomics, 3 no S loads, 4 stream only
+typedef int q64_i32x4 __attribute__((ext_vector_type(4)));
+__device__ q64_i32x4 q64_raw_buffer_load_x4(q64_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
+constexpr int q64_gcd(int a, int b) { return b == 0 ? a : q64_gcd(b, a % b); }
+
+// A = stream units requested ahead of the one being consumed, B = S pairs requested ahead (B < A).  Loads return in
+// the order they were issued, so the wait for the S pair of step k also waits for every stream unit requested before
+// it: with the S pair of step k + B going out BEFORE the stream unit of step k + A, min(B + 1, A - B) steps of stream
+// latency are covered.  (3, 1): two workgroups per CU (64 VGPRs each); (7, 3): one workgroup per CU.
+template <int CB, bool NT, int A, int B, int ABL = 0>
+__global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ ent, u32 ent_bytes, const u32* __restrict__ blkrow,
+                                                    const uint4* __restrict__ piece, const uint4* __restrict__ wgrec,
+                                                    const i64* __restrict__ S, i64* __restrict__ part) {
+  constexpr u32 PD = 1u << CB, CM = PD - 1u;
+  constexpr int RSH = 4 * CB - 32;                     // row field: bits [4 CB, 64) of the quad = y >> RSH
+  constexpr int NU = A + 1, NS = B + 1, L = NU * NS / q64_gcd(NU, NS);
+  static_assert(B < A && L <= 16, "ring sizes");
+  extern __shared__ unsigned long long q64_lds[];
+  unsigned long long* sG = q64_lds;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // one 16-byte record per workgroup: {first piece, end piece, first unit and end unit of the first piece} -- the first
+  // stream loads are one memory round trip away, not three (record -> piece -> stream)
+  const uint4 wr = wgrec[blockIdx.x];
+  const u32 p0 = wr.x, p1 = wr.y;
+  unsigned long long sink = 0ull;
+  // the stream as a buffer resource: a unit index past the wavefront's last block becomes an out-of-range offset, which
+  // loads zeros without touching memory -- no branch around a load (the wait counts stay exact), no duplicate traffic
+  q64_i32x4 rsrc;
+  {
+    const unsigned long long pa = (unsigned long long)ent;
+    rsrc.x = __builtin_amdgcn_readfirstlane((int)(u32)pa);
+    rsrc.y = __builtin_amdgcn_readfirstlane((int)(u32)(pa >> 32));
+    rsrc.z = __builtin_amdgcn_readfirstlane((int)ent_bytes);
+    rsrc.w = 0x00020000;
+  }
+  for (u32 p = p0; p < p1; p++) {
+    uint4 d;                                            // {strip, first unit, end unit, -}: both multiples of 64
+    if (p == p0) d = make_uint4(0u, wr.z, wr.w, 0u); else d = piece[p];
+    // first rows of this wavefront's first <= 64 blocks: requested before the accumulators are zeroed
+    u32 rbv0 = 0;
+    {
+      const u32 fb0 = (d.y >> 6) + wave, fb1 = min((d.y >> 6) + 1024u, d.z >> 6);
+      if (fb0 < fb1) rbv0 = blkrow[fb0 + (min(lane, ((fb1 - fb0 + 15u) >> 4) - 1u) << 4)];
+    }
+    __syncthreads();                                    // the previous piece has been written out
+    for (u32 i = tid; i < PD; i += 1024) sG[i] = 0ull;
+    __syncthreads();
+    // The piece's 64-unit blocks are dealt round-robin to the 16 wavefronts, 1024 blocks (64 per wavefront) at a time: a
+    // wavefront fetches the first rows of its <= 64 blocks with ONE vector load (lane l: its l-th block) and picks them
+    // out with v_readlane as it goes -- a scalar load per block would share its wait counter with the LDS atomics.
+    const u32 pb1 = d.z >> 6;
+    for (u32 bs = d.y >> 6; bs < pb1; bs += 1024u) {
+      const u32 b0 = bs + wave, b1 = min(bs + 1024u, pb1);   // this wavefront's blocks: b0, b0 + 16, ... < b1
+      if (b0 >= b1) continue;
+      const u32 nb = (b1 - b0 + 15u) >> 4, last = nb - 1u;
+      const u32 rbv = bs == (d.y >> 6) ? rbv0 : blkrow[b0 + (min(lane, last) << 4)];
+      uint4 U[NU];
+      unsigned long long Sa[NS], Sb[NS];
+#define Q_LOADU(SLOT, K) { const u32 k_ = (u32)(K);                                                                        \
+          const u32 off_ = k_ < nb ? ((((b0 + (k_ << 4)) << 6) + lane) << 4) : 0xFFFFFFF0u;                                   \
+          const q64_i32x4 t_ = q64_raw_buffer_load_x4(rsrc, (int)off_, 0, NT ? 2 : 0);                                       \
+          U[SLOT] = make_uint4((u32)t_.x, (u32)t_.y, (u32)t_.z, (u32)t_.w); }
+#define Q_LOADS(SLOT, USLOT, K) { const i64* sb_ = S + (u32)__builtin_amdgcn_readlane((int)rbv, (int)min((u32)(K), last)); \
+          if (ABL >= 3) { Sa[SLOT] = U[USLOT].y; Sb[SLOT] = U[USLOT].w; }                                                     \
+          else { Sa[SLOT] = (unsigned long long)sb_[U[USLOT].y >> RSH]; Sb[SLOT] = (unsigned long long)sb_[U[USLOT].w >> RSH]; } }
+#define Q_EAT(E, SA, SB) {                                                                                                   \
+          if (ABL == 2 || ABL == 4) { sink += (E).x + (E).z + (SA) + (SB); } else {                                           \
+          atomicAdd(&sG[(E).x & CM], SA); atomicAdd(&sG[((E).x >> CB) & CM], SA);                                            \
+          atomicAdd(&sG[__builtin_amdgcn_alignbit((E).y, (E).x, 2 * CB) & CM], SA); atomicAdd(&sG[((E).y >> (3 * CB - 32)) & CM], SA); \
+          atomicAdd(&sG[(E).z & CM], SB); atomicAdd(&sG[((E).z >> CB) & CM], SB);                                            \
+          atomicAdd(&sG[__builtin_amdgcn_alignbit((E).w, (E).z, 2 * CB) & CM], SB); atomicAdd(&sG[((E).w >> (3 * CB - 32)) & CM], SB); } }
+      // the prologue issues its loads in the order the steps -A .. -1 of the loop would have: the wait-count pass then
+      // sees the same queue on the loop's entry and on its back edge (it merges the two, and a merge of unlike queues
+      // waits for nearly everything at the top of every L-th step)
+#pragma unroll
+      for (int j = -A; j < 0; j++) {
+        if (j + B >= 0) { Q_LOADS((j + B) % NS, (j + B) % NU, (u32)(j + B)); __builtin_amdgcn_sched_barrier(0); }
+        Q_LOADU((j + A) % NU, (u32)(j + A));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (u32 k0 = 0; k0 < nb; k0 += (u32)L) {
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+          const u32 k = k0 + (u32)j;
+          Q_LOADS((j + B) % NS, (j + B) % NU, k + (u32)B);
+          __builtin_amdgcn_sched_barrier(0);
+          Q_LOADU((j + A) % NU, k + (u32)A);
+          __builtin_amdgcn_sched_barrier(0);
+          if (k < nb) Q_EAT(U[j % NU], Sa[j % NS], Sb[j % NS]);      // wave-uniform; a step past the end holds zeros
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#undef Q_EAT
+#undef Q_LOADS
+#undef Q_LOADU
+    }
+    __syncthreads();
+    i64* out = part + (size_t)p * PD;
+    if (ABL == 2 || ABL == 4) sG[tid] += sink;
+    if (ABL == 1) { if (sG[tid] == 0x1234567ull) out[tid] = 1; }
+    else for (u32 i = tid; i < PD; i += 1024) out[i] = (i64)sG[i];
+  }
+}
+
+template <int CB, bool NT, int A, int B, int ABL = 0>
+static int launch_sweep_q64(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+  const size_t lds_bytes = (size_t)8 << CB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_q64<CB, NT, A, B, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done = true;
+  }
+  hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, ABL>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+                        (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)mat->t_piece,
+                        (const uint4*)mat->t_wgpiece, S, part);
+  return KLR_OK;
+}
+
+// pipeline depth by the number of workgroups the ingest cut the stream for (one or two per CU)
+template <int CB, bool NT, int ABL = 0>
+static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+  if ((int)mat->nwg <= ctx->n_cu) return launch_sweep_q64<CB, NT, 7, 3, ABL>(ctx, mat, S, part, e0, e1);
+  return launch_sweep_q64<CB, NT, 3, 1, ABL>(ctx, mat, S, part, e0, e1);
+}
+
 template <int THREADS, int UNROLL, bool NT, int ABL = 0, int FMT = FMT_U32>
 static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds_bytes = (size_t)TILE_DIM * 16;
@@ -615,61 +761,92 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
   return KLR_OK;
 }
 
-// variant switch for in-process A/B timing (tools/ab_sweep.py); 0 = the shipped configuration
+// Kernel of the shipped configuration per entry format.  The in-process A/B variants and the timing-only ablations
+// (which give wrong results by construction) exist only in a build with -DKLR_ABLATIONS (tools/ab_sweep.py).
+#ifdef KLR_ABLATIONS
 static int g_coo_variant = -1;
-static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
+static int dispatch_ablation(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1, bool* done) {
   if (g_coo_variant < 0) { const char* e = getenv("KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
+  *done = true;
+  if (mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13) {
+    const char* e = getenv("KLR_Q64_ABL");
+    const int abl = e ? atoi(e) : 0;
+    const bool c13 = mat->fmt == FMT_Q64C13;
+    switch (abl) {
+      case 1: return c13 ? launch_sweep_q64_by_grid<13, true, 1>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 1>(ctx, mat, S, part, e0, e1);
+      case 2: return c13 ? launch_sweep_q64_by_grid<13, true, 2>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 2>(ctx, mat, S, part, e0, e1);
+      case 3: return c13 ? launch_sweep_q64_by_grid<13, true, 3>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 3>(ctx, mat, S, part, e0, e1);
+      case 4: return c13 ? launch_sweep_q64_by_grid<13, true, 4>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 4>(ctx, mat, S, part, e0, e1);
+      default: break;
+    }
+    *done = false;
+    return KLR_OK;
+  }
   if (mat->fmt == FMT_R64) {
     switch (g_coo_variant) {
       case 26: return launch_sweep_coo<1024, 2, true, 3, FMT_R64>(ctx, mat, S, part, e0, e1);   // stream only
       case 14: return launch_sweep_coo<1024, 2, false, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
       case 13: return launch_sweep_coo<512, 2, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
       case 12: return launch_sweep_coo<1024, 1, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);   // no prefetch
-      default:
-        // shipped: 32 waves/CU, ping-pong prefetch.  A stream that fits the 256 MiB Infinity Cache together with the
-        // piece vectors is read with plain loads and stays resident from one sweep to the next (every leapfrog epoch
-        // sweeps the same matrix; measured 45.1 us against 48.7 us at configs[2]); larger ones stream non-temporally.
-        // The prefetch loop runs a uniform, even number of trips per tile with masked lanes: only worth it for long
-        // tiles (a 1M-column shard has ~2.6 trips per tile: 116 us with it, 103 us without).
-        if (mat->total4 < (i64)8192 * mat->nrt * mat->nct) return launch_sweep_coo<1024, 1, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
-        if ((size_t)mat->total4 * 16 <= ((size_t)220 << 20)) return launch_sweep_coo<1024, 2, false, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
-        return launch_sweep_coo<1024, 2, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+      default: break;
     }
-  }
-  if (mat->fmt == FMT_U24) {
+  } else if (mat->fmt == FMT_U24) {
     switch (g_coo_variant) {
       case 26: return launch_sweep_coo<1024, 1, true, 3, FMT_U24>(ctx, mat, S, part, e0, e1);   // stream only
       case 14: return launch_sweep_coo<1024, 1, false, 0, FMT_U24>(ctx, mat, S, part, e0, e1);
       case 13: return launch_sweep_coo<512, 1, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);
       case 12: return launch_sweep_coo<1024, 1, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);   // one load per trip, no prefetch
-      default: return launch_sweep_coo<1024, 2, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);   // shipped: 32 waves/CU, nt loads, ping-pong prefetch
+      default: break;
+    }
+  } else if (mat->fmt == FMT_U32) {
+    switch (g_coo_variant) {
+      case 1:  return launch_sweep_coo<512, 4, true>(ctx, mat, S, part, e0, e1);
+      case 2:  return launch_sweep_coo<512, 8, false>(ctx, mat, S, part, e0, e1);
+      case 4:  return launch_sweep_coo<1024, 4, false>(ctx, mat, S, part, e0, e1);
+      case 6:  return launch_sweep_coo<1024, 2, false>(ctx, mat, S, part, e0, e1);
+      case 8:  return launch_sweep_coo<512, 4, true, 1>(ctx, mat, S, part, e0, e1);     // ablation: no atomics
+      case 9:  return launch_sweep_coo<512, 4, true, 2>(ctx, mat, S, part, e0, e1);     // ablation: no s gather
+      case 11: return launch_sweep_coo<1024, 2, true>(ctx, mat, S, part, e0, e1);
+      case 13: return launch_sweep_coo<512, 1, true>(ctx, mat, S, part, e0, e1);
+      case 14: return launch_sweep_coo<1024, 1, false>(ctx, mat, S, part, e0, e1);
+      case 21: return launch_sweep_coo<1024, 1, true, 1>(ctx, mat, S, part, e0, e1);     // ablations of the shipped shape: no atomics
+      case 22: return launch_sweep_coo<1024, 1, true, 2>(ctx, mat, S, part, e0, e1);     //   no s gather
+      case 26: return launch_sweep_coo<1024, 1, true, 3>(ctx, mat, S, part, e0, e1);     //   stream only
+      case 50: return launch_sweep_coo<1024, 1, true, 4>(ctx, mat, S, part, e0, e1);     //   no multiply
+      default: break;
     }
   }
-  switch (g_coo_variant) {
-    case 1:  return launch_sweep_coo<512, 4, true>(ctx, mat, S, part, e0, e1);
-    case 2:  return launch_sweep_coo<512, 8, false>(ctx, mat, S, part, e0, e1);
-    case 3:  return launch_sweep_coo<512, 8, true>(ctx, mat, S, part, e0, e1);
-    case 4:  return launch_sweep_coo<1024, 4, false>(ctx, mat, S, part, e0, e1);
-    case 5:  return launch_sweep_coo<1024, 4, true>(ctx, mat, S, part, e0, e1);
-    case 6:  return launch_sweep_coo<1024, 2, false>(ctx, mat, S, part, e0, e1);
-    case 7:  return launch_sweep_coo<256, 8, false>(ctx, mat, S, part, e0, e1);
-    case 8:  return launch_sweep_coo<512, 4, true, 1>(ctx, mat, S, part, e0, e1);     // ablation: no atomics
-    case 9:  return launch_sweep_coo<512, 4, true, 2>(ctx, mat, S, part, e0, e1);     // ablation: no s gather
-    case 10: return launch_sweep_coo<512, 2, true>(ctx, mat, S, part, e0, e1);
-    case 11: return launch_sweep_coo<1024, 2, true>(ctx, mat, S, part, e0, e1);
-    case 12: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part, e0, e1);
-    case 13: return launch_sweep_coo<512, 1, true>(ctx, mat, S, part, e0, e1);
-    case 14: return launch_sweep_coo<1024, 1, false>(ctx, mat, S, part, e0, e1);
-    case 15: return launch_sweep_coo<768, 1, true>(ctx, mat, S, part, e0, e1);
-    case 16: return launch_sweep_coo<512, 4, false>(ctx, mat, S, part, e0, e1);
-    case 21: return launch_sweep_coo<1024, 1, true, 1>(ctx, mat, S, part, e0, e1);     // ablations of the shipped shape: no atomics
-    case 22: return launch_sweep_coo<1024, 1, true, 2>(ctx, mat, S, part, e0, e1);     //   no s gather
-    case 26: return launch_sweep_coo<1024, 1, true, 3>(ctx, mat, S, part, e0, e1);     //   stream only
-    case 50: return launch_sweep_coo<1024, 1, true, 4>(ctx, mat, S, part, e0, e1);     //   no multiply
-    default: return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part, e0, e1);      // shipped: 32 waves/CU, nt loads
+  *done = false;
+  return KLR_OK;
+}
+#endif
+
+static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+#ifdef KLR_ABLATIONS
+  { bool done; const int rc = dispatch_ablation(ctx, mat, S, part, e0, e1, &done); if (done) return rc; }
+#endif
+  // The stream is read with non-temporal loads whatever its size.  A stream that fits the 256 MiB Infinity Cache would
+  // stay resident from sweep to sweep under plain loads (configs[2]: 45.7 us back to back against 47.7), but a plain
+  // stream that has to come from HBM takes 66 us (it is installed in the Infinity Cache on its way) against 49 us
+  // non-temporal, and inside a whole leapfrog run -- sub-select and reduced solve between two sweeps -- the plain kernel
+  // averaged 48.9 us: no better than non-temporal, with a 35 % cliff behind it (profiles/README.md, round 2).
+  // KLR_STREAM_NT=0 reads it with plain loads (A/B tooling).
+  bool fits_mall = false;
+  if (const char* e = getenv("KLR_STREAM_NT")) fits_mall = atoi(e) == 0 && (size_t)mat->total4 * 16 <= ((size_t)220 << 20);
+  switch (mat->fmt) {
+    case FMT_Q64C12: return fits_mall ? launch_sweep_q64_by_grid<12, false>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true>(ctx, mat, S, part, e0, e1);
+    case FMT_Q64C13: return fits_mall ? launch_sweep_q64_by_grid<13, false>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<13, true>(ctx, mat, S, part, e0, e1);
+    case FMT_R64:
+      // 32 waves/CU, ping-pong prefetch.  The prefetch loop runs a uniform, even number of trips per tile with masked
+      // lanes: only worth it for long tiles (a 1M-column shard has ~2.6 trips per tile: 116 us with it, 103 us without)
+      if (mat->total4 < (i64)8192 * mat->nrt * mat->nct) return launch_sweep_coo<1024, 1, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+      if (fits_mall) return launch_sweep_coo<1024, 2, false, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+      return launch_sweep_coo<1024, 2, true, 0, FMT_R64>(ctx, mat, S, part, e0, e1);
+    case FMT_U24: return launch_sweep_coo<1024, 2, true, 0, FMT_U24>(ctx, mat, S, part, e0, e1);   // nt loads, ping-pong prefetch
+    default:      return launch_sweep_coo<1024, 1, true>(ctx, mat, S, part, e0, e1);             // nt loads
   }
 }
-extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
 
 // ibuf layout (int64): [0, dim) column sums (slot 0 unused) | dim: bias hi | dim+1: bias lo |
 //                      dim+2: loss limb0 | dim+3: loss limb1 | dim+4: non-finite loss terms
@@ -681,7 +858,7 @@ extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
 template <bool FUSE>
 __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
                                                      const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
-                                                     const i64* __restrict__ rowblk, i64 nrowblk, u32 CT,
+                                                     const i64* __restrict__ rowblk, i64 nrowblk, u32 CT, u32 PSTRIDE,
                                                      double inv_scale, double* __restrict__ g, u64* __restrict__ keys,
                                                      u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
   __shared__ i64 sh[4][256];
@@ -729,7 +906,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
 #pragma unroll
       for (int u = 0; u < 8; u++) p[u] = (k + 4u * u < k1) ? ctlist[k + 4u * u] : 0xFFFFFFFFu;
 #pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = (p[u] != 0xFFFFFFFFu) ? part[(i64)p[u] * TILE_DIM + c] : 0;
+      for (int u = 0; u < 8; u++) a[u] = (p[u] != 0xFFFFFFFFu) ? part[(i64)p[u] * PSTRIDE + c] : 0;
       v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
   }
@@ -898,7 +1075,8 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   i64 *S, *part, *ibuf;
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
   KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
-  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * TILE_DIM * 8, (void**)&part));
+  const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;      // width of a piece vector
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * pstride * 8, (void**)&part));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof_on) {
     KLR_HIP(ctx, hipEventCreate(&e0));
@@ -910,10 +1088,10 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   if (!ctx->ar_fn) {
     // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
     hipLaunchKernelGGL(k_finish_coo<true>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
+                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
   } else {
     hipLaunchKernelGGL(k_finish_coo<false>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr);
+                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr);
     KLR_HIP(ctx, hipGetLastError());
     KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
     hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,

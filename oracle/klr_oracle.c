@@ -162,6 +162,7 @@ int klo_gradient_mt(const klo_csr* x, const uint8_t* labels, const double* theta
       for (int64_t j = 0; j < q; j++) gl[ci[j]] += w * cv[j];
     }
   }
+#pragma omp parallel for num_threads(threads) schedule(static)
   for (int64_t j = 0; j < dim; j++) {
     double v = 0.0;
     for (int t = 0; t < threads; t++) v += gt[(size_t)t * (size_t)dim + (size_t)j];

@@ -116,7 +116,9 @@ def test_from_csr_device_route_equals_host_route(ctx, monkeypatch):
     monkeypatch.setenv("KLR_HOST_INGEST", "1")
     mh = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, v, labels)
     monkeypatch.delenv("KLR_HOST_INGEST")
-    assert md.layout() == mh.layout() and md.layout()["tiled"]
+    # the device route builds the row-streamed q64 stream, the host route the tiled formats: different packings of the
+    # same integers -- the sweep must agree bit for bit
+    assert md.layout()["tiled"] and mh.layout()["tiled"] and md.layout()["format"].startswith("q64")
     for a, b in zip(md.to_csr(), mh.to_csr()):
         np.testing.assert_array_equal(a, b)
     cw = md.class_weights()
@@ -152,7 +154,7 @@ def test_large_device_ingest_equals_host_ingest(ctx, host_ingest):
     np.testing.assert_array_equal(val[:x.nnz], x.val)
     assert val.max() > 255
     mh = K.Matrix.from_csr(ctx, md.n, md.dim, rp, col, val, labels)
-    assert md.layout() == mh.layout() and md.layout()["tiled"]
+    assert md.layout()["tiled"] and mh.layout()["tiled"]
     cw = md.class_weights()
     rd = K.sweep_select(ctx, md, None, None, np.zeros(1), cw, 10, want_g=True)
     rh = K.sweep_select(ctx, mh, None, None, np.zeros(1), cw, 10, want_g=True)

@@ -343,7 +343,7 @@ def synth_tiled():
     return x, labels
 
 
-@pytest.fixture(params=["r64", "u24", "u32"])
+@pytest.fixture(params=["q64c12", "q64c13", "r64", "u24", "u32"])
 def entry_format(request, monkeypatch):
     # the packings of the tiled stream: 8-byte quads (row | 4 columns) / 3-byte unit entries / 4-byte entries with a count
     monkeypatch.setenv("KLR_ENTRY_FORMAT", request.param)
@@ -354,8 +354,12 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled, entry_format):
     x, labels = synth_tiled
     m = upload(ctx, x, labels)
     lay = m.layout()
-    assert lay["tiled"] and 0 < lay["tile_rows"] <= 4094 and lay["tile_rows"] % 2 == 0
-    assert lay["value_bytes"] == {"r64": -1, "u24": 0, "u32": 1}[entry_format]
+    assert lay["tiled"] and lay["format"] == entry_format
+    if entry_format.startswith("q64"):
+        assert lay["tile_rows"] == x.n                   # row-streamed: strips only, no row tiles
+    else:
+        assert 0 < lay["tile_rows"] <= 4094 and lay["tile_rows"] % 2 == 0
+    assert lay["value_bytes"] == {"q64c12": -1, "q64c13": -1, "r64": -1, "u24": 0, "u32": 1}[entry_format]
     cw = O.class_weights(labels)
     rng = np.random.default_rng(1)
     for k in (0, 40):

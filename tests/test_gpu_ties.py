@@ -105,7 +105,7 @@ def test_tie_contract_whole_path(ctx):
     red = mat.select_columns(cl["cols"])
     g = K.gradient_dense(ctx, red, cl["theta"], (1.0, 1.0))
     nz = cl["theta"][1:] != 0
-    assert abs(g[0]) < 1e-5 and np.max(np.abs(np.abs(g[1:][nz]) - cl["lam"])) < 2e-3 * cl["lam"]
+    assert abs(g[0]) < 1e-4 and np.max(np.abs(np.abs(g[1:][nz]) - cl["lam"])) < 2e-3 * cl["lam"]
     cl2, ep2 = run()
     np.testing.assert_array_equal(cl2["cols"], cl["cols"]); np.testing.assert_array_equal(cl2["theta"], cl["theta"])
     assert ep2 == ep
