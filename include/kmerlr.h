@@ -83,6 +83,37 @@ int  klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int64_t* rowpt
  * other character are skipped).  CSR, CSC and the tiled stream are all built on the device. */
 int  klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int64_t* seq_off, int64_t n, int M, int N,
                             int revcomp, int binarize, const uint8_t* labels, int64_t n_total, klr_mat** out);
+/* k-mer equivalence classes: the counterpart of gonetics' KmerEquivalenceRelation / KmerCounter as the reference
+ * builds them -- NewKmerCounter(M, N, complement, reverse, revcomp, maxAmbiguous, alphabet), kmerLr_learn.go:94,
+ * kmerLr_features.go:204 (the module itself is not in the reference tree; semantics pinned by TestKmers1,
+ * kmerLr_test.go:30-66).  A class is the orbit of a k-mer under the enabled operations; with the gapped alphabet a
+ * k-mer may hold the gap letter 'n' (matches any nucleotide) at inner positions, at most max_ambiguous of them
+ * (-1: no bound; one value, or one per length M..N).  Columns: lengths ascending, inside a length by the code of the
+ * canonical member (a < c < g < t < n); class c is column c + 1 of the matrix.  Names are the members joined by '|'
+ * ("kmer|revcomp").  klr_kmer_class_find takes any member as text (upper or lower case; anything after a '|' is
+ * ignored, like KmerLrFeatures.ImportConfig, kmerLr_features.go:207-209) and returns the 0-based class or -1. */
+#define KLR_ALPHABET_NUCLEOTIDE 0
+#define KLR_ALPHABET_GAPPED     1    /* "gapped-nucleotide" */
+#define KLR_KMER_MAX_LEN        12
+#define KLR_KMER_INVALID        0xFFFFFFFFu
+typedef struct {
+  int M, N;
+  int complement, reverse, revcomp;
+  int alphabet;
+  int n_max_ambiguous;          /* 0 (no bound), 1, or N - M + 1 */
+  const int* max_ambiguous;
+} klr_kmer_spec;
+typedef struct klr_kmer_classes klr_kmer_classes;
+int     klr_kmer_classes_create(const klr_kmer_spec* spec, klr_kmer_classes** out, char* errbuf, int64_t errcap);
+void    klr_kmer_classes_destroy(klr_kmer_classes* kc);
+int64_t klr_kmer_classes_count(const klr_kmer_classes* kc);
+int     klr_kmer_class_name(const klr_kmer_classes* kc, int64_t cls, char* buf, int64_t cap);
+int64_t klr_kmer_class_find(const klr_kmer_classes* kc, const char* kmer);
+/* klr_mat_from_sequences for any class list (complement / reverse / revcomp, gapped alphabet, max-ambiguous):
+ * every window of length k = M..N is counted once in the class of every k-mer of the alphabet it matches. */
+int  klr_mat_from_sequences_classes(klr_ctx* ctx, const char* seqs, const int64_t* seq_off, int64_t n,
+                                    const klr_kmer_classes* classes, int binarize, const uint8_t* labels,
+                                    int64_t n_total, klr_mat** out);
 void klr_mat_destroy(klr_mat* mat);
 int  klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total);
 /* how the matrix sits in HBM for the full-width sweep: tiled = 1 when the packed integer stream (count data; 2, 3 or

@@ -154,8 +154,25 @@ int  klr_estimator_save_model_pairs(const klr_estimator* est, int64_t i, const c
 int  klr_estimator_save_trace(const klr_estimator* est, const char* filename);
 /* RegularizationPath.Export (kmerLr_estimator_path.go:41-73): lambda norm theta,... */
 int  klr_estimator_save_path(const klr_estimator* est, const char* filename);
-/* model JSON of classifier i ("scoresLr" / "kmerLr" ConfigDistribution; schema parity unpinned, see
- * DESIGN.md): names may be NULL; index_base0[k] = 0-based feature id of selected column k+1 */
+/* model JSON of classifier i: a ConfigDistribution {Name, Parameters, Distributions} (kmerLr_io.go:105-112).
+ * Distributions = one "vector:logistic regression" per member, then "transform" {Offset, Scale}
+ * (kmerLr_classifier_ensemble.go:416-424, kmerLr_transform.go:646-648).  Parameters:
+ *   type "scoresLr":  {Cooccurrence, Features, Index, Names}                         (scoresLr_feature.go:72-86)
+ *   type "kmerLr" after klr_estimator_set_kmer_features: the reference's KmerLrFeatures export
+ *                     {M, N, Binarize, Complement, Cooccurrence, Reverse, Revcomp, MaxAmbiguous, Alphabet, Kmers,
+ *                      Features} in that order (kmerLr_features.go:222-250); Kmers = the class strings
+ *                     ("kmer|revcomp") of the model's features, Features = pairs of positions in Kmers -- the file
+ *                     `loss` / `predict` rebuild their k-mer counter from (kmerLr_loss.go:53-57).
+ * names: one string per feature of the data (class strings for kmerLr) or NULL.  A model with a non-finite
+ * coefficient is refused (KLR_EINVAL): NaN is not JSON (Go's encoder fails the same way). */
+typedef struct {
+  int M, N;
+  int binarize, complement, reverse, revcomp;
+  int n_max_ambiguous;              /* entries of max_ambiguous (the reference's default --max-ambiguous=-1 gives [-1]) */
+  const int* max_ambiguous;
+  const char* alphabet;             /* "nucleotide alphabet", "gapped nucleotide alphabet" (Alphabet.String()) */
+} klr_kmer_features;
+int  klr_estimator_set_kmer_features(klr_estimator* est, const klr_kmer_features* kf);
 int  klr_estimator_save_model(const klr_estimator* est, int64_t i, const char* filename, const char* type_name,
                               const char* const* names);
 

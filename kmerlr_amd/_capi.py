@@ -37,6 +37,12 @@ SIGNATURES = {
     "klr_allreduce_time": (_int, [_vp, _i64, _int, _int, C.POINTER(_dbl)]),
     "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
     "klr_mat_from_sequences": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _i64, _PVP]),
+    "klr_kmer_classes_create": (_int, [_vp, _PVP, _vp, _i64]),
+    "klr_kmer_classes_destroy": (None, [_vp]),
+    "klr_kmer_classes_count": (_i64, [_vp]),
+    "klr_kmer_class_name": (_int, [_vp, _i64, _vp, _i64]),
+    "klr_kmer_class_find": (_i64, [_vp, C.c_char_p]),
+    "klr_mat_from_sequences_classes": (_int, [_vp, _vp, _vp, _i64, _vp, _int, _vp, _i64, _PVP]),
     "klr_mat_destroy": (None, [_vp]),
     "klr_mat_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "klr_mat_layout": (_int, [_vp, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
@@ -185,6 +191,49 @@ def rccl_unique_id():
     return buf.raw
 
 
+ALPHABETS = {"nucleotide": 0, "gapped-nucleotide": 1}
+
+
+class KmerClasses:
+    """klr_kmer_classes: the k-mer equivalence classes of a counter (NewKmerCounter's arguments, kmerLr_learn.go:94)."""
+
+    def __init__(self, M, N, revcomp=False, reverse=False, complement=False, alphabet="nucleotide", max_ambiguous=None):
+        ma = None if max_ambiguous is None else (C.c_int * len(max_ambiguous))(*max_ambiguous)
+
+        class Spec(C.Structure):
+            _fields_ = [("M", C.c_int), ("N", C.c_int), ("complement", C.c_int), ("reverse", C.c_int), ("revcomp", C.c_int),
+                        ("alphabet", C.c_int), ("n_max_ambiguous", C.c_int), ("max_ambiguous", C.c_void_p)]
+        sp = Spec(M, N, int(complement), int(reverse), int(revcomp), ALPHABETS[alphabet], 0 if ma is None else len(max_ambiguous),
+                  None if ma is None else C.cast(ma, C.c_void_p))
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        if lib().klr_kmer_classes_create(C.byref(sp), C.byref(self._h), err, 256) != 0:
+            raise KlrError("klr_kmer_classes_create: %s" % err.value.decode())
+
+    def __len__(self):
+        return lib().klr_kmer_classes_count(self._h)
+
+    def name(self, cls):
+        buf = C.create_string_buffer(128)
+        if lib().klr_kmer_class_name(self._h, int(cls), buf, 128) != 0:
+            raise KlrError("no class %d" % cls)
+        return buf.value.decode()
+
+    def find(self, kmer):
+        return lib().klr_kmer_class_find(self._h, kmer.encode())
+
+    def close(self):
+        if self._h:
+            lib().klr_kmer_classes_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Matrix:
     """klr_mat: rows [row0,row0+n) of the data set, resident in HBM as CSR + padded CSC."""
 
@@ -205,14 +254,19 @@ class Matrix:
         return Matrix(ctx, h)
 
     @staticmethod
-    def from_sequences(ctx, seqs, labels, M, N, revcomp=False, binarize=False, n_total=0):
-        """seqs: list of str/bytes; k-mer counting and the whole matrix build run on the device."""
+    def from_sequences(ctx, seqs, labels, M=0, N=0, revcomp=False, binarize=False, n_total=0, classes=None):
+        """seqs: list of str/bytes; k-mer counting and the whole matrix build run on the device.  classes: a KmerClasses
+        (complement / reverse / gapped alphabet / max-ambiguous); otherwise plain or --revcomp classes of lengths M..N."""
         bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
         off = np.zeros(len(bs) + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(b) for b in bs])
         blob = b"".join(bs) or b"\0"
         labels = np.ascontiguousarray(labels, dtype=np.uint8)
         h = C.c_void_p()
+        if classes is not None:
+            ctx.check(lib().klr_mat_from_sequences_classes(ctx._h, C.c_char_p(blob), _p(off), len(bs), classes._h, int(binarize),
+                                                           _p(labels), n_total, C.byref(h)))
+            return Matrix(ctx, h)
         ctx.check(lib().klr_mat_from_sequences(ctx._h, C.c_char_p(blob), _p(off), len(bs), M, N, int(revcomp), int(binarize),
                                                _p(labels), n_total, C.byref(h)))
         return Matrix(ctx, h)

@@ -13,7 +13,7 @@ LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libkmerlr_hip.so")
 
 SOURCES = ["klr_ctx.hip", "klr_mat.hip", "klr_sweep.hip", "klr_select.hip", "klr_solve.hip",
-           "klr_synth.cpp", "klr_driver.cpp", "klr_ingest.hip"]
+           "klr_synth.cpp", "klr_driver.cpp", "klr_ingest.hip", "klr_kmers.cpp"]
 HEADERS = [os.path.join(CSRC, "klr_internal.h"), os.path.join(HERE, "..", "include", "kmerlr.h"),
            os.path.join(HERE, "..", "include", "kmerlr_driver.h")]
 

@@ -73,48 +73,54 @@ static void read_scores(const std::string& fn, bool header, uint8_t label, DataS
   say(1, "done\n");
 }
 
-// ---- k-mer classes: names on the host; the counting itself runs on the device (klr_mat_from_sequences) ---
-// Column ids: for k = M..N in turn, the base-4 value of the k-mer (a=0,c=1,g=2,t=3), upper/lower case
-// folded, windows containing any other character skipped; --revcomp merges a k-mer with its reverse
-// complement (class id = the smaller of the two codes, classes renumbered densely per k); --binarize
-// stores 1 for every present class.  gonetics' own class order is not verifiable offline.
-struct KmerSpec { int M = 0, N = 0; bool revcomp = false, binarize = false; std::vector<std::vector<int64_t>> cls; std::vector<int64_t> base; int64_t m = 0; };
+// ---- k-mer classes (klr_kmer_classes: NewKmerCounter's arguments, kmerLr_learn.go:94,116-122,193-214); the counting
+// itself runs on the device (klr_mat_from_sequences_classes)
+struct KmerSpec {
+  int M = 0, N = 0;
+  bool revcomp = false, reverse = false, complement = false, binarize = false;
+  std::string alphabet = "nucleotide";          // nucleotide | gapped-nucleotide  (Alphabet.String(): "<name> alphabet")
+  std::vector<int> max_ambiguous{-1};           // --max-ambiguous: one value or one per length
+  klr_kmer_classes* kc = nullptr;
+  int64_t m = 0;
+};
 
-static int64_t revcomp_code(int64_t c, int k) {
-  int64_t r = 0;
-  for (int i = 0; i < k; i++) { r = (r << 2) | (3 - (c & 3)); c >>= 2; }
-  return r;
+// alphabet_from_string (kmerLr_features.go:254-270): lower case, '-' -> ' ', optional " alphabet" suffix
+static std::string alphabet_key(std::string a) {
+  for (auto& c : a) { c = (char)tolower((unsigned char)c); if (c == '-') c = ' '; }
+  const std::string suf = " alphabet";
+  if (a.size() < suf.size() || a.compare(a.size() - suf.size(), suf.size(), suf) != 0) a += suf;
+  return a;
 }
 
 static void kmer_prepare(KmerSpec& s, std::vector<std::string>* names) {
-  s.cls.clear(); s.base.clear(); s.m = 0;
-  static const char L[] = "acgt";
-  for (int k = s.M; k <= s.N; k++) {
-    const int64_t n = (int64_t)1 << (2 * k);
-    std::vector<int64_t> map((size_t)n, -1);
-    int64_t next = 0;
-    for (int64_t c = 0; c < n; c++) {
-      int64_t rep = c;
-      if (s.revcomp) rep = std::min(c, revcomp_code(c, k));
-      if (map[(size_t)rep] < 0) {
-        map[(size_t)rep] = next++;
-        if (names) {
-          std::string nm((size_t)k, 'a');
-          for (int i = 0; i < k; i++) nm[(size_t)(k - 1 - i)] = L[(rep >> (2 * i)) & 3];
-          if (s.revcomp && revcomp_code(rep, k) != rep) {
-            std::string rc((size_t)k, 'a'); const int64_t r2 = revcomp_code(rep, k);
-            for (int i = 0; i < k; i++) rc[(size_t)(k - 1 - i)] = L[(r2 >> (2 * i)) & 3];
-            nm += "|" + rc;
-          }
-          names->push_back(nm);
-        }
-      }
-      map[(size_t)c] = map[(size_t)rep];
-    }
-    s.base.push_back(s.m);
-    s.m += next;
-    s.cls.push_back(std::move(map));
+  klr_kmer_spec sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.M = s.M; sp.N = s.N; sp.complement = s.complement; sp.reverse = s.reverse; sp.revcomp = s.revcomp;
+  const std::string key = alphabet_key(s.alphabet);
+  if (key == "nucleotide alphabet") sp.alphabet = KLR_ALPHABET_NUCLEOTIDE;
+  else if (key == "gapped nucleotide alphabet") sp.alphabet = KLR_ALPHABET_GAPPED;
+  else if (key == "iupac nucleotide alphabet" || key == "ambiguous nucleotide alphabet") die("the iupac-nucleotide alphabet is not part of this build");
+  else die("invalid alphabet");
+  s.alphabet = key;
+  // a scalar -1 (the default) bounds nothing; other values go to the class tables
+  const bool unbounded = s.max_ambiguous.size() == 1 && s.max_ambiguous[0] < 0;
+  sp.n_max_ambiguous = unbounded ? 0 : (int)s.max_ambiguous.size();
+  sp.max_ambiguous = unbounded ? nullptr : s.max_ambiguous.data();
+  char eb[256] = "";
+  if (klr_kmer_classes_create(&sp, &s.kc, eb, sizeof(eb)) != 0) die("%s", eb);
+  s.m = klr_kmer_classes_count(s.kc);
+  if (names) {
+    names->clear();
+    char buf[128];
+    for (int64_t c = 0; c < s.m; c++) { klr_kmer_class_name(s.kc, c, buf, sizeof(buf)); names->push_back(buf); }
   }
+}
+
+static void parse_max_ambiguous(const std::string& v, int M, int N, std::vector<int>& out) {     // kmerLr_learn.go:205-214
+  out.clear();
+  std::stringstream ss(v); std::string t;
+  while (std::getline(ss, t, ',')) out.push_back(atoi(t.c_str()));
+  if (out.size() != 1 && (int)out.size() != N - M + 1) die("invalid option `--max-ambiguous'");
 }
 
 struct SeqSet { std::string blob; std::vector<int64_t> off{0}; std::vector<uint8_t> labels; };
@@ -142,8 +148,8 @@ static klr_mat* count_kmers(klr_ctx* ctx, const SeqSet& q, const KmerSpec& ks) {
   say(1, "Counting k-mers on the device... ");
   klr_mat* mat = nullptr;
   const std::string& blob = q.blob.empty() ? std::string("N") : q.blob;
-  if (klr_mat_from_sequences(ctx, blob.data(), q.off.data(), (int64_t)q.labels.size(), ks.M, ks.N, ks.revcomp ? 1 : 0,
-                             ks.binarize ? 1 : 0, q.labels.data(), 0, &mat) != KLR_OK)
+  if (klr_mat_from_sequences_classes(ctx, blob.data(), q.off.data(), (int64_t)q.labels.size(), ks.kc, ks.binarize ? 1 : 0,
+                                     q.labels.data(), 0, &mat) != KLR_OK)
     die("failed\n%s", klr_last_error(ctx));
   say(1, "done\n");
   return mat;
@@ -187,6 +193,75 @@ static std::vector<double> json_numbers_after(const std::string& s, const std::s
   return out;
 }
 
+// ---- the reference's KmerLrFeatures parameters in a model file (kmerLr_features.go:164-220) --------------------
+static size_t json_key(const std::string& s, const std::string& key, size_t from = 0) {
+  const size_t p = s.find("\"" + key + "\"", from);
+  return p == std::string::npos ? p : s.find(':', p) + 1;
+}
+static bool json_has(const std::string& s, const std::string& key) { return json_key(s, key) != std::string::npos; }
+static long json_int(const std::string& s, const std::string& key) {
+  const size_t p = json_key(s, key);
+  if (p == std::string::npos) die("invalid config file: missing %s", key.c_str());
+  return strtol(s.c_str() + p, nullptr, 10);
+}
+static bool json_bool(const std::string& s, const std::string& key, bool def, bool required) {
+  const size_t p = json_key(s, key);
+  if (p == std::string::npos) { if (required) die("invalid config file: missing %s", key.c_str()); return def; }
+  size_t q = p; while (q < s.size() && isspace((unsigned char)s[q])) q++;
+  return s.compare(q, 4, "true") == 0;
+}
+static std::string json_string(const std::string& s, const std::string& key) {
+  const size_t p = json_key(s, key);
+  if (p == std::string::npos) die("invalid config file: missing %s", key.c_str());
+  const size_t q0 = s.find('"', p), q1 = s.find('"', q0 + 1);
+  return s.substr(q0 + 1, q1 - q0 - 1);
+}
+static std::vector<std::string> json_strings(const std::string& s, const std::string& key) {
+  std::vector<std::string> out;
+  size_t p = json_key(s, key);
+  if (p == std::string::npos) die("invalid config file: missing %s", key.c_str());
+  p = s.find('[', p);
+  const size_t e = s.find(']', p);
+  for (size_t q = s.find('"', p); q != std::string::npos && q < e; ) {
+    const size_t q1 = s.find('"', q + 1);
+    out.push_back(s.substr(q + 1, q1 - q - 1));
+    q = s.find('"', q1 + 1);
+  }
+  return out;
+}
+static std::vector<int> json_ints_or_null(const std::string& s, const std::string& key) {
+  std::vector<int> out;
+  size_t p = json_key(s, key);
+  if (p == std::string::npos) die("invalid config file: missing %s", key.c_str());
+  while (p < s.size() && isspace((unsigned char)s[p])) p++;
+  if (s.compare(p, 4, "null") == 0) return out;
+  const size_t e = s.find(']', p);
+  std::string body = s.substr(p + 1, e - p - 1);
+  for (auto& c : body) if (c == ',') c = ' ';
+  std::stringstream ss(body); int v;
+  while (ss >> v) out.push_back(v);
+  return out;
+}
+
+// KmerLrFeatures.ImportConfig: the counter of a kmerLr model and the classes of its features
+static void kmer_spec_from_model(const std::string& js, KmerSpec& ks, std::vector<double>& index) {
+  ks.M = (int)json_int(js, "M"); ks.N = (int)json_int(js, "N");
+  ks.binarize = json_bool(js, "Binarize", false, true);
+  ks.complement = json_bool(js, "Complement", false, true);
+  ks.reverse = json_bool(js, "Reverse", false, true);
+  ks.revcomp = json_bool(js, "Revcomp", false, true);
+  ks.max_ambiguous = json_ints_or_null(js, "MaxAmbiguous");
+  if (ks.max_ambiguous.empty()) ks.max_ambiguous.push_back(-1);
+  ks.alphabet = json_string(js, "Alphabet");
+  kmer_prepare(ks, nullptr);
+  index.clear();
+  for (const std::string& k : json_strings(js, "Kmers")) {
+    const int64_t c = klr_kmer_class_find(ks.kc, k.c_str());         // rel.EquivalenceClass(strings.Split(str, "|")[0])
+    if (c < 0) die("invalid config file: `%s' is not a k-mer of the model's alphabet and lengths", k.c_str());
+    index.push_back((double)c);
+  }
+}
+
 // The data restricted to a model's features, transform applied (SelectData, kmerLr_classifier.go:125-147): plain
 // models select the Index columns; co-occurrence models (Cooccurrence = true) select them, write out the pair matrix
 // of that restriction and pick the columns of the Features pairs.  theta is permuted along if the columns need sorting.
@@ -205,9 +280,11 @@ static double summarize(const std::string& summary, const std::vector<double>& x
 
 // members: one coefficient vector per ensemble member (a single one for plain models); summary from "Name [summary]"
 static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& js, std::vector<std::vector<double>>& members,
-                           std::string& summary) {
+                           std::string& summary, const std::vector<double>* kmer_index = nullptr) {
   size_t pos = 0;
-  std::vector<double> index = json_numbers_after(js, "Index", 0, &pos);
+  // scoresLr models name their features by "Index"; kmerLr models by the class strings in "Kmers" (kmer_index: their
+  // columns in the counter rebuilt from the model)
+  std::vector<double> index = kmer_index ? *kmer_index : json_numbers_after(js, "Index", 0, &pos);
   const size_t dpos = js.find("\"Distributions\"");
   members.clear();
   summary.clear();
@@ -362,8 +439,11 @@ int main(int argc, char** argv) {
     } else {
       if (o.pos.size() != 5) die("usage: kmerlr learn [options] M N FG.fa BG.fa BASENAME");
       ks.M = atoi(o.pos[0].c_str()); ks.N = atoi(o.pos[1].c_str());
-      if (ks.M < 1 || ks.N < ks.M || ks.N > 12) die("invalid k-mer lengths");
+      if (ks.M < 1 || ks.N < ks.M) die("invalid k-mer lengths");
       ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+      ks.reverse = flag(o, "reverse"); ks.complement = flag(o, "complement");
+      ks.alphabet = opt(o, "alphabet", "nucleotide");
+      parse_max_ambiguous(opt(o, "max-ambiguous", "-1"), ks.M, ks.N, ks.max_ambiguous);
       kmer_prepare(ks, &d.names);
       read_fasta(o.pos[2], 1, sq);
       read_fasta(o.pos[3], 0, sq);
@@ -419,6 +499,15 @@ int main(int argc, char** argv) {
     fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), scale, offset);
     klr_estimator* est = nullptr;
     if (klr_estimator_create(&be, &cfg, &est) != KLR_OK) die("cannot create estimator");
+    if (!scores) {
+      // kmerLr models carry their counter (KmerLrFeatures.ExportConfig, kmerLr_features.go:222-250)
+      klr_kmer_features kf;
+      memset(&kf, 0, sizeof(kf));
+      kf.M = ks.M; kf.N = ks.N; kf.binarize = ks.binarize; kf.complement = ks.complement; kf.reverse = ks.reverse; kf.revcomp = ks.revcomp;
+      kf.n_max_ambiguous = (int)ks.max_ambiguous.size(); kf.max_ambiguous = ks.max_ambiguous.data();
+      kf.alphabet = ks.alphabet.c_str();
+      klr_estimator_set_kmer_features(est, &kf);
+    }
     std::vector<const char*> names;
     for (auto& s : d.names) names.push_back(s.c_str());
     if (kfold > 1) {
@@ -497,20 +586,20 @@ int main(int argc, char** argv) {
     const std::string js = buf.str();
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
+    std::vector<double> kindex;
     if (scores) {
       read_scores(o.pos[1], flag(o, "header"), 1, d); read_scores(o.pos[2], flag(o, "header"), 0, d);
       if (klr_mat_from_csr(ctx, (int64_t)d.labels.size(), d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
         die("%s", klr_last_error(ctx));
     } else {
+      // the counter comes from the model (kmerLr_loss.go:53-57)
       KmerSpec ks; SeqSet sq;
-      ks.M = atoi(opt(o, "m", "0").c_str()); ks.N = atoi(opt(o, "n", "0").c_str());
-      if (ks.M < 1) die("kmerlr loss --type=kmerLr needs --m=M --n=N (the k-mer lengths the model was trained with)");
-      ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+      kmer_spec_from_model(js, ks, kindex);
       read_fasta(o.pos[1], 1, sq); read_fasta(o.pos[2], 0, sq);
       mat = count_kmers(ctx, sq, ks);
     }
     std::vector<std::vector<double>> members; std::string summary;
-    red = model_data(ctx, mat, js, members, summary);
+    red = model_data(ctx, mat, js, members, summary, scores ? nullptr : &kindex);
     const double cw[2] = {1.0, 1.0};
     std::vector<double> lv;                                             // {Kmer,Scores}LrEnsemble.Loss: summary of the members' losses
     for (auto& th : members) {
@@ -529,6 +618,7 @@ int main(int argc, char** argv) {
     const std::string js = buf.str();
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
+    std::vector<double> kindex;
     int64_t n = 0;
     if (scores) {
       read_scores(o.pos[1], flag(o, "header"), 0, d);
@@ -537,15 +627,13 @@ int main(int argc, char** argv) {
         die("%s", klr_last_error(ctx));
     } else {
       KmerSpec ks; SeqSet sq;
-      ks.M = atoi(opt(o, "m", "0").c_str()); ks.N = atoi(opt(o, "n", "0").c_str());
-      if (ks.M < 1) die("kmerlr predict --type=kmerLr needs --m=M --n=N (the k-mer lengths the model was trained with)");
-      ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+      kmer_spec_from_model(js, ks, kindex);
       read_fasta(o.pos[1], 0, sq);
       n = (int64_t)sq.labels.size();
       mat = count_kmers(ctx, sq, ks);
     }
     std::vector<std::vector<double>> members; std::string summary;
-    red = model_data(ctx, mat, js, members, summary);
+    red = model_data(ctx, mat, js, members, summary, scores ? nullptr : &kindex);
     std::vector<double> out((size_t)std::max<int64_t>(n, 1));
     {
       // {Kmer,Scores}LrEnsemble.Predict (kmerLr_classifier_ensemble.go:124-137): summary of the members' LogPdf per row

@@ -68,6 +68,12 @@ struct klr_estimator {
   Path path;
   std::vector<double> ep_lambda;
   std::vector<int64_t> ep_nonzero;
+  // k-mer counter of the data (klr_estimator_set_kmer_features): kmerLr models are written with the reference's
+  // KmerLrFeatures parameters
+  bool has_kmer = false;
+  klr_kmer_features kf{};
+  std::vector<int> kf_max_amb;
+  std::string kf_alphabet;
 };
 
 static int fail(klr_estimator* e, int code, const char* fmt, ...) {
@@ -478,32 +484,98 @@ static void json_str(FILE* f, const char* s) {
   fputc('"', f);
 }
 
-// ConfigDistribution{Name, Parameters, Distributions} as written by ExportDistribution
-// (kmerLr_io.go:105-112; scoresLr_classifier_ensemble.go:409-427, scoresLr_feature.go:72-86,
-// kmerLr_transform.go:646-648).  The third-party serialiser's exact key order / number format is
-// not available here: schema parity unpinned.
+extern "C" int klr_estimator_set_kmer_features(klr_estimator* e, const klr_kmer_features* kf) {
+  if (!e || !kf) return KLR_EINVAL;
+  e->kf = *kf;
+  e->kf_max_amb.assign(kf->max_ambiguous ? kf->max_ambiguous : nullptr, kf->max_ambiguous ? kf->max_ambiguous + kf->n_max_ambiguous : nullptr);
+  e->kf_alphabet = kf->alphabet ? kf->alphabet : "nucleotide alphabet";
+  e->kf.max_ambiguous = nullptr; e->kf.alphabet = nullptr;
+  e->has_kmer = true;
+  return KLR_OK;
+}
+
+static bool all_finite(const std::vector<double>& v) {
+  for (double x : v) if (!std::isfinite(x)) return false;
+  return true;
+}
+
+// "Name" and "Parameters" of a model file.  index = 0-based features of the data the model uses (ascending), features =
+// pairs of positions in index (equal for a single feature), names = one string per feature of the DATA (nullable).
+// ConfigDistribution{Name, Parameters, Distributions} as written by ExportDistribution (kmerLr_io.go:105-112): field
+// order of Parameters as the exporting Go structs declare them (encoding/json keeps declaration order) --
+// kmerLr_features.go:222-235 for kmerLr, scoresLr_feature.go:72-80 for scoresLr.  The envelope itself comes from the
+// absent autodiff module: its exact spelling is unpinned.
+static void write_head(FILE* f, const klr_estimator* e, const std::string& name, bool cooccurrence, const std::vector<int64_t>& index,
+                       const std::vector<std::pair<size_t, size_t>>& features, const char* const* names) {
+  const bool kmer = e->has_kmer && name.compare(0, 6, "kmerLr") == 0;
+  fprintf(f, "{\n  \"Name\": ");
+  json_str(f, name.c_str());
+  fprintf(f, ",\n  \"Parameters\": {\n");
+  auto put_features = [&]() {
+    fprintf(f, "    \"Features\": [");
+    for (size_t k = 0; k < features.size(); k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", features[k].first, features[k].second);
+    fprintf(f, "]");
+  };
+  auto put_names = [&](const char* key) {
+    fprintf(f, "    \"%s\": [", key);
+    if (names) for (size_t k = 0; k < index.size(); k++) { if (k) fputc(',', f); json_str(f, names[index[k]]); }
+    fprintf(f, "]");
+  };
+  if (kmer) {
+    const klr_kmer_features& kf = e->kf;
+    fprintf(f, "    \"M\": %d,\n    \"N\": %d,\n    \"Binarize\": %s,\n    \"Complement\": %s,\n    \"Cooccurrence\": %s,\n"
+               "    \"Reverse\": %s,\n    \"Revcomp\": %s,\n    \"MaxAmbiguous\": ",
+            kf.M, kf.N, kf.binarize ? "true" : "false", kf.complement ? "true" : "false", cooccurrence ? "true" : "false",
+            kf.reverse ? "true" : "false", kf.revcomp ? "true" : "false");
+    if (e->kf_max_amb.empty()) fprintf(f, "null");
+    else { fputc('[', f); for (size_t k = 0; k < e->kf_max_amb.size(); k++) fprintf(f, "%s%d", k ? "," : "", e->kf_max_amb[k]); fputc(']', f); }
+    fprintf(f, ",\n    \"Alphabet\": ");
+    json_str(f, e->kf_alphabet.c_str());
+    fprintf(f, ",\n");
+    put_names("Kmers");
+    fprintf(f, ",\n");
+    put_features();
+    fprintf(f, "\n  },\n");
+    return;
+  }
+  fprintf(f, "    \"Cooccurrence\": %s,\n", cooccurrence ? "true" : "false");
+  put_features();
+  fprintf(f, ",\n    \"Index\": [");
+  for (size_t k = 0; k < index.size(); k++) fprintf(f, "%s%lld", k ? "," : "", (long long)index[k]);
+  fprintf(f, "],\n");
+  put_names("Names");
+  fprintf(f, "\n  },\n");
+}
+
+static void write_lr(FILE* f, const std::vector<double>& theta, bool last_comma) {
+  fprintf(f, "    {\"Name\": \"vector:logistic regression\", \"Parameters\": [");
+  for (size_t k = 0; k < theta.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", theta[k]);
+  fprintf(f, "], \"Distributions\": null}%s\n", last_comma ? "," : "");
+}
+
+static void write_transform_and_close(FILE* f, const std::vector<double>& offset, const std::vector<double>& scale) {
+  fprintf(f, "    {\"Name\": \"transform\", \"Parameters\": {\"Offset\": [");
+  for (size_t k = 0; k < offset.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", offset[k]);
+  fprintf(f, "], \"Scale\": [");
+  for (size_t k = 0; k < scale.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", scale[k]);
+  fprintf(f, "]}, \"Distributions\": null}\n  ]\n}\n");
+}
+
 extern "C" int klr_estimator_save_model(const klr_estimator* e, int64_t i, const char* filename, const char* type_name,
                                         const char* const* names) {
   if (!e || !filename || i < 0 || i >= (int64_t)e->out.size()) return KLR_EINVAL;
   const Classifier& c = e->out[(size_t)i];
+  if (!all_finite(c.theta) || !all_finite(c.scale) || !all_finite(c.offset)) return KLR_EINVAL;   // NaN is not JSON
   FILE* f = fopen(filename, "w");
   if (!f) return KLR_EINVAL;
   const size_t nf = c.cols.size() - 1;
-  fprintf(f, "{\n  \"Name\": ");
-  json_str(f, type_name ? type_name : "scoresLr");
-  fprintf(f, ",\n  \"Parameters\": {\n    \"Cooccurrence\": false,\n    \"Features\": [");
-  for (size_t k = 0; k < nf; k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", k, k);          // non-co-occurrence: [k,k]
-  fprintf(f, "],\n    \"Index\": [");
-  for (size_t k = 0; k < nf; k++) fprintf(f, "%s%lld", k ? "," : "", (long long)(c.cols[k + 1] - 1));
-  fprintf(f, "],\n    \"Names\": [");
-  if (names) for (size_t k = 0; k < nf; k++) { if (k) fputc(',', f); json_str(f, names[c.cols[k + 1] - 1]); }
-  fprintf(f, "]\n  },\n  \"Distributions\": [\n    {\"Name\": \"vector:logistic regression\", \"Parameters\": [");
-  for (size_t k = 0; k < c.theta.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.theta[k]);
-  fprintf(f, "], \"Distributions\": null},\n    {\"Name\": \"transform\", \"Parameters\": {\"Offset\": [");
-  for (size_t k = 0; k < c.offset.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.offset[k]);
-  fprintf(f, "], \"Scale\": [");
-  for (size_t k = 0; k < c.scale.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.scale[k]);
-  fprintf(f, "]}, \"Distributions\": null}\n  ]\n}\n");
+  std::vector<int64_t> index(nf);
+  std::vector<std::pair<size_t, size_t>> features(nf);
+  for (size_t k = 0; k < nf; k++) { index[k] = c.cols[k + 1] - 1; features[k] = {k, k}; }       // non-co-occurrence: [k,k]
+  write_head(f, e, type_name ? type_name : "scoresLr", false, index, features, names);
+  fprintf(f, "  \"Distributions\": [\n");
+  write_lr(f, c.theta, true);
+  write_transform_and_close(f, c.offset, c.scale);
   fclose(f);
   return KLR_OK;
 }
@@ -563,23 +635,15 @@ extern "C" int klr_estimator_save_model_pairs(const klr_estimator* e, int64_t i,
   std::sort(index.begin(), index.end());
   index.erase(std::unique(index.begin(), index.end()), index.end());
   auto pos = [&](int64_t f) { return (size_t)(std::lower_bound(index.begin(), index.end(), f) - index.begin()); };
+  if (!all_finite(c.theta) || !all_finite(c.scale) || !all_finite(c.offset)) return KLR_EINVAL;
   FILE* f = fopen(filename, "w");
   if (!f) return KLR_EINVAL;
-  fprintf(f, "{\n  \"Name\": ");
-  json_str(f, type_name ? type_name : "scoresLr");
-  fprintf(f, ",\n  \"Parameters\": {\n    \"Cooccurrence\": true,\n    \"Features\": [");
-  for (size_t k = 0; k < nf; k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", pos(pairs[2 * k]), pos(pairs[2 * k + 1]));
-  fprintf(f, "],\n    \"Index\": [");
-  for (size_t k = 0; k < index.size(); k++) fprintf(f, "%s%lld", k ? "," : "", (long long)index[k]);
-  fprintf(f, "],\n    \"Names\": [");
-  if (names) for (size_t k = 0; k < index.size(); k++) { if (k) fputc(',', f); json_str(f, names[index[k]]); }
-  fprintf(f, "]\n  },\n  \"Distributions\": [\n    {\"Name\": \"vector:logistic regression\", \"Parameters\": [");
-  for (size_t k = 0; k < c.theta.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.theta[k]);
-  fprintf(f, "], \"Distributions\": null},\n    {\"Name\": \"transform\", \"Parameters\": {\"Offset\": [");
-  for (size_t k = 0; k < c.offset.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.offset[k]);
-  fprintf(f, "], \"Scale\": [");
-  for (size_t k = 0; k < c.scale.size(); k++) fprintf(f, "%s%.17g", k ? "," : "", c.scale[k]);
-  fprintf(f, "]}, \"Distributions\": null}\n  ]\n}\n");
+  std::vector<std::pair<size_t, size_t>> features(nf);
+  for (size_t k = 0; k < nf; k++) features[k] = {pos(pairs[2 * k]), pos(pairs[2 * k + 1])};
+  write_head(f, e, type_name ? type_name : "scoresLr", true, index, features, names);
+  fprintf(f, "  \"Distributions\": [\n");
+  write_lr(f, c.theta, true);
+  write_transform_and_close(f, c.offset, c.scale);
   fclose(f);
   return KLR_OK;
 }
@@ -640,15 +704,13 @@ extern "C" int klr_estimator_save_ensemble(const klr_estimator* e, int64_t j, in
   if (!f) return KLR_EINVAL;
   std::string name = type_name ? type_name : "scoresLr";
   if (summary && *summary) name += std::string(" [") + summary + "]";
-  fprintf(f, "{\n  \"Name\": ");
-  json_str(f, name.c_str());
-  fprintf(f, ",\n  \"Parameters\": {\n    \"Cooccurrence\": false,\n    \"Features\": [");
-  for (size_t k = 0; k < nf; k++) fprintf(f, "%s[%zu,%zu]", k ? "," : "", k, k);
-  fprintf(f, "],\n    \"Index\": [");
-  for (size_t k = 0; k < nf; k++) fprintf(f, "%s%lld", k ? "," : "", (long long)(uni[k] - 1));
-  fprintf(f, "],\n    \"Names\": [");
-  if (names) for (size_t k = 0; k < nf; k++) { if (k) fputc(',', f); json_str(f, names[uni[k] - 1]); }
-  fprintf(f, "]\n  },\n  \"Distributions\": [\n");
+  {
+    std::vector<int64_t> index(nf);
+    std::vector<std::pair<size_t, size_t>> features(nf);
+    for (size_t k = 0; k < nf; k++) { index[k] = uni[k] - 1; features[k] = {k, k}; }
+    write_head(f, e, name, false, index, features, names);
+  }
+  fprintf(f, "  \"Distributions\": [\n");
   for (int k = 0; k < ensemble_size; k++) {
     const Classifier& c = e->out[(size_t)(k * nla + j)];
     std::vector<double> th(nf + 1, 0.0);

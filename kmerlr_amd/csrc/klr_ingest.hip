@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "klr_internal.h"
+#include "klr_kmers.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -23,61 +24,56 @@
 
 #define INVALID_ID 0xFFFFFFFFu
 
-// ---- class tables ---------------------------------------------------------------------------------
-__device__ __forceinline__ u32 revcomp_code(u32 c, int k) {
-  u32 r = 0;
-  for (int i = 0; i < k; i++) { r = (r << 2) | (3u - (c & 3u)); c >>= 2; }
-  return r;
-}
-
-__global__ __launch_bounds__(256) void k_rep_flag(u32 ncode, int k, u32* __restrict__ flag) {
-  const u32 c = blockIdx.x * 256 + threadIdx.x;
-  if (c < ncode) flag[c] = (min(c, revcomp_code(c, k)) == c) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_class_map(u32 ncode, int k, const i64* __restrict__ rank, int revcomp, u32 base,
-                                                   u32* __restrict__ map) {
-  const u32 c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncode) return;
-  const u32 rep = revcomp ? min(c, revcomp_code(c, k)) : c;
-  map[c] = base + (revcomp ? (u32)rank[rep] : c);
-}
-
 // ---- windows ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int base_code(unsigned char ch) {
   switch (ch | 0x20) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; default: return -1; }
 }
 
-// windows of row i for k = M..N are laid out k-major: [k=M windows | k=M+1 windows | ...]
-__global__ __launch_bounds__(256) void k_row_windows(const i64* __restrict__ seq_off, i64 n, int M, int N, u32* __restrict__ wcount) {
+// Candidate k-mers of a window.  Nucleotide alphabet: the window itself.  Gapped alphabet: the window with every subset
+// of its inner positions replaced by the gap letter (2^(k-2) candidates); the class table says which of them are
+// k-mers of the alphabet (gaps never first or last, at most max-ambiguous of them) -- the others map to INVALID_ID.
+__host__ __device__ static inline u32 window_variants(int k, int gapped) { return gapped && k > 2 ? 1u << (k - 2) : 1u; }
+
+// ids of row i for k = M..N are laid out k-major: [k=M windows x variants | k=M+1 ... | ...]
+__global__ __launch_bounds__(256) void k_row_windows(const i64* __restrict__ seq_off, i64 n, int M, int N, int gapped,
+                                                    u32* __restrict__ wcount, u32* __restrict__ overflow) {
   const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const i64 len = seq_off[i + 1] - seq_off[i];
-  u32 w = 0;
-  for (int k = M; k <= N; k++) if (len >= k) w += (u32)(len - k + 1);
-  wcount[i] = w;
+  unsigned long long w = 0;
+  for (int k = M; k <= N; k++) if (len >= k) w += (unsigned long long)(len - k + 1) * window_variants(k, gapped);
+  if (w >= 0xFFFFFFFFull) { atomicOr(overflow, 1u); w = 0; }
+  wcount[i] = (u32)w;
 }
 
 __global__ __launch_bounds__(256) void k_emit_ids(const unsigned char* __restrict__ seqs, const i64* __restrict__ seq_off,
-                                                  const i64* __restrict__ woff, i64 n, int M, int N,
-                                                  const u32* __restrict__ maps, const u32* __restrict__ map_off,
+                                                  const i64* __restrict__ woff, i64 n, int M, int N, int gapped,
+                                                  const u32* __restrict__ maps, const unsigned long long* __restrict__ map_off,
                                                   u32* __restrict__ ids) {
-  // one block per row; threads stride over the row's windows
+  // one block per row; threads stride over the row's (window, variant) pairs
   const i64 i = blockIdx.x;
   const i64 s0 = seq_off[i], len = seq_off[i + 1] - s0;
+  const u32 B = gapped ? 5u : 4u;
   i64 o = woff[i];
   for (int k = M; k <= N; k++) {
     if (len < k) continue;
-    const i64 nw = len - k + 1;
+    const u32 V = window_variants(k, gapped);
+    const i64 nw = (len - k + 1) * (i64)V;
     const u32* map = maps + map_off[k - M];
-    for (i64 p = threadIdx.x; p < nw; p += 256) {
+    for (i64 t = threadIdx.x; t < nw; t += 256) {
+      const i64 p = t / V;
+      const u32 mask = (u32)(t - p * V);                 // bit q - 1 set: inner position q carries the gap letter
       u32 code = 0; bool ok = true;
       for (int q = 0; q < k; q++) {
-        const int b = base_code(seqs[s0 + p + q]);
+        const unsigned char ch = seqs[s0 + p + q];
+        int b = base_code(ch);
+        const bool gap = q > 0 && q < k - 1 && ((mask >> (q - 1)) & 1u);
+        if (gapped && (ch | 0x20) == 'n') { b = 4; ok = ok && gap; }     // a gap in the sequence only matches a gap
+        else if (gap) b = 4;
         ok = ok && b >= 0;
-        code = (code << 2) | (u32)(b & 3);
+        code = code * B + (u32)(b < 0 ? 0 : b);
       }
-      ids[o + p] = ok ? map[code] : INVALID_ID;
+      ids[o + t] = ok ? map[code] : INVALID_ID;
     }
     o += nw;
   }
@@ -753,54 +749,61 @@ extern "C" int klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int6
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, out != nullptr);
   *out = nullptr;
-  KLR_ARG(ctx, seqs != nullptr && seq_off != nullptr && labels != nullptr && n >= 1 && seq_off[0] == 0);
-  KLR_ARG(ctx, M >= 1 && N >= M && N <= 12);
+  klr_kmer_spec spec;
+  memset(&spec, 0, sizeof(spec));
+  spec.M = M; spec.N = N; spec.revcomp = revcomp ? 1 : 0; spec.alphabet = KLR_ALPHABET_NUCLEOTIDE;
+  klr_kmer_classes* kc = nullptr;
+  char eb[256] = "";
+  if (klr_kmer_classes_create(&spec, &kc, eb, sizeof(eb)) != 0) return klr_fail(ctx, KLR_EINVAL, "%s", eb);
+  const int rc = klr_mat_from_sequences_classes(ctx, seqs, seq_off, n, kc, binarize, labels, n_total, out);
+  klr_kmer_classes_destroy(kc);
+  return rc;
+}
+
+extern "C" int klr_mat_from_sequences_classes(klr_ctx* ctx, const char* seqs, const int64_t* seq_off, int64_t n,
+                                              const klr_kmer_classes* classes, int binarize, const uint8_t* labels,
+                                              int64_t n_total, klr_mat** out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, out != nullptr);
+  *out = nullptr;
+  KLR_ARG(ctx, seqs != nullptr && seq_off != nullptr && labels != nullptr && classes != nullptr && n >= 1 && seq_off[0] == 0);
+  const klr_kmer_spec* spec = klr_kmer_classes_spec(classes);
+  const int M = spec->M, N = spec->N;
+  const int gapped = spec->alphabet == KLR_ALPHABET_GAPPED ? 1 : 0;
   if (n_total == 0) n_total = n;
   KLR_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   TmpPool tmp;
   const i64 nbytes = seq_off[n];
-  // ---- class tables
-  std::vector<u32> h_mapoff((size_t)(N - M + 1));
-  u64 tot_codes = 0;
-  for (int k = M; k <= N; k++) { h_mapoff[(size_t)(k - M)] = (u32)tot_codes; tot_codes += (u64)1 << (2 * k); }
-  u32 *maps, *d_mapoff, *flag; i64* rank;
-  KLR_TRY(tmp.get(ctx, &maps, (size_t)tot_codes)); KLR_TRY(tmp.get(ctx, &d_mapoff, h_mapoff.size()));
-  const u32 maxcode = (u32)1 << (2 * N);
-  KLR_TRY(tmp.get(ctx, &flag, (size_t)maxcode)); KLR_TRY(tmp.get(ctx, &rank, (size_t)maxcode + 1));
-  KLR_HIP(ctx, hipMemcpyAsync(d_mapoff, h_mapoff.data(), h_mapoff.size() * 4, hipMemcpyHostToDevice, st));
-  u32 m_total = 0;
-  for (int k = M; k <= N; k++) {
-    const u32 nc = (u32)1 << (2 * k);
-    u32 nclass = nc;
-    if (revcomp) {
-      hipLaunchKernelGGL(k_rep_flag, dim3(ceil_div(nc, 256)), dim3(256), 0, st, nc, k, flag);
-      KLR_TRY(exscan64(ctx, flag, nc, rank));
-      i64 h;
-      KLR_TRY(d2h_sync(ctx, &h, rank + nc, 8));
-      nclass = (u32)h;
-    }
-    hipLaunchKernelGGL(k_class_map, dim3(ceil_div(nc, 256)), dim3(256), 0, st, nc, k, rank, revcomp, m_total,
-                       maps + h_mapoff[(size_t)(k - M)]);
-    KLR_HIP(ctx, hipStreamSynchronize(st));        // `rank` is reused by the next k
-    m_total += nclass;
-  }
-  const i64 dim = (i64)m_total + 1;
+  // ---- class tables (built on the host, klr_kmers.cpp): code -> class id, one table per length
+  const uint32_t* h_map; const uint64_t* h_mapoff; int base;
+  klr_kmer_classes_tables(classes, &h_map, &h_mapoff, &base);
+  const u64 tot_codes = h_mapoff[(size_t)(N - M + 1)];
+  u32* maps; unsigned long long* d_mapoff;
+  KLR_TRY(tmp.get(ctx, &maps, (size_t)tot_codes)); KLR_TRY(tmp.get(ctx, &d_mapoff, (size_t)(N - M + 2)));
+  KLR_HIP(ctx, hipMemcpyAsync(maps, h_map, (size_t)tot_codes * 4, hipMemcpyHostToDevice, st));
+  KLR_HIP(ctx, hipMemcpyAsync(d_mapoff, h_mapoff, (size_t)(N - M + 2) * 8, hipMemcpyHostToDevice, st));
+  const i64 dim = klr_kmer_classes_count(classes) + 1;
   // ---- sequences, windows
-  unsigned char* d_seqs; i64* d_seqoff; u32* wcount; i64* woff;
+  unsigned char* d_seqs; i64* d_seqoff; u32* wcount; i64* woff; u32* d_ovf;
   KLR_TRY(tmp.get(ctx, &d_seqs, (size_t)nbytes)); KLR_TRY(tmp.get(ctx, &d_seqoff, (size_t)n + 1));
-  KLR_TRY(tmp.get(ctx, &wcount, (size_t)n)); KLR_TRY(tmp.get(ctx, &woff, (size_t)n + 1));
+  KLR_TRY(tmp.get(ctx, &wcount, (size_t)n)); KLR_TRY(tmp.get(ctx, &woff, (size_t)n + 1)); KLR_TRY(tmp.get(ctx, &d_ovf, 1));
+  KLR_HIP(ctx, hipMemsetAsync(d_ovf, 0, 4, st));
   KLR_HIP(ctx, hipMemcpyAsync(d_seqs, seqs, (size_t)nbytes, hipMemcpyHostToDevice, st));
   KLR_HIP(ctx, hipMemcpyAsync(d_seqoff, seq_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_row_windows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_seqoff, n, M, N, wcount);
+  hipLaunchKernelGGL(k_row_windows, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d_seqoff, n, M, N, gapped, wcount, d_ovf);
   KLR_TRY(exscan64(ctx, wcount, n, woff));
   i64 nwin = 0;
   KLR_TRY(d2h_sync(ctx, &nwin, woff + n, 8));
-  KLR_ARG(ctx, nwin < (i64)0xFFFFFFF0ll);
+  u32 h_ovf = 0;
+  KLR_TRY(d2h_sync(ctx, &h_ovf, d_ovf, 4));
+  if (h_ovf || nwin >= (i64)0xFFFFFFF0ll)
+    return klr_fail(ctx, KLR_EINVAL, "too many k-mer candidates (%lld) for one matrix: count fewer sequences at a time or bound --max-ambiguous",
+                    (long long)nwin);
   u32 *ids, *ids_sorted, *head, *rowheads;
   KLR_TRY(tmp.get(ctx, &ids, (size_t)nwin)); KLR_TRY(tmp.get(ctx, &ids_sorted, (size_t)nwin));
   KLR_TRY(tmp.get(ctx, &head, (size_t)nwin)); KLR_TRY(tmp.get(ctx, &rowheads, (size_t)n));
-  hipLaunchKernelGGL(k_emit_ids, dim3((unsigned)n), dim3(256), 0, st, d_seqs, d_seqoff, woff, n, M, N, maps, d_mapoff, ids);
+  hipLaunchKernelGGL(k_emit_ids, dim3((unsigned)n), dim3(256), 0, st, d_seqs, d_seqoff, woff, n, M, N, gapped, maps, d_mapoff, ids);
   // ---- per-row sort (segments = rows)
   {
     size_t tsz = 0;

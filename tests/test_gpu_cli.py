@@ -78,7 +78,13 @@ def test_kmers_learn_config1_matches_oracle_driver(tmp_path):
     fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
     run(["-v", "learn", "--lambda-auto=10", "--save-path", "4", "4", fg, bg, "km"], tmp_path)
     m = json.load(open(tmp_path / "km.json"))
-    assert m["Name"] == "kmerLr" and len(m["Parameters"]["Index"]) == 10
+    # the reference's KmerLrFeatures parameters, in its field order (kmerLr_features.go:222-250)
+    P = m["Parameters"]
+    assert m["Name"] == "kmerLr" and list(P.keys()) == ["M", "N", "Binarize", "Complement", "Cooccurrence", "Reverse", "Revcomp",
+                                                       "MaxAmbiguous", "Alphabet", "Kmers", "Features"]
+    assert (P["M"], P["N"], P["Binarize"], P["Complement"], P["Cooccurrence"], P["Reverse"], P["Revcomp"]) == (4, 4, False, False, False, False, False)
+    assert P["MaxAmbiguous"] == [-1] and P["Alphabet"] == "nucleotide alphabet"
+    assert len(P["Kmers"]) == 10 and P["Features"] == [[k, k] for k in range(10)]
     cf, cb = count_kmers(fg, 4), count_kmers(bg, 4)
     assert cf.shape == (11, 256) and cb.shape == (11, 256)
     dense = np.concatenate([cf, cb])
@@ -91,10 +97,16 @@ def test_kmers_learn_config1_matches_oracle_driver(tmp_path):
     h = OD.matrix(x, labels)
     c = OD.estimator().estimate(h, [10])[0]
     OD.free_matrix(h)
-    assert m["Parameters"]["Index"] == list(c["cols"][1:] - 1)       # identical selected k-mers
+    def name(j):
+        return "acgt"[j // 64] + "acgt"[j // 16 % 4] + "acgt"[j // 4 % 4] + "acgt"[j % 4]
+    assert P["Kmers"] == [name(j - 1) for j in c["cols"][1:]]          # identical selected k-mers
     np.testing.assert_allclose(m["Distributions"][0]["Parameters"], c["theta"], rtol=1e-6, atol=1e-10)
-    assert m["Parameters"]["Names"][0] == "acgt"[(c["cols"][1] - 1) // 64] + "acgt"[(c["cols"][1] - 1) // 16 % 4] + \
-        "acgt"[(c["cols"][1] - 1) // 4 % 4] + "acgt"[(c["cols"][1] - 1) % 4]
+    # loss / predict rebuild the counter from the model alone (kmerLr_loss.go:53-57): no --m / --n / flags
+    out = run(["loss", "km.json", fg, bg], tmp_path).stdout
+    red = O.select_columns(x, c["cols"])
+    assert abs(float(out) - O.loss(red, labels, c["theta"])) < 1e-6        # printed with %15e
+    pr = [float(v) for v in run(["predict", "km.json", fg], tmp_path).stdout.split()[1:]]
+    assert len(pr) == 11 and all(v <= 0 for v in pr)
 
 
 def test_scores_learn_kfold_cv(tmp_path):
@@ -234,13 +246,14 @@ def test_kmers6_cooccurrence_fasta_cli(tmp_path):
     fg, bg = os.path.join(GOLDEN, "kmerLr_test_co_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_co_bg.fa")
     run(["learn", "--lambda-auto=2", "--epsilon-loss=1e-8", "--binarize", "--revcomp", "--co-occurrence", "2", "6", fg, bg, "co"], tmp_path)
     m = json.load(open(tmp_path / "co.json"))
-    assert m["Parameters"]["Cooccurrence"] is True
+    assert m["Parameters"]["Cooccurrence"] is True and m["Parameters"]["Binarize"] is True and m["Parameters"]["Revcomp"] is True
+    assert (m["Parameters"]["M"], m["Parameters"]["N"]) == (2, 6) and all("|" in k for k in m["Parameters"]["Kmers"])
     feats = m["Parameters"]["Features"]
     assert len(feats) == 2 and all(a != b for a, b in feats)                # two pairs (kmerLr_test.go:204-205)
     theta = m["Distributions"][0]["Parameters"]
     assert len(theta) == 3 and theta[1] > 0 and theta[2] > 0
-    pf = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "co.json", fg], tmp_path).stdout.split()[1:]]
-    pb = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "co.json", bg], tmp_path).stdout.split()[1:]]
+    pf = [float(v) for v in run(["predict", "co.json", fg], tmp_path).stdout.split()[1:]]
+    pb = [float(v) for v in run(["predict", "co.json", bg], tmp_path).stdout.split()[1:]]
     assert len(pf) == 10 and len(pb) == 10
     # both pair features are present in every fg row and in no bg row: two prediction levels, theta0 + theta1 + theta2 / theta0
     np.testing.assert_allclose(pf, [-np.log1p(np.exp(-(theta[0] + theta[1] + theta[2])))] * 10, rtol=1e-6)
@@ -248,9 +261,26 @@ def test_kmers6_cooccurrence_fasta_cli(tmp_path):
     # the reference's theta through our predict: its goldens (:226-262)
     m["Distributions"][0]["Parameters"] = [-0.1000970529629098, 0.09995715710821684, 0.09995715710821684]
     json.dump(m, open(tmp_path / "ref.json", "w"))
-    pf = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "ref.json", fg], tmp_path).stdout.split()[1:]]
-    pb = [float(v) for v in run(["predict", "--m=2", "--n=6", "--binarize", "--revcomp", "ref.json", bg], tmp_path).stdout.split()[1:]]
+    pf = [float(v) for v in run(["predict", "ref.json", fg], tmp_path).stdout.split()[1:]]
+    pb = [float(v) for v in run(["predict", "ref.json", bg], tmp_path).stdout.split()[1:]]
     np.testing.assert_allclose(pf, [-0.6444834689451768] * 10, atol=1e-6)
     np.testing.assert_allclose(pb, [-0.744447612033651] * 10, atol=1e-6)
-    out = run(["loss", "--m=2", "--n=6", "--binarize", "--revcomp", "ref.json", fg, bg], tmp_path).stdout
+    out = run(["loss", "ref.json", fg, bg], tmp_path).stdout
     assert abs(float(out) - 0.644417014007959) < 1e-4                       # :223 (the reference's tolerance)
+
+
+def test_kmers_gapped_alphabet_cli_round_trip(tmp_path):
+    """learn --alphabet=gapped-nucleotide --revcomp --max-ambiguous=1 writes the counter into the model; loss / predict read
+    it back and reproduce the training loss with no counter flags (KmerLrFeatures.ExportConfig / ImportConfig)."""
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
+    r = run(["-v", "learn", "--lambda-auto=6", "--alphabet=gapped-nucleotide", "--revcomp", "--max-ambiguous=1", "--save-trace",
+             "4", "5", fg, bg, "gp"], tmp_path)
+    m = json.load(open(tmp_path / "gp.json"))
+    P = m["Parameters"]
+    assert P["Alphabet"] == "gapped nucleotide alphabet" and P["MaxAmbiguous"] == [1] and P["Revcomp"] is True and (P["M"], P["N"]) == (4, 5)
+    assert len(P["Kmers"]) == 6 and all(k.count("|") == 1 and k.count("n") <= 2 for k in P["Kmers"])
+    trace = open(tmp_path / "gp.trace").read().splitlines()
+    last_loss = float(trace[-1].split()[-1])
+    lam = float(trace[-1].split()[-2])
+    out = run(["loss", "--lambda=%r" % lam, "gp.json", fg, bg], tmp_path).stdout
+    assert abs(float(out) - last_loss) < 1e-6

@@ -168,3 +168,86 @@ def test_large_device_ingest_equals_host_ingest(ctx, host_ingest):
     top = np.argsort(-np.abs(rd["g"][1:]))[:4]
     names = {"".join("acgt"[(c >> (2 * (5 - i))) & 3] for i in range(6)) for c in top}
     assert names & {"acgtac", "cgtacg", "ttgacc", "tgacca"}
+
+
+def test_kmers1_known_answers_gapped_revcomp(ctx):
+    """TestKmers1 (kmerLr_test.go:30-66), the only counting known-answers the reference holds: M = 4, N = 8, revcomp,
+    gapped nucleotide alphabet on kmerLr_test.fa; row 0: gntanc|gntanc = 3, gntcaa|ttganc = 0, aaagaaa|tttcttt = 1,
+    aagannt|anntctt = 7, aacgcgna|tncgcgtt = 1, tgaatgca|tgcattca = 1; the pair feature (gntanc, aagannt) = 21.
+    Classes are addressed by NAME: gonetics' own class numbering (4671, 5486, ...) cannot be reproduced offline."""
+    seqs, cur = [], []
+    for line in open(os.path.join(GOLDEN, "kmerLr_test.fa")):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur)); cur = []
+        elif line:
+            cur.append(line)
+    seqs.append("".join(cur))
+    assert len(seqs) == 2
+    kc = K.KmerClasses(4, 8, revcomp=True, alphabet="gapped-nucleotide")
+    known = {"gntanc|gntanc": 3, "gntcaa|ttganc": 0, "aaagaaa|tttcttt": 1, "aagannt|anntctt": 7, "aacgcgna|tncgcgtt": 1,
+             "tgaatgca|tgcattca": 1}
+    cls = {}
+    for name in known:
+        c = kc.find(name)
+        assert c >= 0 and kc.name(c) == name and kc.find(name.split("|")[1]) == c
+        cls[name] = c
+    labels = np.array([1, 0], dtype=np.uint8)
+    m = K.Matrix.from_sequences(ctx, seqs, labels, classes=kc)
+    assert m.dim == len(kc) + 1
+    rp, col, val = m.to_csr()
+    row0 = dict(zip(col[rp[0]:rp[1]], val[rp[0]:rp[1]]))
+    for name, cnt in known.items():
+        assert row0.get(cls[name] + 1, 0.0) == cnt, name
+    assert row0[cls["gntanc|gntanc"] + 1] * row0[cls["aagannt|anntctt"] + 1] == 21
+    # every row against a brute-force matcher for a few hundred random classes of every length
+    import re
+    comp = {"a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+    rng = np.random.default_rng(3)
+    for c in rng.choice(len(kc), size=300, replace=False):
+        a, b = kc.name(int(c)).split("|")
+        assert b == "".join(comp[ch] for ch in reversed(a))
+        for i, sq in enumerate(seqs):
+            sq = sq.lower()
+            cnt = len(re.findall("(?=%s)" % a.replace("n", "[acgt]"), sq))
+            if a != b:
+                cnt += len(re.findall("(?=%s)" % b.replace("n", "[acgt]"), sq))
+            row = dict(zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]]))
+            assert row.get(int(c) + 1, 0.0) == cnt, (a, b, i)
+    # max-ambiguous = 0 leaves the ungapped classes: the plain --revcomp counter
+    kc0 = K.KmerClasses(4, 6, revcomp=True, alphabet="gapped-nucleotide", max_ambiguous=[0])
+    kcp = K.KmerClasses(4, 6, revcomp=True)
+    assert len(kc0) == len(kcp)
+    m0 = K.Matrix.from_sequences(ctx, seqs, labels, classes=kc0)
+    mp = K.Matrix.from_sequences(ctx, seqs, labels, 4, 6, revcomp=True)
+    for a, b in zip(m0.to_csr(), mp.to_csr()):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_complement_and_reverse_classes(ctx):
+    """--complement / --reverse (kmerLr_learn.go:118,121): classes are orbits under the enabled operations; counts
+    against a brute-force matcher."""
+    rng = np.random.default_rng(8)
+    seqs = ["".join("acgt"[v] for v in rng.integers(0, 4, size=300)) for _ in range(6)]
+    labels = np.array([1, 1, 1, 0, 0, 0], dtype=np.uint8)
+    comp = {"a": "t", "c": "g", "g": "c", "t": "a"}
+    for kw in ({"complement": True}, {"reverse": True}, {"complement": True, "reverse": True}):
+        kc = K.KmerClasses(3, 4, **kw)
+        m = K.Matrix.from_sequences(ctx, seqs, labels, classes=kc)
+        rp, col, val = m.to_csr()
+        for c in range(len(kc)):
+            members = set(kc.name(c).split("|"))
+            a = kc.name(c).split("|")[0]
+            want = {a}
+            if kw.get("complement"):
+                want.add("".join(comp[ch] for ch in a))
+            if kw.get("reverse"):
+                want.add(a[::-1])
+            if len(kw) == 2:
+                want.add("".join(comp[ch] for ch in a[::-1]))
+            assert members == want
+            for i, sq in enumerate(seqs):
+                cnt = sum(sq[p:p + len(a)] in members for p in range(len(sq) - len(a) + 1))
+                row = dict(zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]]))
+                assert row.get(c + 1, 0.0) == cnt
