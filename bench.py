@@ -321,7 +321,7 @@ def main(argv=None):
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
-                     "allreduce_elements": m + 6 if R.comm else 0},
+                     "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N)},
             "cd_sweeps_per_s": cd["sweeps_per_s"], "cd_sweeps": cd,
             "cd_solve": {"sweeps_to_converge": n_sweeps_solve, "seconds": round(t_solve, 4), "nonzero": int(np.count_nonzero(theta[1:]))},
             "estimate_lambda_auto": estimate,
@@ -354,6 +354,16 @@ def sweep_kernel_in_estimate(R, mat, lam_auto):
     est.close()
     return {"kernel_avg_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "note": "sweep kernel timed inside klr_estimator_estimate (sub-select and reduced solve between sweeps)"}
+
+
+def sweep_collective(world, m, N):
+    """What klr_sweep_select posts per sweep (klr_select.hip): one rank nothing; from 131,072 columns on (KLR_RS_MIN_DIM)
+    a reduce-scatter of the int64 column sums + an all-gather of nranks x 2N candidates; below that one all-reduce."""
+    if world <= 1:
+        return "none (one rank)"
+    if m + 1 >= int(os.environ.get("KLR_RS_MIN_DIM", "131072")) and 2 * N <= 4096:
+        return "reduce-scatter of %d int64 + all-gather of %d x %d candidates" % (m + 6, world, 2 * N)
+    return "all-reduce of %d int64" % (m + 6)
 
 
 def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, warmup=3, steps=10):
@@ -391,7 +401,8 @@ def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, w
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "scaling": "weak",
             "roofline": roofline,
             "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
-                     "allreduce_elements": m + 6 if R.comm else 0},
+                     "allreduce_elements": m + 6 if R.comm else 0,
+                     "sweep_collective": sweep_collective(world, m, N)},
             "estimate_lambda_auto": est,
             "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]}}
 

@@ -60,6 +60,19 @@ int         klr_ctx_synchronize(klr_ctx* ctx);
 #define KLR_I64 1
 typedef int (*klr_allreduce_fn)(void* user, void* dev_buf, int64_t count, int dtype, void* hip_stream);
 int         klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* user, int rank, int nranks);
+/* Optional second pair of hooks for the full-width sweep's collective ("a direct reduce-scatter +
+ * all-gather that uses all links ... prefer the latter").  With both installed (and klr_ctx_set_allreduce's nranks > 1)
+ * klr_sweep_select reduce-scatters the int64 column sums -- rank r then owns the exact sums of columns
+ * [r * slice, (r+1) * slice), slice = ceil((dim + 5) / nranks) -- selects its slice's 2N largest |g| locally and
+ * all-gathers the nranks x 2N candidates (a few KB): the same selection and lambda as the all-reduce path, bit for bit,
+ * for half the bytes on the links and 1/nranks of the conversion work.  Semantics:
+ *   reduce_scatter: recv[i] = sum over ranks of send[rank * recv_count + i], i < recv_count (send holds nranks * recv_count
+ *                   elements of dtype); out of place
+ *   allgather:      recv[r * send_bytes + b] = rank r's send[b]
+ * Both take DEVICE pointers and run in stream order on the ctx stream.  klr_ctx_init_rccl installs RCCL's. */
+typedef int (*klr_reduce_scatter_fn)(void* user, const void* send_dev, void* recv_dev, int64_t recv_count, int dtype, void* hip_stream);
+typedef int (*klr_allgather_fn)(void* user, const void* send_dev, void* recv_dev, int64_t send_bytes, void* hip_stream);
+int         klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_allgather_fn ag, void* user);
 /* built-in hook: RCCL over xGMI.  id = 128-byte ncclUniqueId obtained on rank 0 with
  * klr_rccl_unique_id and distributed by the launcher. */
 int         klr_rccl_unique_id(void* id128);

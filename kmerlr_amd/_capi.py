@@ -20,6 +20,8 @@ class IterRec(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+REDUCE_SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # name -> (restype, argtypes); also the export list checked by tests/test_abi.py
 _vp, _i64, _dbl, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
@@ -31,6 +33,7 @@ SIGNATURES = {
     "klr_ctx_set_stream": (_int, [_vp, _vp]),
     "klr_ctx_synchronize": (_int, [_vp]),
     "klr_ctx_set_allreduce": (_int, [_vp, ALLREDUCE_FN, _vp, _int, _int]),
+    "klr_ctx_set_collectives": (_int, [_vp, REDUCE_SCATTER_FN, ALLGATHER_FN, _vp]),
     "klr_rccl_unique_id": (_int, [_vp]),
     "klr_ctx_init_rccl": (_int, [_vp, _vp, _int, _int]),
     "klr_ctx_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
@@ -150,6 +153,27 @@ class Context:
                 return 1
         self._cb = ALLREDUCE_FN(tramp)
         self.check(lib().klr_ctx_set_allreduce(self._h, self._cb, None, rank, nranks))
+
+    def set_collectives(self, rs_fn, ag_fn):
+        """Reduce-scatter + all-gather hooks (klr_ctx_set_collectives), after set_allreduce:
+        rs_fn(send_ptr, recv_ptr, recv_count, dtype, stream), ag_fn(send_ptr, recv_ptr, send_bytes, stream)."""
+        def t_rs(user, send, recv, count, dtype, stream):
+            try:
+                rs_fn(send, recv, count, dtype, stream)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("reduce-scatter hook failed:", e)
+                return 1
+
+        def t_ag(user, send, recv, nbytes, stream):
+            try:
+                ag_fn(send, recv, nbytes, stream)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("all-gather hook failed:", e)
+                return 1
+        self._cb_rs, self._cb_ag = REDUCE_SCATTER_FN(t_rs), ALLGATHER_FN(t_ag)
+        self.check(lib().klr_ctx_set_collectives(self._h, self._cb_rs, self._cb_ag, None))
 
     def init_rccl(self, unique_id: bytes, rank, nranks):
         buf = C.create_string_buffer(unique_id, 128)

@@ -122,6 +122,19 @@ extern "C" int klr_rccl_unique_id(void* id128) {
   return KLR_OK;
 }
 
+static int rccl_reduce_scatter_hook(void* user, const void* send, void* recv, int64_t recv_count, int dtype, void* stream) {
+  RcclState* st = (RcclState*)user;
+  const int ncclInt64 = 4, ncclFloat64 = 8, ncclSum = 0;
+  if (!st->ReduceScatter) return 1;
+  return st->ReduceScatter(send, recv, (size_t)recv_count, dtype == KLR_I64 ? ncclInt64 : ncclFloat64, ncclSum, st->comm, (hipStream_t)stream) == 0 ? 0 : 1;
+}
+static int rccl_allgather_hook(void* user, const void* send, void* recv, int64_t send_bytes, void* stream) {
+  RcclState* st = (RcclState*)user;
+  const int ncclInt8 = 0;
+  if (!st->AllGather) return 1;
+  return st->AllGather(send, recv, (size_t)send_bytes, ncclInt8, st->comm, (hipStream_t)stream) == 0 ? 0 : 1;
+}
+
 static int rccl_allreduce_hook(void* user, void* dev_buf, int64_t count, int dtype, void* stream) {
   RcclState* st = (RcclState*)user;
   const int ncclInt64 = 4, ncclFloat64 = 8, ncclSum = 0;
@@ -148,6 +161,7 @@ extern "C" int klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int 
   ctx->rccl = st;
   ctx->ar_fn = rccl_allreduce_hook;
   ctx->ar_user = st;
+  if (st->ReduceScatter && st->AllGather) { ctx->rs_fn = rccl_reduce_scatter_hook; ctx->ag_fn = rccl_allgather_hook; ctx->coll_user = st; }
   ctx->rank = rank;
   ctx->nranks = nranks;
   return KLR_OK;
@@ -160,6 +174,7 @@ extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* us
   ctx->ar_user = user;
   ctx->rank = rank;
   ctx->nranks = nranks;
+  ctx->rs_fn = nullptr; ctx->ag_fn = nullptr; ctx->coll_user = nullptr;     // belong to the previous hook
   return KLR_OK;
 }
 
@@ -201,6 +216,13 @@ extern "C" int klr_allreduce_time(klr_ctx* ctx, int64_t count, int dtype, int it
   if (rc != KLR_OK) return rc;
   if (he != hipSuccess) return klr_fail(ctx, KLR_EHIP, "timing the all-reduce failed: %s", hipGetErrorString(he));
   *ms_avg = (double)ms / iters;
+  return KLR_OK;
+}
+
+extern "C" int klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_allgather_fn ag, void* user) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, (rs == nullptr) == (ag == nullptr));
+  ctx->rs_fn = rs; ctx->ag_fn = ag; ctx->coll_user = user;
   return KLR_OK;
 }
 

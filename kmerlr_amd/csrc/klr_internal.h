@@ -52,6 +52,9 @@ struct klr_ctx {
   klr_allreduce_fn ar_fn = nullptr;
   void*        ar_user = nullptr;
   int          rank = 0, nranks = 1;
+  klr_reduce_scatter_fn rs_fn = nullptr;   // optional: reduce-scatter + all-gather form of the sweep's collective
+  klr_allgather_fn      ag_fn = nullptr;
+  void*        coll_user = nullptr;
   void*        rccl = nullptr;       // struct RcclState*
   DevBuf       ws[WS_COUNT];
   // pinned host staging
@@ -221,7 +224,12 @@ struct FastCtl { u32 cursor, n, above, pad0; u64 low; u32 pad[10]; };
 // over the keys at all.  tau = 0: off.
 struct SelHint { u64 tau; Cand* cand; FastCtl* ctl; };
 int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
-                       const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint = nullptr);
+                       const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint = nullptr, i64** ibuf_out = nullptr,
+                       i64 ibuf_elems = 0);
+// the second half of sweep_fix_finish when it was stopped before its collective (ibuf_out): all-reduce + conversion
+int   sweep_fix_tail(klr_ctx* ctx, const klr_mat* mat, double scale, i64* ibuf, double* gbuf, u64* keys, u32* hist,
+                     const SelHint* hint);
+#define IB_EXTRA 5
 int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                           const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
                           const double* theta_host = nullptr, i64 theta_len = 0);

@@ -524,6 +524,35 @@ int sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist) {
   return KLR_OK;
 }
 
+// Select :95-119 and computeLambda :179-192 on the K = min(m, 2N) candidates sorted by (|g| desc, column asc);
+// vkey = key of the N-th, wkey = the largest key below it
+static void select_finish_host(const std::vector<Cand>& hc, i64 K, u64 vkey, u64 wkey, uint8_t* b, i64 c_prev, i64 N,
+                               double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out, int* ok_out, i64* picked_out) {
+  i64 c = c_prev;
+  int ok = 0;
+  for (i64 k = 0; k < K; k++) {                                        // :95-105
+    if (c >= N) break;
+    const u32 j = hc[k].idx;
+    if (!b[j + 1] && hc[k].key != 0ull) { ok = 1; b[j + 1] = 1; c++; }
+  }
+  for (i64 k = 0; k < K; k++) {                                        // :107-116
+    if (c >= N) break;
+    const u32 j = hc[k].idx;
+    if (!b[j + 1]) { b[j + 1] = 1; c++; }
+  }
+  if (c > N) ok = 1;                                                   // :117-119
+  // computeLambda :179-192
+  double l = 0.0;
+  if (!(N > K) && N >= 1) {
+    const double v = key_to_double(vkey), w = key_to_double(wkey);
+    l = (v + w) / 2.0;
+  }
+  if (picked_out) for (i64 k = 0; k < K; k++) picked_out[k] = (i64)hc[k].idx;
+  *lambda_out = l;
+  *c_out = c;
+  *ok_out = (ok || (eps_lambda > 0.0 && std::fabs(lambda_prev - l) >= eps_lambda)) ? 1 : 0;   // :133
+}
+
 int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                        double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
                        int* ok_out, i64* picked_out, bool keys_hist_ready, const double* extra_src, double* extra_out,
@@ -597,30 +626,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     }
   }
   if (K == 0 && extra_src && extra_out) KLR_TRY(d2h_sync(ctx, extra_out, extra_src, sizeof(double)));
-  // ---- Select :95-119 on the sorted candidates ------------------------------------------------
-  i64 c = c_prev;
-  int ok = 0;
-  for (i64 k = 0; k < K; k++) {                                        // :95-105
-    if (c >= N) break;
-    const u32 j = hc[k].idx;
-    if (!b[j + 1] && hc[k].key != 0ull) { ok = 1; b[j + 1] = 1; c++; }
-  }
-  for (i64 k = 0; k < K; k++) {                                        // :107-116
-    if (c >= N) break;
-    const u32 j = hc[k].idx;
-    if (!b[j + 1]) { b[j + 1] = 1; c++; }
-  }
-  if (c > N) ok = 1;                                                   // :117-119
-  // computeLambda :179-192
-  double l = 0.0;
-  if (!(N > K) && N >= 1) {
-    const double v = key_to_double(vkey), w = key_to_double(wkey);
-    l = (v + w) / 2.0;
-  }
-  if (picked_out) for (i64 k = 0; k < K; k++) picked_out[k] = (i64)hc[k].idx;
-  *lambda_out = l;
-  *c_out = c;
-  *ok_out = (ok || (eps_lambda > 0.0 && std::fabs(lambda_prev - l) >= eps_lambda)) ? 1 : 0;   // :133
+  select_finish_host(hc, K, vkey, wkey, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, picked_out);
   return KLR_OK;
 }
 
@@ -647,6 +653,136 @@ extern "C" int klr_select_fixed(klr_ctx* ctx, const double* g_full, int64_t m, u
     if (max_features > 0 && c >= max_features && ok) break;
   }
   *c_out = c; *ok_out = ok;
+  return KLR_OK;
+}
+
+// =================================================================================================
+// The sweep's collective as reduce-scatter + local top-2N + all-gather of the candidates.
+//
+// ibuf = this rank's int64 column sums [0, dim) | bias hi, lo | loss limbs | non-finite count, zero padded to
+// nranks * slice.  After the reduce-scatter rank r holds the EXACT sums of columns [r * slice, (r+1) * slice).  It
+// converts them to keys, selects its 2N largest |g| with the same device kernels as the whole-vector selection (they
+// sort by (|g| desc, column asc)), and all-gathers one block per rank:
+//     [FastState 40 B | - | 5 int64 extras it owns at +64 | Cand[K_r] at +128]
+// Every rank then merges the nranks sorted lists on the host -- the global 2N largest are among the local 2N largest
+// -- and finishes Select / computeLambda exactly as the single-vector path does.  lambda needs w = the largest |g|
+// BELOW the N-th: it is among the gathered candidates unless some rank's list is all >= v and its slice holds more
+// columns than the list; then (and when a local selection fell back to the radix select) every rank -- they all see
+// the same gathered blocks -- takes the all-reduce path on its intact ibuf instead.  Integer sums are the same
+// numbers whichever collective adds them: selection and lambda are bitwise those of the all-reduce path.
+// =================================================================================================
+#define SCAT_HDR 128
+__global__ __launch_bounds__(256) void k_slice_keys(const i64* __restrict__ rbuf, i64 lo, i64 feat0, i64 m_s, double inv_scale,
+                                                    u64* __restrict__ keys, u32* __restrict__ hist) {
+  __shared__ u32 sh[FAST_BINS];
+  for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < m_s; t += (i64)gridDim.x * 256) {
+    const double v = (double)rbuf[feat0 + t - lo] * inv_scale;        // inv_scale is a power of two: exact
+    const u64 k = abs_key(v);
+    keys[t] = k;
+    atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// the five scalars behind the column sums (global elements dim .. dim+4): the rank that owns one writes it, the others 0
+__global__ void k_slice_extras(const i64* __restrict__ rbuf, i64 lo, i64 slice, i64 dim, i64* __restrict__ dst, u32 m_s, u32 K_s) {
+  const int q = threadIdx.x;
+  if (q < IB_EXTRA) { const i64 j = dim + q; dst[q] = (j >= lo && j < lo + slice) ? rbuf[j - lo] : 0; }
+  if (q == 5) dst[5] = ((i64)m_s << 32) | (i64)K_s;
+}
+
+static int sweep_select_scatter(klr_ctx* ctx, const klr_mat* full, double scale_fx, i64* ibuf, i64 slice, i64 N, uint8_t* b, i64 c_prev,
+                                double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out, int* ok_out, double* loss_sum,
+                                bool* done) {
+  *done = false;
+  hipStream_t st = ctx->stream;
+  const i64 dim = full->dim, m = dim - 1;
+  const int R = ctx->nranks, r = ctx->rank;
+  const i64 lo = (i64)r * slice, hi = std::min<i64>(lo + slice, dim);
+  const i64 feat0 = std::max<i64>(lo, 1);                              // global column of this rank's first feature
+  const i64 m_s = std::max<i64>(0, hi - feat0);
+  const i64 Kmax = std::min<i64>(m, 2 * N);                            // candidates per rank at most
+  const i64 K_s = std::min<i64>(m_s, 2 * N);
+  const size_t blk = SCAT_HDR + (size_t)std::max<i64>(Kmax, 1) * sizeof(Cand);
+  i64* rbuf; char *sendb, *recvb;
+  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)slice * 8 + blk * (size_t)(R + 1), (void**)&rbuf));
+  sendb = (char*)(rbuf + slice); recvb = sendb + blk;
+  if (ctx->rs_fn(ctx->coll_user, ibuf, rbuf, slice, KLR_I64, (void*)st) != 0) return klr_fail(ctx, KLR_ECOMM, "reduce-scatter hook failed");
+  KLR_HIP(ctx, hipMemsetAsync(sendb, 0, blk, st));
+  if (K_s > 0) {
+    u64* keys; u32* hist; Cand* cand;
+    KLR_TRY(sel_prepare(ctx, m_s, &keys, &hist));
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)GCAND_CAP * sizeof(Cand), (void**)&cand));
+    FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+    hipLaunchKernelGGL(k_slice_keys, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 1024), 256))), dim3(256), 0, st, rbuf, lo, feat0,
+                       m_s, 1.0 / scale_fx, keys, hist);
+    static bool attr = false;
+    if (!attr) {
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FAST_CAP * sizeof(Cand))));
+      attr = true;
+    }
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 4096), 256));
+    hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m_s, (u32)K_s, cand);
+    hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K_s, (u32)std::min<i64>(N, K_s),
+                       cand, (FastState*)sendb, (Cand*)(sendb + SCAT_HDR), (const double*)nullptr, (double*)nullptr);
+  }
+  hipLaunchKernelGGL(k_slice_extras, dim3(1), dim3(64), 0, st, rbuf, lo, slice, dim, (i64*)(sendb + 64), (u32)m_s, (u32)K_s);
+  KLR_HIP(ctx, hipGetLastError());
+  if (ctx->ag_fn(ctx->coll_user, sendb, recvb, (int64_t)blk, (void*)st) != 0) return klr_fail(ctx, KLR_ECOMM, "all-gather hook failed");
+  char* pin;
+  KLR_TRY(pin_get(ctx, blk * (size_t)R, (void**)&pin));
+  KLR_HIP(ctx, hipMemcpyAsync(pin, recvb, blk * (size_t)R, hipMemcpyDeviceToHost, st));
+  KLR_HIP(ctx, hipStreamSynchronize(st));
+  // ---- merge on the host (identical on every rank)
+  std::vector<Cand> all;
+  i64 tot[IB_EXTRA] = {0, 0, 0, 0, 0};
+  bool fallback = false;
+  for (int q = 0; q < R; q++) {
+    const char* bq = pin + blk * (size_t)q;
+    FastState fs; memcpy(&fs, bq, sizeof(fs));
+    i64 ex[6]; memcpy(ex, bq + 64, sizeof(ex));
+    for (int u = 0; u < IB_EXTRA; u++) tot[u] += ex[u];
+    const i64 mq = (i64)((u64)ex[5] >> 32), Kq = (i64)((u64)ex[5] & 0xFFFFFFFFull);
+    if (Kq == 0) continue;
+    if (fs.fallback) { fallback = true; break; }
+    const i64 base = std::max<i64>((i64)q * slice, 1) - 1;             // global feature index of the rank's local feature 0
+    const Cand* cq = (const Cand*)(bq + SCAT_HDR);
+    for (i64 k = 0; k < Kq; k++) { Cand c = cq[k]; c.idx = (u32)(c.idx + base); c.pad = (u32)q; all.push_back(c); }
+    (void)mq;
+  }
+  const i64 K = Kmax;
+  u64 vkey = 0, wkey = 0;
+  if (!fallback) {
+    std::sort(all.begin(), all.end(), [](const Cand& a, const Cand& c) { return a.key != c.key ? a.key > c.key : a.idx < c.idx; });
+    if ((i64)all.size() < K) fallback = true;                          // cannot happen (every feature is in some slice); be safe
+  }
+  if (!fallback && !(N > K) && N >= 1) {
+    vkey = all[(size_t)N - 1].key;
+    bool found = false;
+    for (const Cand& c : all) if (c.key < vkey) { wkey = c.key; found = true; break; }     // sorted: the first below v is the largest
+    // a rank whose list holds nothing below v may hide larger keys below v than the one found, unless its list is its whole slice
+    for (int q = 0; q < R && !fallback; q++) {
+      const char* bq = pin + blk * (size_t)q;
+      i64 ex[6]; memcpy(ex, bq + 64, sizeof(ex));
+      const i64 mq = (i64)((u64)ex[5] >> 32), Kq = (i64)((u64)ex[5] & 0xFFFFFFFFull);
+      if (Kq == 0 || Kq == mq) continue;
+      const Cand* cq = (const Cand*)(bq + SCAT_HDR);
+      if (cq[Kq - 1].key >= vkey) fallback = true;                     // its smallest candidate is not below v
+    }
+    if (!found) fallback = true;
+  }
+  if (fallback) return KLR_OK;                                         // *done stays false: the caller takes the all-reduce path
+  std::vector<Cand> hc(all.begin(), all.begin() + (size_t)K);
+  if (K > 0 && hc[(size_t)K - 1].key != 0ull) {
+    ctx->sel_hint = abs_key_host(0.9 * key_to_double(hc[(size_t)K - 1].key));
+    ctx->sel_hint_K = K; ctx->sel_hint_m = m;
+  } else ctx->sel_hint = 0;
+  select_finish_host(hc, K, vkey, wkey, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr);
+  *loss_sum = tot[4] ? NAN : ((double)tot[2] + (double)tot[3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
+  *done = true;
   return KLR_OK;
 }
 
@@ -707,7 +843,27 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale_fx, S,
                                 &rowblk, &nrowblk, theta_inline ? theta_red : nullptr, theta_inline ? c_plus_1 : 0));
     const bool tr = scale != nullptr || offset != nullptr;
-    KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk, hint.tau ? &hint : nullptr));
+    // reduce-scatter form of the collective: wide matrices on several ranks with both hooks installed, nothing that
+    // needs the whole vector on every rank (g_out, a transform), a selection the one-workgroup sort can hold
+    static const i64 rs_min_dim = getenv("KLR_RS_MIN_DIM") ? atoll(getenv("KLR_RS_MIN_DIM")) : 131072;
+    const bool scatter = ctx->rs_fn && ctx->ag_fn && ctx->ar_fn && ctx->nranks > 1 && !tr && !g_out && dim >= rs_min_dim && 2 * N <= FAST_CAP && N >= 1;
+    if (scatter) {
+      const i64 slice = ceil_div(dim + IB_EXTRA, (i64)ctx->nranks);
+      i64* ibuf = nullptr;
+      KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, nullptr, nullptr, rowblk, nrowblk, nullptr, &ibuf, slice * ctx->nranks));
+      bool done = false;
+      double loss_sum_s = NAN;
+      KLR_TRY(sweep_select_scatter(ctx, full, scale_fx, ibuf, slice, N, b, c_prev, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, &loss_sum_s, &done));
+      if (done) {
+        if (loss_out) *loss_out = full->n_total ? loss_sum_s / (double)full->n_total : 0.0;
+        return KLR_OK;
+      }
+      ctx->sel_hist_zeroed = nullptr;                                // the slice selection used the same buffers: start clean
+      KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
+      KLR_TRY(sweep_fix_tail(ctx, full, scale_fx, ibuf, gbuf, keys, hist, nullptr));
+      hint_tau = 0;
+    } else
+      KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk, hint.tau ? &hint : nullptr));
     keys_ready = m > 0 && !tr;
   } else {
     // the row pass leaves the local loss partial in gbuf[dim]; [g | loss] in ONE f64 all-reduce

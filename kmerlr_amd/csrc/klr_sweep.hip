@@ -850,7 +850,6 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
 
 // ibuf layout (int64): [0, dim) column sums (slot 0 unused) | dim: bias hi | dim+1: bias lo |
 //                      dim+2: loss limb0 | dim+3: loss limb1 | dim+4: non-finite loss terms
-#define IB_EXTRA 5
 
 // 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile (4 independent
 // loads in flight), LDS combines.  FUSE (no all-reduce between the two steps, i.e. one rank and no hook): the
@@ -1065,7 +1064,7 @@ int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double
 
 // integer sweep over the packed stream, int64 all-reduce of [column sums | bias | loss], back to f64
 int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
-                     const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint) {
+                     const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint, i64** ibuf_out, i64 ibuf_elems) {
   const u64 tau = hint && keys ? hint->tau : 0ull;
   if (tau) hist = nullptr;                       // hinted: the coarse histogram is only built if the hint fails (select_from_device)
   Cand* hcand = hint ? hint->cand : nullptr;
@@ -1074,7 +1073,7 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   hipStream_t st = ctx->stream;
   i64 *S, *part, *ibuf;
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(n, 1) * 8, (void**)&S));
-  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)std::max<i64>(dim + IB_EXTRA, ibuf_elems) * 8, (void**)&ibuf));
   const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;      // width of a piece vector
   KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * pstride * 8, (void**)&part));
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1093,10 +1092,26 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
     hipLaunchKernelGGL(k_finish_coo<false>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
                        nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr);
     KLR_HIP(ctx, hipGetLastError());
-    KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
-    hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, st, ibuf, dim, 1.0 / scale, gbuf,
-                       keys, hist, tau, hcand, hcur);
+    if (ibuf_out) {                                // the caller runs the collective (reduce-scatter form, klr_select.hip)
+      if (ibuf_elems > dim + IB_EXTRA) KLR_HIP(ctx, hipMemsetAsync(ibuf + dim + IB_EXTRA, 0, (size_t)(ibuf_elems - dim - IB_EXTRA) * 8, st));
+      *ibuf_out = ibuf;
+      return KLR_OK;
+    }
+    return sweep_fix_tail(ctx, mat, scale, ibuf, gbuf, keys, hist, hint);
   }
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
+int sweep_fix_tail(klr_ctx* ctx, const klr_mat* mat, double scale, i64* ibuf, double* gbuf, u64* keys, u32* hist, const SelHint* hint) {
+  const u64 tau = hint && keys ? hint->tau : 0ull;
+  if (tau) hist = nullptr;
+  Cand* hcand = hint ? hint->cand : nullptr;
+  u32* hcur = hint ? &hint->ctl->cursor : nullptr;
+  const i64 dim = mat->dim;
+  KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
+  hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, ctx->stream, ibuf, dim,
+                     1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }

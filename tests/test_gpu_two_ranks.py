@@ -40,3 +40,14 @@ def test_two_ranks_one_gpu():
 def test_two_ranks_mixed_layouts():
     outs = run_two(29537, "mixed")
     assert "two ranks ok (mixed layouts)" in outs[0]
+
+
+def test_two_ranks_reduce_scatter_collective():
+    env_extra = {"KLR_RS_MIN_DIM": "1"}
+    os.environ.update(env_extra)
+    try:
+        outs = run_two(29541, "scatter")
+    finally:
+        for k in env_extra:
+            os.environ.pop(k, None)
+    assert "two ranks ok (scatter)" in outs[0]

@@ -35,6 +35,8 @@ def main():
     ctx.set_allreduce(hook, rank, world)
     if os.environ.get("KLR_TWO_RANK_MODE") == "mixed":
         return mixed_layouts(K, dist, ctx, rank, world, calls)
+    if os.environ.get("KLR_TWO_RANK_MODE") == "scatter":
+        return scatter_collective(K, dist, ctx, hip, rank, world, calls)
     rowptr, col, val, labels = K.synth_csr(20261004, rank * n_local, n_local, n_total, m, draws, 2 * N)
     shard = K.Matrix.from_csr(ctx, n_local, m + 1, rowptr, col, val, labels, n_total)
     assert shard.layout()["tiled"]
@@ -68,6 +70,79 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def scatter_collective(K, dist, ctx, hip, rank, world, calls):
+    """The sweep's collective as reduce-scatter + local top-2N + all-gather of the candidates (klr_ctx_set_collectives)
+    against the all-reduce form on the same shards: selection, lambda and loss must be BITWISE the same; whole leapfrog
+    runs through the driver must give identical classifiers."""
+    import torch
+    from kmerlr_amd import _driver
+    n_total, m, draws, N = 12000, 40000, 300, 25
+    n_local = n_total // world
+    cnt = {"rs": 0, "ag": 0}
+
+    def d2h(ptr, nbytes):
+        host = np.empty(nbytes, dtype=np.uint8)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+        return host
+
+    def h2d(ptr, host):
+        assert hip.hipMemcpy(C.c_void_p(ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes), 1) == 0
+
+    def rs_hook(send, recv, count, dtype, stream):
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        full = d2h(send, count * world * 8).view(np.int64 if dtype == 1 else np.float64).copy()
+        t = torch.from_numpy(full)
+        dist.all_reduce(t)                                            # gloo has no reduce-scatter: all-reduce, keep the own slice
+        h2d(recv, np.ascontiguousarray(full[rank * count:(rank + 1) * count]).view(np.uint8))
+        cnt["rs"] += 1
+
+    def ag_hook(send, recv, nbytes, stream):
+        hip.hipStreamSynchronize(C.c_void_p(stream))
+        mine = torch.from_numpy(d2h(send, nbytes).copy())
+        outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(outs, mine)
+        h2d(recv, np.concatenate([o.numpy() for o in outs]))
+        cnt["ag"] += 1
+
+    rowptr, col, val, labels = K.synth_csr(20261004, rank * n_local, n_local, n_total, m, draws, 2 * N)
+    shard = K.Matrix.from_csr(ctx, n_local, m + 1, rowptr, col, val, labels, n_total)
+    assert shard.layout()["tiled"]
+    cw = shard.class_weights()
+    # all-reduce form first (no extra hooks installed)
+    a0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
+    cols = np.nonzero(a0["b"])[0]
+    red = shard.select_columns(cols)
+    theta, _ = K.cd_solve(ctx, red, np.zeros(len(cols)), cw=cw, l1reg=a0["lam"] * n_total, eps_loss=1e-10)
+    a1 = K.sweep_select(ctx, shard, red, cols, theta, cw, N)
+    est = _driver.hip_estimator(ctx)
+    ca = est.estimate(shard._h, [10, N]); ea = est.epochs(); est.close()
+    at = K.sweep_select(ctx, shard, None, None, np.zeros(1), (1.0, 1.0), 400)     # tied count data, wide selection
+    i64_before = calls["i64"]
+    # reduce-scatter form
+    ctx.set_collectives(rs_hook, ag_hook)
+    s0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
+    s1 = K.sweep_select(ctx, shard, red, cols, theta, cw, N)
+    assert cnt["rs"] == 2 and cnt["ag"] == 2 and calls["i64"] == i64_before, (cnt, calls)     # no int64 all-reduce was posted
+    for a, s in ((a0, s0), (a1, s1)):
+        np.testing.assert_array_equal(a["b"], s["b"])
+        assert a["lam"] == s["lam"] and a["loss"] == s["loss"] and a["c"] == s["c"] and a["ok"] == s["ok"]
+    est = _driver.hip_estimator(ctx)
+    cs = est.estimate(shard._h, [10, N]); es = est.epochs(); est.close()
+    assert es == ea
+    for a, s in zip(ca, cs):
+        np.testing.assert_array_equal(a["cols"], s["cols"]); np.testing.assert_array_equal(a["theta"], s["theta"])
+    # tied count data at theta = 0 with a selection that straddles tie groups: the same result, through the candidates or
+    # -- when a rank's candidate list cannot prove the largest |g| below the N-th -- through the all-reduce fallback
+    st = K.sweep_select(ctx, shard, None, None, np.zeros(1), (1.0, 1.0), 400)
+    np.testing.assert_array_equal(at["b"], st["b"])
+    assert at["lam"] == st["lam"] and at["loss"] == st["loss"] and at["c"] == st["c"]
+    if rank == 0:
+        print("two ranks ok (scatter): lambda=%e rs=%d ag=%d" % (s0["lam"], cnt["rs"], cnt["ag"]))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def mixed_layouts(K, dist, ctx, rank, world, calls):
