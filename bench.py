@@ -204,7 +204,7 @@ def roofline_of(lay, alg_bytes, kern_avg_ms, launches, cold_avg_ms, n_local, nnz
 
 def load_traffic(lay, nnz, m):
     """HBM traffic of the sweep kernel from the committed PMC passes (profiles/): valid for this exact workload only."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r02_pmc_traffic.json", "r02_pmc_traffic_c3.json"):
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", name)))
             w = pj["workload"]

@@ -425,6 +425,14 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
 // pieces of a q64 stream: the 64-unit blocks are dealt to nwg workgroups in equal shares, a share snapped to a strip
 // boundary when one lies within a few percent of it; a share is cut into pieces where the strip changes
 static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64>& strip_unit, i64 nct) {
+  // first row of a block, read back from the device table (one entry per workgroup; rows + 1024 must stay inside S)
+  std::vector<u32> h_blkrow((size_t)(strip_unit[(size_t)nct] / 64));
+  KLR_HIP(ctx, hipMemcpy(h_blkrow.data(), m->t_blkrow, h_blkrow.size() * 4, hipMemcpyDeviceToHost));
+  const i64 n_rows = m->n;
+  auto h_blkrow_at = [&](u32 b) -> u32 {
+    const i64 r = b < h_blkrow.size() ? (i64)h_blkrow[b] : 0;
+    return (u32)std::max<i64>(0, std::min<i64>(r, n_rows - 1024));       // the warming load reads S[r .. r + 1024)
+  };
   const u64 total_blk = (u64)strip_unit[(size_t)nct] / 64;
   // one workgroup per CU (a piece vector written per (strip, workgroup): half as many as with two), KLR_Q64_WGS=2 for two
   const int per_cu = getenv("KLR_Q64_WGS") ? std::max(1, std::min(2, atoi(getenv("KLR_Q64_WGS")))) : 1;
@@ -476,18 +484,21 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
   }
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)std::max<u32>(npiece, 1) * 16));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 16));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 32));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
   KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
   {
-    // per workgroup: {first piece, end piece, first unit, end unit of the first piece}
-    std::vector<u32> rec((size_t)nwg * 4, 0u);
+    // per workgroup: {first piece, end piece, first unit, end unit of the first piece} {first row of its first block, -, -, -}
+    std::vector<u32> rec((size_t)nwg * 8, 0u);
     for (u32 w = 0; w < nwg; w++) {
-      rec[(size_t)w * 4] = wgp[w]; rec[(size_t)w * 4 + 1] = wgp[w + 1];
-      if (wgp[w] < wgp[w + 1]) { rec[(size_t)w * 4 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 4 + 3] = piece[(size_t)wgp[w] * 4 + 2]; }
+      rec[(size_t)w * 8] = wgp[w]; rec[(size_t)w * 8 + 1] = wgp[w + 1];
+      if (wgp[w] < wgp[w + 1]) {
+        rec[(size_t)w * 8 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 8 + 3] = piece[(size_t)wgp[w] * 4 + 2];
+        rec[(size_t)w * 8 + 4] = h_blkrow_at(piece[(size_t)wgp[w] * 4 + 1] / 64);
+      }
     }
-    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 16, hipMemcpyHostToDevice));
+    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 32, hipMemcpyHostToDevice));
   }
   KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));

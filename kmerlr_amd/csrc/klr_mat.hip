@@ -71,8 +71,8 @@ extern "C" int klr_mat_stream_info(const klr_mat* mat, int* format, int64_t* str
   const bool q64 = mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13;
   if (piece_bytes) *piece_bytes = t ? (mat->fmt == FMT_Q64C13 ? 8192 : (int64_t)TILE_DIM) * 8 : 0;
   // read by the sweep: piece records (16 B) and -- tiled formats: one 32-byte record per workgroup, tile offsets (4 B per
-  // tile); q64: a 16-byte record per workgroup, the first row of every 64-unit block (4 B per KiB of stream)
-  if (table_bytes) *table_bytes = !t ? 0 : q64 ? (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 16 + mat->total4 / 64 * 4
+  // tile); q64: a 32-byte record per workgroup, the first row of every 64-unit block (4 B per KiB of stream)
+  if (table_bytes) *table_bytes = !t ? 0 : q64 ? (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 32 + mat->total4 / 64 * 4
                                                : (int64_t)mat->npiece * 16 + (int64_t)mat->nwg * 32 + ((int64_t)mat->nrt * mat->nct + 2) * 4;
   return KLR_OK;
 }
