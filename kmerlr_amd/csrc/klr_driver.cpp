@@ -70,6 +70,7 @@ struct klr_estimator {
   std::vector<int64_t> ep_nonzero;
   // k-mer counter of the data (klr_estimator_set_kmer_features): kmerLr models are written with the reference's
   // KmerLrFeatures parameters
+  std::vector<klr_iter_rec> recs;     // scratch of solve_reduced
   bool has_kmer = false;
   klr_kmer_features kf{};
   std::vector<int> kf_max_amb;
@@ -158,11 +159,14 @@ static void adopt_selection(klr_estimator* e, const std::vector<uint8_t>& b) {
 
 // KmerLrEstimator.estimate (kmerLr_estimator.go:147-173): solve on the reduced data, append the path
 static int solve_reduced(klr_estimator* e, const klr_mat* red, int64_t n_total, double l1reg, std::vector<double>& theta) {
-  const int64_t cap = 1 << 16;
-  std::vector<klr_iter_rec> recs((size_t)cap);
+  // the hook records of one solve: kept in the estimator (an epoch allocates nothing), none asked for when nobody reads them
+  const bool want = e->cfg.save_trace || e->cfg.verbose > 1;
+  const int64_t cap = want ? (1 << 16) : 0;
+  if (want && e->recs.size() < (size_t)cap) e->recs.resize((size_t)cap);
+  std::vector<klr_iter_rec>& recs = e->recs;
   int64_t nrec = 0;
   int rc = e->be.cd_solve(e->be.ctx, red, theta.data(), e->cw, l1reg, e->cfg.l2reg, e->cfg.epsilon, e->cfg.epsilon_loss,
-                          e->cfg.eval_loss, e->cfg.max_iterations, recs.data(), cap, &nrec);
+                          e->cfg.eval_loss, e->cfg.max_iterations, want ? recs.data() : nullptr, cap, &nrec);
   if (rc != KLR_OK) return be_fail(e, rc, "cd_solve");
   const int64_t keep = std::min(nrec, cap);
   if (e->cfg.save_trace || e->cfg.verbose > 1) {

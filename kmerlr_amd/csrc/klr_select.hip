@@ -846,7 +846,9 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     // reduce-scatter form of the collective: wide matrices on several ranks with both hooks installed, nothing that
     // needs the whole vector on every rank (g_out, a transform), a selection the one-workgroup sort can hold
     static const i64 rs_min_dim = getenv("KLR_RS_MIN_DIM") ? atoll(getenv("KLR_RS_MIN_DIM")) : 131072;
-    const bool scatter = ctx->rs_fn && ctx->ag_fn && ctx->ar_fn && ctx->nranks > 1 && !tr && !g_out && dim >= rs_min_dim && 2 * N <= FAST_CAP && N >= 1;
+    static const bool rs_force = getenv("KLR_RS_FORCE") != nullptr;      // plumbing check: take the path with one rank too
+    const bool scatter = ctx->rs_fn && ctx->ag_fn && ctx->ar_fn && (ctx->nranks > 1 || rs_force) && !tr && !g_out && dim >= rs_min_dim &&
+                         2 * N <= FAST_CAP && N >= 1;
     if (scatter) {
       const i64 slice = ceil_div(dim + IB_EXTRA, (i64)ctx->nranks);
       i64* ibuf = nullptr;

@@ -1,6 +1,7 @@
 """GPU: the host driver over the HIP backend must follow the same leapfrog path as over the oracle
 backend; the all-reduce hook plumbing (f64 and int64) is exercised with an emulated second rank."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -8,6 +9,8 @@ import pytest
 import kmerlr_amd as K
 from oracle import oracle as O
 from tests import oracle_driver as OD
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -240,3 +243,36 @@ def test_full_size_estimate_kkt_and_reproducibility(ctx, monkeypatch):
     np.testing.assert_array_equal(cl3["cols"], cols)
     np.testing.assert_array_equal(cl3["theta"], theta)
     red.close(); full.close()
+
+
+def test_rccl_collectives_single_rank_plumbing(ctx):
+    """The library's own RCCL communicator with ONE rank (two ranks on one card are refused by RCCL; more cards are not on
+    the test box): all-reduce, and -- forced -- the reduce-scatter + all-gather form of the sweep's collective, run through
+    ncclAllReduce / ncclReduceScatter / ncclAllGather and must reproduce the hook-free results bit for bit."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import kmerlr_amd as K
+n, m, N = 6000, 30000, 20
+rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 300, 2 * N)
+base = K.Context(0)
+mb = K.Matrix.from_csr(base, n, m + 1, rowptr, col, val, labels)
+cw = mb.class_weights()
+r0 = K.sweep_select(base, mb, None, None, np.zeros(1), cw, N)
+ctx = K.Context(0)
+ctx.init_rccl(K.rccl_unique_id(), 0, 1)
+info = ctx.comm_info()
+assert info["rccl_ranks"] == 1 and info["nranks"] == 1, info
+mc = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
+r1 = K.sweep_select(ctx, mc, None, None, np.zeros(1), cw, N)           # KLR_RS_FORCE: reduce-scatter + all-gather
+assert r1["lam"] == r0["lam"] and r1["loss"] == r0["loss"] and r1["c"] == r0["c"] and np.array_equal(r1["b"], r0["b"])
+r2 = K.sweep_select(ctx, mc, None, None, np.zeros(1), cw, N, want_g=True)   # g_out: the all-reduce form
+assert r2["lam"] == r0["lam"] and np.array_equal(r2["b"], r0["b"])
+assert ctx.allreduce_time(m + 6, 1, 3) >= 0.0
+print("rccl single rank ok")
+''' % ROOT
+    env = dict(os.environ, KLR_RS_FORCE="1", KLR_RS_MIN_DIM="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl single rank ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
