@@ -261,6 +261,25 @@ __device__ __forceinline__ void rank_sort_1024(const Cand* src, Cand* dst, u32* 
   __syncthreads();
 }
 
+// the same for up to FAST_CAP candidates: a thread owns up to four of them (t, t + 1024, ...) and walks the whole list once
+// (every lane reads the same LDS word: a broadcast read), counting for each of its own how many come before it.
+// n = 1,300: 7 us (the bitonic network it replaces: 66 barrier stages, 65-75 us at 2,048 slots).  Ends with a barrier.
+__device__ __forceinline__ void rank_sort_big(const Cand* src, Cand* dst, u32 n) {
+  const u32 t = threadIdx.x;
+  Cand my[4]; u32 r[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const u32 e = t + 1024u * u; my[u] = e < n ? src[e] : Cand{0ull, 0xFFFFFFFFu, 0u}; }
+  const int cnt = (int)((n - 1u) / 1024u) + 1;          // owned slots in use (wave-uniform upper bound)
+  for (u32 j = 0; j < n; j++) {
+    const Cand c = src[j];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (u < cnt) r[u] += cand_before(c, my[u]) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { const u32 e = t + 1024u * u; if (e < n) dst[r[u]] = my[u]; }
+  __syncthreads();
+}
+
 // control block + histograms of the fast path (all zero between calls: k_fast_finish re-zeroes what was used)
 #define FINE_BINS 4096
 #define FINE_SHIFT 38
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u3
                                                       u32 K, u32 Nth, const Cand* __restrict__ gcand, FastState* st,
                                                       Cand* __restrict__ out, const double* __restrict__ extra_src,
                                                       double* __restrict__ extra_dst) {
-  extern __shared__ Cand sc[];                    // FAST_CAP candidates
+  extern __shared__ Cand sc[];                    // FAST_CAP candidates + FAST_CAP sorted
   __shared__ u32 ssum[1024], wtot[16];
   __shared__ unsigned long long wbest;
   __shared__ u32 s_cursor, s_fbin, s_nt;
@@ -391,22 +410,8 @@ __global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u3
     sorted = sc + 1024;
     rank_sort_1024(sc, sorted, ssum, nt);
   } else {
-    u32 P = 2; while (P < nt) P <<= 1;
-    for (u32 i = nt + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
-    __syncthreads();
-    for (u32 size = 2; size <= P; size <<= 1) {
-      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-        for (u32 q = t; q < P / 2; q += 1024) {
-          const u32 lo = 2 * q - (q & (stride - 1));
-          const u32 hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          Cand a = sc[lo], b = sc[hi];
-          const bool swap = up ? cand_before(b, a) : cand_before(a, b);
-          if (swap) { sc[lo] = b; sc[hi] = a; }
-        }
-        __syncthreads();
-      }
-    }
+    sorted = sc + FAST_CAP;
+    rank_sort_big(sc, sorted, nt);
   }
   for (u32 i = t; i < K && i < nt; i += 1024) out[i] = sorted[i];
   const u64 vkey = (Nth >= 1 && Nth <= nt) ? sorted[Nth - 1].key : 0ull;
@@ -422,12 +427,35 @@ __global__ __launch_bounds__(1024) void k_fast_finish(u32* __restrict__ hist, u3
 // Hinted selection: the candidate list was filled while the keys were produced (SelHint).  One workgroup sorts it;
 // if the hint was too high (fewer than K candidates) or far too low (more than FAST_CAP) it reports fallback = 2 and
 // leaves the histogram for the regular path.
+// Ranks of the hinted candidates over MANY workgroups: the n^2 comparisons of a rank sort are what a one-workgroup sort
+// spends its time on (n = 1,300 candidates at K = 1,000: 65 us on one CU, whatever the network).  FAST_RANK_WGS workgroups
+// each stage the whole list in LDS and rank their share (32 lanes per candidate, partial counts met by shuffles); a
+// candidate lands at sorted_dev[rank].  k_fast_direct then only copies.
+#define FAST_RANK_WGS 128
+__global__ __launch_bounds__(1024) void k_fast_rank(const FastCtl* __restrict__ ctl, u32 K, const Cand* __restrict__ gcand,
+                                                    Cand* __restrict__ sorted_dev) {
+  extern __shared__ Cand sc[];
+  const u32 n = ctl->cursor;
+  if (n < K || n > FAST_CAP) return;                 // k_fast_direct reports the fallback
+  const u32 t = threadIdx.x;
+  for (u32 i = t; i < n; i += 1024) sc[i] = gcand[i];
+  __syncthreads();
+  const u32 per = (n + FAST_RANK_WGS - 1) / FAST_RANK_WGS;       // <= 32 candidates per workgroup
+  const u32 cl = t >> 5, part = t & 31u;
+  const u32 ci = blockIdx.x * per + cl;
+  const bool valid = cl < per && ci < n;
+  const Cand my = valid ? sc[ci] : Cand{0ull, 0xFFFFFFFFu, 0u};
+  u32 r = 0;
+  if (valid) for (u32 j = part; j < n; j += 32u) r += cand_before(sc[j], my) ? 1u : 0u;
+  r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 16, 64);
+  if (valid && part == 0) sorted_dev[r] = my;
+}
+
 __global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ /*hist: untouched (not built when hinted)*/, FastCtl* __restrict__ ctl, u64 tau, u32 K, u32 Nth,
-                                                      const Cand* __restrict__ gcand, FastState* st, Cand* __restrict__ out,
+                                                      const Cand* __restrict__ sorted_dev, FastState* st, Cand* __restrict__ out,
                                                       const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
-  extern __shared__ Cand sc[];                    // FAST_CAP candidates
+  extern __shared__ Cand sc[];                    // the candidates, sorted by k_fast_rank
   __shared__ unsigned long long wbest;
-  __shared__ u32 srk[1024];
   const int t = threadIdx.x;
   if (t == 0 && extra_src) *extra_dst = *extra_src;
   const u32 n = ctl->cursor;
@@ -438,30 +466,9 @@ __global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ /*hist: 
     if (t == 0) { st->lowkey = tau; st->ncand = n; st->cursor = 0; st->fallback = 2; st->wfound = 0; st->vkey = 0; st->wkey = 0; }
     return;
   }
-  for (u32 i = t; i < n; i += 1024) sc[i] = gcand[i];
+  for (u32 i = t; i < n; i += 1024) sc[i] = sorted_dev[i];
   __syncthreads();
-  Cand* sorted = sc;
-  if (n <= 1024) {
-    sorted = sc + 1024;
-    rank_sort_1024(sc, sorted, srk, n);
-  } else {
-    u32 P = 2; while (P < n) P <<= 1;
-    for (u32 i = n + t; i < P; i += 1024) { sc[i].key = 0ull; sc[i].idx = 0xFFFFFFFFu; sc[i].pad = 0; }
-    __syncthreads();
-    for (u32 size = 2; size <= P; size <<= 1) {
-      for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-        for (u32 q = t; q < P / 2; q += 1024) {
-          const u32 lo = 2 * q - (q & (stride - 1));
-          const u32 hi = lo + stride;
-          const bool up = (lo & size) == 0;
-          Cand a = sc[lo], b = sc[hi];
-          const bool swap = up ? cand_before(b, a) : cand_before(a, b);
-          if (swap) { sc[lo] = b; sc[hi] = a; }
-        }
-        __syncthreads();
-      }
-    }
-  }
+  const Cand* sorted = sc;
   for (u32 i = t; i < K; i += 1024) out[i] = sorted[i];
   const u64 vkey = (Nth >= 1 && Nth <= n) ? sorted[Nth - 1].key : 0ull;
   for (u32 i = t; i < n; i += 1024)
@@ -568,7 +575,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
     // WS_TMP0: GCAND_CAP compacted candidates.  The result -- [FastState (40 B) + caller scalar | K sorted candidates],
     // 3 KB -- is written by k_fast_finish straight into pinned host memory (device-visible, coherent): no copy kernel
-    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)GCAND_CAP * sizeof(Cand), (void**)&cand));
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&cand));
     char* pin;
     KLR_TRY(pin_get(ctx, 64 + (size_t)K * sizeof(Cand), (void**)&pin));
     FastState* fs = (FastState*)pin;
@@ -581,8 +588,10 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     static bool attr = false;
     if (!attr) {
       KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(FAST_CAP * sizeof(Cand))));
+                                       (int)(2 * FAST_CAP * sizeof(Cand))));
       KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_direct, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(2 * FAST_CAP * sizeof(Cand))));
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_rank, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(FAST_CAP * sizeof(Cand))));
       attr = true;
     }
@@ -590,7 +599,9 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     if (hint_tau != 0 && keys_hist_ready) {
       // the candidates are already in `cand` (SelHint): one sort kernel, no pass over the keys
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
-      hipLaunchKernelGGL(k_fast_direct, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, ctl, hint_tau, (u32)K, (u32)N, cand, fs, out,
+      Cand* sorted_dev = cand + GCAND_CAP;             // WS_TMP0 holds the candidates and, behind them, their sorted copy
+      hipLaunchKernelGGL(k_fast_rank, dim3(FAST_RANK_WGS), dim3(1024), FAST_CAP * sizeof(Cand), st, (const FastCtl*)ctl, (u32)K, (const Cand*)cand, sorted_dev);
+      hipLaunchKernelGGL(k_fast_direct, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, ctl, hint_tau, (u32)K, (u32)N, (const Cand*)sorted_dev, fs, out,
                          extra_src, extra_dst);
       KLR_HIP(ctx, hipGetLastError());
       KLR_HIP(ctx, hipStreamSynchronize(st));
@@ -604,7 +615,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
       }
       const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 4096), 256));
       hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m, (u32)K, cand);
-      hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K, (u32)N,
+      hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), 2 * FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K, (u32)N,
                          cand, fs, out, extra_src, extra_dst);
       KLR_HIP(ctx, hipGetLastError());
       KLR_HIP(ctx, hipStreamSynchronize(st));
@@ -715,18 +726,18 @@ static int sweep_select_scatter(klr_ctx* ctx, const klr_mat* full, double scale_
   if (K_s > 0) {
     u64* keys; u32* hist; Cand* cand;
     KLR_TRY(sel_prepare(ctx, m_s, &keys, &hist));
-    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)GCAND_CAP * sizeof(Cand), (void**)&cand));
+    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&cand));
     FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
     hipLaunchKernelGGL(k_slice_keys, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 1024), 256))), dim3(256), 0, st, rbuf, lo, feat0,
                        m_s, 1.0 / scale_fx, keys, hist);
     static bool attr = false;
     if (!attr) {
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FAST_CAP * sizeof(Cand))));
+      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * FAST_CAP * sizeof(Cand))));
       attr = true;
     }
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 4096), 256));
     hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m_s, (u32)K_s, cand);
-    hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K_s, (u32)std::min<i64>(N, K_s),
+    hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), 2 * FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K_s, (u32)std::min<i64>(N, K_s),
                        cand, (FastState*)sendb, (Cand*)(sendb + SCAT_HDR), (const double*)nullptr, (double*)nullptr);
   }
   hipLaunchKernelGGL(k_slice_extras, dim3(1), dim3(64), 0, st, rbuf, lo, slice, dim, (i64*)(sendb + 64), (u32)m_s, (u32)K_s);
@@ -810,12 +821,17 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   bool theta_inline = false;
   bool use_int;                                        // integer stream on EVERY rank, or the f64 protocol on every rank
   KLR_TRY(sweep_protocol(ctx, full, &use_int));
-  memset(b, 0, (size_t)dim);
-  b[0] = 1;
+  // the mask itself (dim bytes: 1 MB at a million columns, 20 us of the host's time) is written once the kernels are
+  // queued -- restore_b below -- so that the device is already busy while the host clears it
+  auto restore_b = [&]() {
+    memset(b, 0, (size_t)dim);
+    b[0] = 1;
+    if (reduced) for (i64 p = 1; p < c_plus_1; p++) if (theta_red[p] != 0.0) b[red_cols[p]] = 1;
+  };
   if (reduced) {
     for (i64 p = 1; p < c_plus_1; p++) {
       KLR_ARG(ctx, red_cols[p] > 0 && red_cols[p] < dim);
-      if (theta_red[p] != 0.0) { b[red_cols[p]] = 1; c_prev++; }
+      if (theta_red[p] != 0.0) c_prev++;
     }
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
     // count data and a small reduced problem: theta rides in the row pass's kernel arguments (a 1 KB upload
@@ -823,7 +839,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     theta_inline = use_int && c_plus_1 <= 128;
     if (!theta_inline) KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
   }
-  bool keys_ready = false;
+  bool keys_ready = false, restored = false;
   u64 hint_tau = 0;
   if (use_int) {
     // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
@@ -832,7 +848,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
     SelHint hint{0ull, nullptr, nullptr};
     if (ctx->sel_hint != 0 && ctx->sel_hint_K == std::min<i64>(m, 2 * N) && ctx->sel_hint_m == m && !(scale || offset)) {
-      KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)GCAND_CAP * sizeof(Cand), (void**)&hint.cand));
+      KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&hint.cand));
       hint.tau = ctx->sel_hint;
       hint.ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
       hint_tau = hint.tau;
@@ -855,6 +871,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
       KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, nullptr, nullptr, rowblk, nrowblk, nullptr, &ibuf, slice * ctx->nranks));
       bool done = false;
       double loss_sum_s = NAN;
+      restore_b(); restored = true;
       KLR_TRY(sweep_select_scatter(ctx, full, scale_fx, ibuf, slice, N, b, c_prev, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, &loss_sum_s, &done));
       if (done) {
         if (loss_out) *loss_out = full->n_total ? loss_sum_s / (double)full->n_total : 0.0;
@@ -873,6 +890,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     else         KLR_TRY(launch_row_const(ctx, full, theta_red[0], ROW_SWEEP, cw, s, nullptr, gbuf + dim));
     KLR_TRY(sweep_all(ctx, full, cw, s, nullptr, gbuf));
   }
+  if (!restored) restore_b();
   if (scale || offset) KLR_TRY(apply_transform_dev(ctx, gbuf, dim, scale, offset));
   // g_out is the gradient the selection sees (transformed like klr_gradient's), kmerLr_logistic_regression.go:196-222
   if (g_out) KLR_HIP(ctx, hipMemcpyAsync(g_out, gbuf, (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -880,9 +880,15 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
                                                      const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
                                                      const i64* __restrict__ rowblk, i64 nrowblk, u32 CT, u32 PSTRIDE,
                                                      double inv_scale, double* __restrict__ g, u64* __restrict__ keys,
-                                                     u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
+                                                     u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor,
+                                                     u32 ITER) {
   __shared__ i64 sh[4][256];
   __shared__ u32 shh[FUSE ? FAST_BINS : 1];
+  // hinted compaction: the workgroup gathers its candidates in LDS and claims their slots with ONE atomic on the global
+  // cursor (a thousand same-address atomics, one per candidate, took 15 us of this kernel at a million columns)
+  __shared__ Cand wcand[FUSE ? 256 : 1];
+  __shared__ u32 wcnt, wbase;
+  if (threadIdx.x == 0) wcnt = 0u;
   if (blockIdx.x == gridDim.x - 1) {
     // last block: bias halves, loss limbs and the non-finite count from the row pass's block partials
     if (rowblk) {
@@ -915,8 +921,9 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
     return;
   }
   const int cx = threadIdx.x & 255, ly = threadIdx.x >> 8;
-  const i64 j = (i64)blockIdx.x * 256 + cx;
   if (FUSE && hist) { for (int i = threadIdx.x; i < FAST_BINS; i += 1024) shh[i] = 0u; }
+  for (u32 it = 0; it < ITER; it++) {
+  const i64 j = ((i64)blockIdx.x * ITER + it) * 256 + cx;
   i64 v = 0;
   if (j < dim) {
     const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
@@ -942,11 +949,23 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
         keys[j - 1] = kk;
         if (hist) atomicAdd(&shh[(u32)(kk >> FAST_SHIFT)], 1u);
         if (tau != 0ull && kk >= tau) {                       // hinted compaction (SelHint)
-          const u32 pos = atomicAdd(cursor, 1u);
-          if (pos < GCAND_CAP) { cand[pos].key = kk; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
+          const u32 wp = atomicAdd(&wcnt, 1u);
+          if (wp < 256u) { wcand[wp].key = kk; wcand[wp].idx = (u32)(j - 1); wcand[wp].pad = 0; }
+          else {
+            const u32 pos = atomicAdd(cursor, 1u);
+            if (pos < GCAND_CAP) { cand[pos].key = kk; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
+          }
         }
       }
     } else ibuf[j] = sum;
+  }
+  __syncthreads();                                            // sh is reused by the next column group
+  }
+  if (FUSE && tau != 0ull) {
+    if (threadIdx.x == 0) { const u32 nw = min(wcnt, 256u); wbase = nw ? atomicAdd(cursor, nw) : 0u; }
+    __syncthreads();
+    const u32 nw = min(wcnt, 256u);
+    if (threadIdx.x < nw && wbase + threadIdx.x < GCAND_CAP) cand[wbase + threadIdx.x] = wcand[threadIdx.x];
   }
   if (FUSE && hist) {
     __syncthreads();
@@ -996,8 +1015,13 @@ __global__ __launch_bounds__(256) void k_fix_s(const double* __restrict__ s, con
 __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, i64 dim, double inv_scale,
                                                   double* __restrict__ g, u64* __restrict__ keys, u32* __restrict__ hist,
                                                   u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
-  // grid-stride; the coarse key histogram is privatised in LDS (most keys share a few bins)
+  // grid-stride; the coarse key histogram is privatised in LDS (most keys share a few bins); hinted candidates are
+  // gathered per workgroup and claim their slots with one atomic on the global cursor
   __shared__ u32 sh[FAST_BINS];
+  __shared__ Cand wcand[256];
+  __shared__ u32 wcnt, wbase;
+  if (threadIdx.x == 0) wcnt = 0u;
+  __syncthreads();
   if (hist) {
     for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
     __syncthreads();
@@ -1013,8 +1037,12 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
         keys[j - 1] = k;
         if (hist) atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
         if (tau != 0ull && k >= tau) {                          // hinted compaction (SelHint)
-          const u32 pos = atomicAdd(cursor, 1u);
-          if (pos < GCAND_CAP) { cand[pos].key = k; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
+          const u32 wp = atomicAdd(&wcnt, 1u);
+          if (wp < 256u) { wcand[wp].key = k; wcand[wp].idx = (u32)(j - 1); wcand[wp].pad = 0; }
+          else {
+            const u32 pos = atomicAdd(cursor, 1u);
+            if (pos < GCAND_CAP) { cand[pos].key = k; cand[pos].idx = (u32)(j - 1); cand[pos].pad = 0; }
+          }
         }
       }
     } else {
@@ -1022,6 +1050,13 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
       const double l = ((double)ibuf[dim + 2] + (double)ibuf[dim + 3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
       g[dim] = ibuf[dim + 4] ? nan("") : l;
     }
+  }
+  if (tau != 0ull) {
+    __syncthreads();
+    if (threadIdx.x == 0) { const u32 nw = min(wcnt, 256u); wbase = nw ? atomicAdd(cursor, nw) : 0u; }
+    __syncthreads();
+    const u32 nw = min(wcnt, 256u);
+    if (threadIdx.x < nw && wbase + threadIdx.x < GCAND_CAP) cand[wbase + threadIdx.x] = wcand[threadIdx.x];
   }
   if (hist) {
     __syncthreads();
@@ -1104,14 +1139,16 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   }
   KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1));
   if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
-  const dim3 fgrid((unsigned)ceil_div(dim, 256) + 1);
+  // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
+  const u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
+  const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
   if (!ctx->ar_fn) {
     // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
     hipLaunchKernelGGL(k_finish_coo<true>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
+                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
   } else {
     hipLaunchKernelGGL(k_finish_coo<false>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr);
+                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
     KLR_HIP(ctx, hipGetLastError());
     if (ibuf_out) {                                // the caller runs the collective (reduce-scatter form, klr_select.hip)
       if (ibuf_elems > dim + IB_EXTRA) KLR_HIP(ctx, hipMemsetAsync(ibuf + dim + IB_EXTRA, 0, (size_t)(ibuf_elems - dim - IB_EXTRA) * 8, st));
