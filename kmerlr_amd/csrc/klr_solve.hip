@@ -383,6 +383,106 @@ __global__ __launch_bounds__(256) void k_gram_reduce_assemble(const unsigned lon
   else if (k == 0) G[t] = a0[j];
 }
 
+// =================================================================================================
+// Dense-panel Gram on the matrix cores (north_star: "MFMA used only if the selected-feature block is materialised as a
+// dense panel"; the reference's dense inputs are the scoresLr tables, every column stored: scoresLr_data.go:108-117).
+// When every row of the reduced matrix holds all d entries, its CSR value array IS the row-major n x d panel X, and
+// G = X' diag(w) X is a GEMM with K = n: v_mfma_f64_16x16x4_f64, D[i][j] += sum_k A[i][k] B[k][j] with
+// A[i][k] = w_k x[k][16 ta + i], B[k][j] = x[k][16 tb + j] (lane l: A row l & 15, k = l >> 4; B column l & 15, k = l >> 4;
+// C/D column l & 15, row (l >> 4) + 4 reg).  A workgroup stages GD_ROWS rows of the panel (and w) in LDS, its 16
+// wavefronts share the upper-triangle tiles; row blocks are dealt to the workgroups; every workgroup writes its partial
+// tiles and k_gram_dense_reduce adds them in block order (deterministic) and mirrors.  The sparse builds above spend one
+// LDS atomic per pair: n d^2 / 2 of them on dense rows (5e8 at n = 100k, d = 101).
+// =================================================================================================
+#define GD_ROWS 32
+#define GD_MAXD 256
+typedef double gd_double4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void k_gram_dense_mfma(const double* __restrict__ X, const double* __restrict__ w, i64 n, int d,
+                                                          double* __restrict__ part) {
+  extern __shared__ double gd_lds[];
+  const int T = (d + 15) >> 4, dpad = T * 16 + 2;        // + 2 doubles: rows of a fragment fall into different banks
+  double* xs = gd_lds;                                   // GD_ROWS x dpad
+  double* ws = gd_lds + GD_ROWS * dpad;                  // GD_ROWS
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntile = T * (T + 1) / 2;
+  constexpr int MAXOWN = (GD_MAXD / 16) * (GD_MAXD / 16 + 1) / 2 / 16 + 1;     // 9 tiles per wavefront at d = 256
+  gd_double4 acc[MAXOWN];
+  int ta_[MAXOWN], tb_[MAXOWN];
+  int nown = 0;
+  {
+    int q = 0;
+    for (int ta = 0; ta < T; ta++) for (int tb = ta; tb < T; tb++, q++)
+      if ((q & 15) == wave && nown < MAXOWN) { ta_[nown] = ta; tb_[nown] = tb; nown++; }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXOWN; u++) acc[u] = gd_double4{0.0, 0.0, 0.0, 0.0};
+  const i64 nblk = (n + GD_ROWS - 1) / GD_ROWS;
+  for (i64 blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const i64 r0 = blk * GD_ROWS;
+    __syncthreads();                                     // the previous chunk has been consumed
+    for (int idx = tid; idx < GD_ROWS * dpad; idx += 1024) {
+      const int row = idx / dpad, c = idx - row * dpad;
+      xs[idx] = (c < d && r0 + row < n) ? X[(r0 + row) * d + c] : 0.0;
+    }
+    if (tid < GD_ROWS) ws[tid] = (r0 + tid < n) ? w[r0 + tid] : 0.0;
+    __syncthreads();
+    const int kk = lane >> 4, cc = lane & 15;
+#pragma unroll
+    for (int u = 0; u < MAXOWN; u++) {
+      if (u < nown) {
+        const int ca = ta_[u] * 16 + cc, cb = tb_[u] * 16 + cc;
+#pragma unroll
+        for (int k = 0; k < GD_ROWS; k += 4) {
+          const double a = xs[(k + kk) * dpad + ca] * ws[k + kk];
+          const double b = xs[(k + kk) * dpad + cb];
+          acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[u], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial tiles, raw accumulator layout: [block][tile q][reg][lane]
+  {
+    int q = 0, u = 0;
+    for (int ta = 0; ta < T; ta++) for (int tb = ta; tb < T; tb++, q++)
+      if ((q & 15) == wave && u < MAXOWN) {
+        double* o = part + ((size_t)blockIdx.x * ntile + q) * 256;
+        o[lane] = acc[u].x; o[64 + lane] = acc[u].y; o[128 + lane] = acc[u].z; o[192 + lane] = acc[u].w;
+        u++;
+      }
+  }
+}
+
+// cell (a, b), a <= b: sum of its partials in block order; row / column 0 and the diagonal from the column sums like
+// k_gram_assemble (a0 = sum w x, nm = sum w x^2: the operands the solver uses elsewhere); G symmetric
+__global__ __launch_bounds__(256) void k_gram_dense_reduce(const double* __restrict__ part, int nblk, int d, const double* __restrict__ a0,
+                                                           const double* __restrict__ nm, int use_sums, double* __restrict__ G) {
+  const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (i64)d * d) return;
+  const int a = (int)(t / d), b = (int)(t % d);
+  if (a > b) return;
+  double v;
+  if (use_sums && a == b) v = nm[a];
+  else if (use_sums && a == 0) v = a0[b];
+  else {
+    const int T = (d + 15) >> 4, ntile = T * (T + 1) / 2;
+    const int ta = a >> 4, tb = b >> 4, i = a & 15, j = b & 15;
+    const int q = ta * T - ta * (ta - 1) / 2 + (tb - ta);
+    const int lane = j + 16 * (i & 3), reg = i >> 2;                    // C/D: column = lane & 15, row = (lane >> 4) + 4 reg
+    v = 0.0;
+    for (int k = 0; k < nblk; k++) v += part[((size_t)k * ntile + q) * 256 + reg * 64 + lane];
+  }
+  G[(i64)a * d + b] = v;
+  G[(i64)b * d + a] = v;
+}
+
+// several ranks: after the all-reduce of the local partial Grams, row / column 0 and the diagonal from the all-reduced sums
+__global__ __launch_bounds__(256) void k_gram_dense_fix(const double* __restrict__ a0, const double* __restrict__ nm, int d, double* __restrict__ G) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= d) return;
+  G[(i64)j * d + j] = nm[j];
+  if (j > 0) { G[j] = a0[j]; G[(i64)j * d] = a0[j]; }
+}
+
 // G from its parts: row/column 0 and the diagonal from the column sweeps, the rest from the integers
 __global__ __launch_bounds__(256) void k_gram_assemble(const double* __restrict__ a0, const double* __restrict__ nm,
                                                        const i64* __restrict__ Gi, const double* __restrict__ sc, int d,
@@ -1355,13 +1455,19 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // one Gram row per workgroup once there are enough columns to fill the chip with workgroups (KLR_GRAM_ROWS_MIN)
   const int gram_rows_min = getenv("KLR_GRAM_ROWS_MIN") ? atoi(getenv("KLR_GRAM_ROWS_MIN")) : 384;
   const bool gram_rows = !gram_lds && d > 128 && d >= gram_rows_min && gram_many && (size_t)d * 8 <= 128 * 1024 && red->d_collen != nullptr;
+  // every row stores all d columns (dense score tables): the value array is the n x d panel -> Gram on the matrix cores
+  const bool gram_dense_ok = red->nnz == n * (i64)d && d >= 2 && d <= GD_MAXD && n >= 256 && !getenv("KLR_GRAM_NO_MFMA");
+  const bool gram_dense = gram_dense_ok && (!gram_env || gram_env[0] == 'm');
+  const unsigned gram_dense_blocks = gram_dense ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n, (i64)GD_ROWS))) : 0u;
   const bool gram_tiled = !gram_lds && !gram_rows && (size_t)d * d * 8 > 128 * 1024 && d <= 1024 && gram_many;
   const unsigned gram_groups = gram_tiled ? (unsigned)std::max<i64>(1, std::min<i64>(std::max(1, ctx->n_cu / gram_npairs), ceil_div(n, 2 * 1024))) : 0u;
   if (gram_tiled) {
     static bool attr = false;
     if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, GT * GT * 8)); attr = true; }
   }
-  const size_t gram_part_bytes = gram_tiled ? (size_t)gram_npairs * gram_groups * GT * GT * 8 : (size_t)gram_blocks * d * d * 8;
+  const int gd_T = (d + 15) / 16;
+  const size_t gram_dense_bytes = gram_dense ? (size_t)gram_dense_blocks * (gd_T * (gd_T + 1) / 2) * 256 * 8 : 0;
+  const size_t gram_part_bytes = std::max(gram_dense_bytes, gram_tiled ? (size_t)gram_npairs * gram_groups * GT * GT * 8 : (size_t)gram_blocks * d * d * 8);
   const size_t gram_toff_bytes = gram_tiled ? (size_t)n * (gram_nt + 1) * sizeof(unsigned short) : 0;
   KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8 + gram_part_bytes + gram_toff_bytes, (void**)&G));
   unsigned short* gram_toff = (unsigned short*)((char*)G + (size_t)2 * d * d * 8 + gram_part_bytes);
@@ -1434,9 +1540,26 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     }
     DBG_STEP("irls sums");
     // the LDS-privatised build writes whole partials and the reduce overwrites the result slot: nothing to zero
-    if ((!gram_lds && !gram_tiled && !gram_rows) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
+    if ((!gram_lds && !gram_tiled && !gram_rows && !gram_dense) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     bool assembled = false;
-    if (n) {
+    if (n && gram_dense) {
+      static bool attr = false;
+      if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+      double* gpart = (double*)(Gi + (size_t)d * d);
+      const size_t lds = ((size_t)GD_ROWS * (gd_T * 16 + 2) + GD_ROWS) * 8;
+      hipLaunchKernelGGL(k_gram_dense_mfma, dim3(gram_dense_blocks), dim3(1024), lds, st, (const double*)red->val, w, n, d, gpart);
+      if (single) {
+        hipLaunchKernelGGL(k_gram_dense_reduce, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, (const double*)gpart, (int)gram_dense_blocks, d,
+                           a0, nm, 1, G);
+      } else {
+        // local partial Gram in f64, summed over the ranks, then row / column 0 and the diagonal from the all-reduced sums
+        hipLaunchKernelGGL(k_gram_dense_reduce, dim3((unsigned)ceil_div((i64)d * d, 256)), dim3(256), 0, st, (const double*)gpart, (int)gram_dense_blocks, d,
+                           a0, nm, 0, G);
+        KLR_TRY(klr_allreduce(ctx, G, (i64)d * d, KLR_F64));
+        hipLaunchKernelGGL(k_gram_dense_fix, dim3((unsigned)ceil_div((i64)d, 256)), dim3(256), 0, st, (const double*)a0, (const double*)nm, d, G);
+      }
+      assembled = true;
+    } else if (n) {
       if (gram_lds) {
         hipLaunchKernelGGL(k_gram_offdiag<true>, dim3(gram_blocks), dim3(1024), (size_t)d * d * 8, st, red->rowptr, red->col,
                            (const double*)red->val, w, n, d, gsc, (unsigned long long*)Gi);

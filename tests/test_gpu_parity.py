@@ -603,3 +603,33 @@ def test_tiled_ragged_rows_and_empty_tiles(ctx, entry_format):
     assert_g_close(r["g"], O.gradient(x, labels, np.zeros(x.dim)))
     rp, cc, vv = mat.to_csr()
     np.testing.assert_array_equal(rp, x.rowptr); np.testing.assert_array_equal(cc, x.col); np.testing.assert_array_equal(vv, x.val)
+
+
+@pytest.mark.parametrize("n,m", [(4000, 60), (3000, 255), (700, 17)])
+def test_dense_panel_mfma_gram(ctx, n, m, monkeypatch):
+    """Dense score tables (every column stored, scoresLr_data.go:108-117): the reduced matrix is a dense n x d panel and
+    the Gram matrix of a re-weighting is built on the matrix cores (k_gram_dense_mfma, v_mfma_f64_16x16x4_f64).  The
+    solve must follow the oracle's iterate sequence (theta within 1e-6) and agree with the sparse Gram builds."""
+    rng = np.random.default_rng(12)
+    dense = np.c_[np.ones(n), rng.normal(size=(n, m))]
+    beta = np.zeros(m + 1); beta[1:9] = rng.normal(size=8)
+    labels = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-dense @ beta))).astype(np.uint8)
+    rowptr = np.arange(n + 1, dtype=np.int64) * (m + 1)
+    col = np.tile(np.arange(m + 1, dtype=np.int64), n)
+    x = O.Csr(n, m + 1, rowptr, col, dense.reshape(-1).copy())
+    mat = upload(ctx, x, labels)
+    assert not mat.layout()["tiled"]
+    cw = O.class_weights(labels)
+    cols = np.arange(m + 1)
+    red = mat.select_columns(cols)
+    assert red.nnz == n * (m + 1)
+    l1 = 0.02 * n
+    th, recs = K.cd_solve(ctx, red, np.zeros(m + 1), cw=cw, l1reg=l1, eps_loss=1e-10, max_iter=80)
+    tho, reco = O.cd_solve(x, labels, np.zeros(m + 1), cw=cw, l1reg=l1, eps_loss=1e-10, max_iter=80)
+    assert [a["iteration"] for a in recs] == [a["iteration"] for a in reco]
+    assert [a["nonzero"] for a in recs] == [a["nonzero"] for a in reco]
+    np.testing.assert_allclose(th, tho, rtol=THETA_RTOL, atol=1e-10)
+    monkeypatch.setenv("KLR_GRAM_NO_MFMA", "1")
+    th2, recs2 = K.cd_solve(ctx, red, np.zeros(m + 1), cw=cw, l1reg=l1, eps_loss=1e-10, max_iter=80)
+    assert len(recs2) == len(recs)
+    np.testing.assert_allclose(th, th2, rtol=1e-8, atol=1e-12)
