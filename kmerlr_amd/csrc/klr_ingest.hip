@@ -396,6 +396,74 @@ __global__ __launch_bounds__(256) void k_q64_fill(const i64* __restrict__ rowptr
   if (cur != 0xFFFFFFFFu && (p & 3u)) ent[qpos++] = w;
 }
 
+// Bank-aware column order.  The sweep's k-th LDS atomic of a step adds to column slot k of every lane's unit.  An 8-byte
+// LDS atomic is serviced like an 8-byte store: the wave-instruction's 64 addresses go through in four groups of 16
+// consecutive lanes, the bank of byte address a is (a / 4) mod 32, so an accumulator covers one of 16 bank pairs,
+// (column mod 16); a group takes one LDS cycle per lane on its fullest bank pair.  Columns in ascending order leave
+// that to chance (16 lanes on 16 bank pairs: 3.1 on the fullest, ~12.3 cycles per instruction); with at most two lanes
+// per bank pair in every group the instruction costs what its address and data transfer costs anyway (8 - 9.6 cycles,
+// tools/lds_probe2.hip).  Which slot of its quad a column sits in carries no meaning (all four get the row's S), nor
+// which of a unit's two quads when both name the same row: this pass permutes the columns inside every lane's unit so
+// that no bank pair is wanted by three or more lanes of a 16-lane group in the same slot.  One wavefront per 64-unit
+// block, a parallel local search: count, every lane on an over-subscribed (slot, residue) proposes a swap with one of
+// its own slots where both columns find room, half of the lanes (a hash of position and round) act per round, a few
+// rounds.  Deterministic; the sums are integers, so the sweep's result does not depend on the order.
+__global__ __launch_bounds__(64) void k_q64_bank_order(uint4* __restrict__ ent, int CB, int rounds) {
+  __shared__ u32 cnt[4 * 8 * 16];
+  const u32 lane = threadIdx.x;
+  const size_t pos = (size_t)blockIdx.x * 64 + lane;
+  const uint4 e = ent[pos];
+  const unsigned long long qa = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+  const unsigned long long qb = (unsigned long long)e.z | ((unsigned long long)e.w << 32);
+  const int rsh = 4 * CB;
+  const u32 CM = (1u << CB) - 1u;
+  u32 c[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { c[i] = (u32)(qa >> (CB * i)) & CM; c[4 + i] = (u32)(qb >> (CB * i)) & CM; }
+  const bool same = (qa >> rsh) == (qb >> rsh);
+  u32* my = cnt + (lane >> 4) * 128u;
+  bool changed = false;
+  for (int it = 0; it < rounds; it++) {
+    for (u32 i = lane; i < 512u; i += 64u) cnt[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; s++) atomicAdd(&my[s * 16 + (c[s] & 15u)], 1u);
+    __syncthreads();
+    u32 hsh = (u32)pos * 2654435761u + (u32)it * 0x9E3779B9u;
+    hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12;
+    const bool act = (hsh & 1u) != 0u;
+    bool bad = false, moved = false;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      const u32 r = c[s] & 15u;
+      if (my[s * 16 + r] >= 3u) {
+        bad = true;
+        if (act && !moved) {
+#pragma unroll
+          for (int s2 = 0; s2 < 8; s2++) {
+            if (s2 == s) continue;
+            if (!same && (s2 >> 2) != (s >> 2)) continue;
+            const u32 r2 = c[s2] & 15u;
+            if (!moved && r2 != r && my[s2 * 16 + r] < 2u && my[s * 16 + r2] < 2u) {
+              const u32 t = c[s]; c[s] = c[s2]; c[s2] = t;
+              moved = true;
+            }
+          }
+        }
+      }
+    }
+    changed |= moved;
+    if (!__any((int)bad)) break;
+    __syncthreads();
+  }
+  if (changed) {
+    unsigned long long na = (qa >> rsh) << rsh, nb = (qb >> rsh) << rsh;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { na |= (unsigned long long)c[i] << (CB * i); nb |= (unsigned long long)c[4 + i] << (CB * i); }
+    ent[pos] = make_uint4((u32)na, (u32)(na >> 32), (u32)nb, (u32)(nb >> 32));
+  }
+}
+
 // the stream pre-filled with null unit entries (row 4095, column 0): bytes FF 0F 00 repeating
 __global__ __launch_bounds__(256) void k_fill_u24_null(u32* __restrict__ w, i64 nwords) {
   const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -439,23 +507,43 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
   const u32 nwg = (u32)std::max(2, per_cu * ctx->n_cu);
   std::vector<u64> sb((size_t)nct + 1);
   for (i64 t = 0; t <= nct; t++) sb[(size_t)t] = (u64)strip_unit[(size_t)t] / 64;
+  // The kernel ends when its slowest workgroup does.  Equal shares of the blocks, with two corrections: a cut within
+  // 4 % of a share of a strip boundary is snapped to it (a piece is 2^CB x 8 bytes written and read back: not worth a
+  // sliver of a strip), and a share that still crosses a boundary pays for its second piece -- a second vector zeroed
+  // and written out, its wavefronts' pipelines started a second time: 1 - 2 us, tools/q64_phases.py -- with
+  // KLR_Q64_PIECE_COST blocks (default 40), which all shares carry in proportion (first pass: how many cross).
+  // KLR_Q64_CUT=snap leaves the crossing shares whole (A/B).
   std::vector<u64> cut((size_t)nwg + 1);
   {
-    const char* sn = getenv("KLR_CUT_SNAP");
-    const double tolf = sn ? atof(sn) : 0.08;
-    i64 t = 0;
-    cut[0] = 0;
-    for (u32 w = 1; w <= nwg; w++) {
-      const u64 prev = cut[w - 1];
-      const u64 share = (total_blk - prev) / (u64)(nwg - w + 1);
-      const u64 ideal = prev + share;
-      const double tol = tolf * (double)share;
-      while (t < nct && sb[(size_t)t + 1] <= ideal) t++;
-      u64 c = ideal;
-      const u64 lo = sb[(size_t)t], hi = t < nct ? sb[(size_t)t + 1] : total_blk;
-      if (lo > prev && (double)(ideal - lo) <= tol && (ideal - lo) <= (hi - ideal)) c = lo;
-      else if ((double)(hi - ideal) <= tol) c = hi;
-      cut[w] = std::max(c, prev);
+    const char* pc = getenv("KLR_Q64_PIECE_COST");
+    const u64 piece_cost = pc ? (u64)std::max(0, atoi(pc)) : 40;
+    const char* cs = getenv("KLR_Q64_CUT");
+    const bool plain = cs && !strcmp(cs, "snap");
+    const char* st = getenv("KLR_Q64_SNAP_TOL");
+    const double tolf = st ? atof(st) : 0.04;
+    u32 crossings = 0;
+    for (int pass = plain ? 1 : 0; pass < 2; pass++) {
+      const double extra = pass && !plain ? (double)piece_cost * (double)crossings / (double)std::max<u64>(total_blk, 1) : 0.0;
+      i64 t = 0;
+      cut[0] = 0;
+      u32 crossed = 0;
+      for (u32 w = 1; w <= nwg; w++) {
+        const u64 prev = cut[w - 1];
+        const u64 share = (u64)((double)(total_blk - prev) * (1.0 + extra) / (double)(nwg - w + 1));
+        const u64 ideal = std::min<u64>(prev + share, total_blk);
+        const double tol = tolf * (double)share;
+        while (t < nct && sb[(size_t)t + 1] <= ideal) t++;
+        u64 c = ideal;
+        const u64 lo = sb[(size_t)t], hi = t < nct ? sb[(size_t)t + 1] : total_blk;
+        if (lo > prev && (double)(ideal - lo) <= tol && (ideal - lo) <= (hi - ideal)) c = lo;
+        else if ((double)(hi - ideal) <= tol) c = hi;
+        if (lo > prev && c > lo) {
+          crossed++;
+          if (pass && !plain && c > lo + 16) c -= std::min<u64>(piece_cost, c - lo - 16);
+        }
+        cut[w] = std::max(c, prev);
+      }
+      crossings = crossed;
     }
     cut[nwg] = total_blk;
   }
@@ -476,6 +564,15 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     wgp[nwg] = (u32)(piece.size() / 4);
   }
   const u32 npiece = (u32)(piece.size() / 4);
+  if (getenv("KLR_Q64_DEBUG")) {
+    fprintf(stderr, "q64 cuts: %llu blocks, %lld strips, %u workgroups, %u pieces\n", (unsigned long long)total_blk, (long long)nct, nwg, npiece);
+    for (u32 w = 0; w < std::min<u32>(nwg, 10u); w++) {
+      fprintf(stderr, "  wg %u:", w);
+      for (u32 q = wgp[w]; q < wgp[w + 1]; q++) fprintf(stderr, " [strip %u: blocks %u..%u of %llu..%llu]", piece[(size_t)q * 4], piece[(size_t)q * 4 + 1] / 64,
+                                                        piece[(size_t)q * 4 + 2] / 64, (unsigned long long)sb[piece[(size_t)q * 4]], (unsigned long long)sb[(size_t)piece[(size_t)q * 4] + 1]);
+      fprintf(stderr, "\n");
+    }
+  }
   std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(std::max<u32>(npiece, 1));
   for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
   for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
@@ -564,6 +661,11 @@ static int build_q64(klr_ctx* ctx, klr_mat* m, TmpPool& tmp, bool* built) {
   hipLaunchKernelGGL(k_q64_blkrow, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT, rq_prefix, strip_unit, blkrow);
   hipLaunchKernelGGL(k_q64_fill, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT, CB, rq_prefix, strip_unit,
                      (const u32*)blkrow, ent64, d_flag);
+  {
+    const char* bo = getenv("KLR_Q64_BANK");             // rounds of the bank-aware column order, 0 = columns stay ascending
+    const int rounds = bo ? std::max(0, std::min(64, atoi(bo))) : 16;
+    if (rounds > 0) hipLaunchKernelGGL(k_q64_bank_order, dim3((unsigned)(units / 64)), dim3(64), 0, st, (uint4*)ent64, CB, rounds);
+  }
   KLR_HIP(ctx, hipGetLastError());
   u32 h_flag = 0;
   KLR_TRY(d2h_sync(ctx, &h_flag, d_flag, 4));

@@ -621,14 +621,25 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
 // ABL (timing-only ablations, builds with -DKLR_ABLATIONS; results wrong by construction): 1 no write-out,
 // 2 no atomics, 3 no S loads, 4 stream only
 typedef int q64_i32x4 __attribute__((ext_vector_type(4)));
+#ifdef KLR_ABLATIONS
+// development builds: 100 MHz wall-clock stamps of workgroup phases (tools/q64_phases.py), wave 0 and wave 15
+__device__ unsigned long long q64_ts[2 * 1024 * 8];
+#define Q_TS(I) { if (lane == 0u && (wave == 0u || wave == 15u) && blockIdx.x < 1024u) q64_ts[((wave ? 1024u : 0u) + blockIdx.x) * 8u + (I)] = wall_clock64(); }
+extern "C" int klr_debug_q64_ts(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(q64_ts), sizeof(q64_ts)); }
+#else
+#define Q_TS(I)
+#endif
 __device__ q64_i32x4 q64_raw_buffer_load_x4(q64_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 constexpr int q64_gcd(int a, int b) { return b == 0 ? a : q64_gcd(b, a % b); }
 
 // A = stream units requested ahead of the one being consumed, B = S pairs requested ahead (B < A).  Loads return in
 // the order they were issued, so the wait for the S pair of step k also waits for every stream unit requested before
 // it: with the S pair of step k + B going out BEFORE the stream unit of step k + A, min(B + 1, A - B) steps of stream
-// latency are covered.  (3, 1): two workgroups per CU (64 VGPRs each); (7, 3): one workgroup per CU.
-template <int CB, bool NT, int A, int B, int ABL = 0>
+// latency are covered.  (2, 1) with one workgroup per CU, (1, 0) with two.  A wavefront has only 50 - 70 steps in the
+// whole kernel (16 wavefronts x 256 workgroups share ~200k - 290k blocks), so the pipeline is never in a steady state:
+// deeper rings ((7, 3) was the choice while the LDS atomics set the pace) now only lengthen the start and the drain --
+// measured 41.7 / 43.0 / 44.0 / 44.9 us at (2,1) / (3,1) / (5,2) / (7,3) on configs[2] (tools/ab_q64_depth.py).
+template <int CB, bool NT, int A, int B, int R, int ABL = 0>
 __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ ent, u32 ent_bytes, const u32* __restrict__ blkrow,
                                                     const uint4* __restrict__ piece, const uint4* __restrict__ wgrec,
                                                     const i64* __restrict__ S, i64* __restrict__ part) {
@@ -636,16 +647,18 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
   constexpr int RSH = 4 * CB - 32;                     // row field: bits [4 CB, 64) of the quad = y >> RSH
   constexpr int NU = A + 1, NS = B + 1, L = NU * NS / q64_gcd(NU, NS);
   static_assert(B < A && L <= 24, "ring sizes");
+  static_assert(R == 1 || R == 2, "accumulator regions");
   extern __shared__ unsigned long long q64_lds[];
-  unsigned long long* sG = q64_lds;
+  unsigned long long* sG = q64_lds;                    // the accumulators of the piece being streamed: region (p - p0) % R
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // one 32-byte record per workgroup: {first piece, end piece, first unit and end unit of the first piece} {first row of
   // its first block} -- the first stream loads are one memory round trip away, not three (record -> piece -> stream), and
   // the accumulators are zeroed while the record is on its way
+  Q_TS(0);
   const uint4 wr = wgrec[2 * blockIdx.x];
   const u32 rb_first = wgrec[2 * blockIdx.x + 1].x;
-  for (u32 i = tid; i < PD; i += 1024) sG[i] = 0ull;
+  for (u32 i = tid; i < (u32)R * PD; i += 1024) q64_lds[i] = 0ull;
   const u32 p0 = wr.x, p1 = wr.y;
   // the s values of the workgroup's first rows are requested now, beside the first stream units: the first S loads of
   // the pipeline (which need a stream unit to have landed) then find them in the cache instead of going to HBM in turn
@@ -662,31 +675,23 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
     rsrc.z = __builtin_amdgcn_readfirstlane((int)ent_bytes);
     rsrc.w = 0x00020000;
   }
-  for (u32 p = p0; p < p1; p++) {
-    uint4 d;                                            // {strip, first unit, end unit, -}: both multiples of 64
-    if (p == p0) d = make_uint4(0u, wr.z, wr.w, 0u); else d = piece[p];
-    // first rows of this wavefront's first <= 64 blocks: requested before the accumulators are zeroed
-    u32 rbv0 = 0;
-    {
-      const u32 fb0 = (d.y >> 6) + wave, fb1 = min((d.y >> 6) + 1024u, d.z >> 6);
-      if (fb0 < fb1) rbv0 = blkrow[fb0 + (min(lane, ((fb1 - fb0 + 15u) >> 4) - 1u) << 4)];
-    }
-    if (p != p0) {
-      __syncthreads();                                  // the previous piece has been written out
-      for (u32 i = tid; i < PD; i += 1024) sG[i] = 0ull;
-    }
-    __syncthreads();
-    // The piece's 64-unit blocks are dealt round-robin to the 16 wavefronts, 1024 blocks (64 per wavefront) at a time: a
-    // wavefront fetches the first rows of its <= 64 blocks with ONE vector load (lane l: its l-th block) and picks them
-    // out with v_readlane as it goes -- a scalar load per block would share its wait counter with the LDS atomics.
-    const u32 pb1 = d.z >> 6;
-    for (u32 bs = d.y >> 6; bs < pb1; bs += 1024u) {
-      const u32 b0 = bs + wave, b1 = min(bs + 1024u, pb1);   // this wavefront's blocks: b0, b0 + 16, ... < b1
-      if (b0 >= b1) continue;
-      const u32 nb = (b1 - b0 + 15u) >> 4, last = nb - 1u;
-      const u32 rbv = bs == (d.y >> 6) ? rbv0 : blkrow[b0 + (min(lane, last) << 4)];
-      uint4 U[NU];
-      unsigned long long Sa[NS], Sb[NS];
+  // The workgroup's stream is a sequence of SEGMENTS: a piece (one strip's accumulators) in rounds of 1024 blocks, dealt
+  // round-robin to the 16 wavefronts (64 per wavefront and round: a wavefront fetches the first rows of its <= 64 blocks
+  // with ONE vector load, lane l its l-th block, and picks them out with v_readlane as it goes -- a scalar load per block
+  // would share its wait counter with the LDS atomics).  The stream units go to registers, so the first A of the NEXT
+  // segment (and its row bases) are requested as soon as the current segment's loop ends -- before the barrier, the
+  // write-out and the zeroing at a piece boundary, which then cost the drain only: with the descriptor, the row bases,
+  // the stream and S each a dependent round trip after the barrier, a boundary cost ~9 us (a 1M-column shard has one in
+  // every fifth workgroup; tools/q64_phases.py).
+  if (p0 < p1) {
+    const u32 blk_last = (ent_bytes >> 10) - 1u;
+    uint4 U[NU];
+    unsigned long long Sa[NS], Sb[NS];
+    u32 p = p0, b0 = 0, nb = 0, last = 0, rbv = 0, flushed = 0;
+    uint4 d = make_uint4(0u, wr.z, wr.w, 0u);            // {strip, first unit, end unit, -}: both multiples of 64
+    uint4 dn = make_uint4(0u, 0u, 0u, 0u);
+    if (p0 + 1u < p1) dn = piece[p0 + 1u];
+    u32 bs = d.y >> 6;
 #define Q_LOADU(SLOT, K) { const u32 k_ = (u32)(K);                                                                        \
           const u32 off_ = k_ < nb ? ((((b0 + (k_ << 4)) << 6) + lane) << 4) : 0xFFFFFFF0u;                                   \
           const q64_i32x4 t_ = q64_raw_buffer_load_x4(rsrc, (int)off_, 0, NT ? 2 : 0);                                       \
@@ -700,49 +705,106 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
           atomicAdd(&sG[__builtin_amdgcn_alignbit((E).y, (E).x, 2 * CB) & CM], SA); atomicAdd(&sG[((E).y >> (3 * CB - 32)) & CM], SA); \
           atomicAdd(&sG[(E).z & CM], SB); atomicAdd(&sG[((E).z >> CB) & CM], SB);                                            \
           atomicAdd(&sG[__builtin_amdgcn_alignbit((E).w, (E).z, 2 * CB) & CM], SB); atomicAdd(&sG[((E).w >> (3 * CB - 32)) & CM], SB); } }
-      // the prologue issues its loads in the order the steps -A .. -1 of the loop would have: the wait-count pass then
-      // sees the same queue on the loop's entry and on its back edge (it merges the two, and a merge of unlike queues
-      // waits for nearly everything at the top of every L-th step)
+    // this wavefront's blocks of the segment (D, BS): b0, b0 + 16, ... ; their row bases and the first A stream units
+#define Q_SEGMENT(D, BS) {                                                                                                   \
+          const u32 e_ = min((BS) + 1024u, (D).z >> 6);                                                                       \
+          b0 = (BS) + wave; nb = b0 < e_ ? (e_ - b0 + 15u) >> 4 : 0u; last = nb ? nb - 1u : 0u;                                \
+          rbv = blkrow[min(b0 + (min(lane, last) << 4), blk_last)];                                                          \
+          _Pragma("unroll") for (int j_ = 0; j_ < A; j_++) { Q_LOADU(j_, j_); __builtin_amdgcn_sched_barrier(0); } }
+    Q_SEGMENT(d, bs);
+    bool fresh = true;
+    for (;;) {
+      if (fresh) __syncthreads();                        // the accumulators are zero
+      fresh = false;
+      if (nb) {
+        // the S pairs of steps 0 .. B-1; the loop's step k then requests S(k + B) and U(k + A) and consumes step k
 #pragma unroll
-      for (int j = -A; j < 0; j++) {
-        if (j + B >= 0) { Q_LOADS((j + B) % NS, (j + B) % NU, (u32)(j + B)); __builtin_amdgcn_sched_barrier(0); }
-        Q_LOADU((j + A) % NU, (u32)(j + A));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      for (u32 k0 = 0; k0 < nb; k0 += (u32)L) {
+        for (int j = 0; j < B; j++) { Q_LOADS(j % NS, j % NU, (u32)j); __builtin_amdgcn_sched_barrier(0); }
+        for (u32 k0 = 0; k0 < nb; k0 += (u32)L) {
+#ifdef KLR_ABLATIONS
+          if (p == p0 + 1u && bs == (d.y >> 6) && k0 == (u32)L) Q_TS(1);     // the second piece's first L steps are done
+#endif
 #pragma unroll
-        for (int j = 0; j < L; j++) {
-          const u32 k = k0 + (u32)j;
-          Q_LOADS((j + B) % NS, (j + B) % NU, k + (u32)B);
-          __builtin_amdgcn_sched_barrier(0);
-          Q_LOADU((j + A) % NU, k + (u32)A);
-          __builtin_amdgcn_sched_barrier(0);
-          if (k < nb) Q_EAT(U[j % NU], Sa[j % NS], Sb[j % NS]);      // wave-uniform; a step past the end holds zeros
-          __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < L; j++) {
+            const u32 k = k0 + (u32)j;
+            Q_LOADS((j + B) % NS, (j + B) % NU, k + (u32)B);
+            __builtin_amdgcn_sched_barrier(0);
+            Q_LOADU((j + A) % NU, k + (u32)A);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < nb) Q_EAT(U[j % NU], Sa[j % NS], Sb[j % NS]);      // wave-uniform; a step past the end holds zeros
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
+      // the next segment: the next round of this piece, or the first round of the next piece
+      u32 bsn = bs + 1024u, pn = p;
+      const bool piece_ends = bsn >= (d.z >> 6);
+      uint4 dx = d;
+      if (piece_ends) { pn = p + 1u; dx = dn; bsn = dn.y >> 6; }
+      const bool more = pn < p1;
+      if (more) {
+        if (piece_ends) { dn = make_uint4(0u, 0u, 0u, 0u); if (pn + 1u < p1) dn = piece[pn + 1u]; }
+        Q_SEGMENT(dx, bsn);
+      }
+      if (piece_ends) {
+#ifdef KLR_ABLATIONS
+        if (tid == 0u && blockIdx.x < 1024u) {
+          unsigned long long* r_ = &q64_ts[blockIdx.x * 8u];
+          r_[6] = (p == p0 ? 0ull : r_[6]) + ((d.z - d.y) >> 6);
+          if (p == p0) r_[7] = (unsigned long long)(p1 - p0) | ((unsigned long long)((d.z - d.y) >> 6) << 8);
+        }
+#endif
+        // With R = 2 regions a workgroup's second piece accumulates beside its first: no barrier, no drain -- a wavefront
+        // that has finished its blocks of the first piece goes on with the second while the others are still in the
+        // first.  A region is written out (all wavefronts at a barrier) only when a later piece needs it, or at the end.
+        const u32 q = p - p0;                                              // the piece just finished, 0-based
+        const bool need = !more || q + 2u > (u32)R + flushed;              // piece q + 1 wants region (q + 1) % R
+        if (need) {
+          if (p == p0) Q_TS(2);
+          __syncthreads();                                                 // every wavefront has added its last unit of pieces <= q
+          if (p == p0) Q_TS(3);
+          if (ABL == 2 || ABL == 4) q64_lds[tid] += sink;
+          const u32 q_end = more ? q + 2u - (u32)R : q + 1u;                 // pieces flushed .. q_end - 1 are written out
+          for (u32 f = flushed; f < q_end; f++) {
+            unsigned long long* reg = q64_lds + (f % (u32)R) * PD;
+            i64* out = part + (size_t)(p0 + f) * PD;
+            if (ABL == 1) { if (reg[tid] == 0x1234567ull) out[tid] = 1; }
+            else for (u32 i = tid; i < PD; i += 1024) { out[i] = (i64)reg[i]; reg[i] = 0ull; }   // each thread zeroes what it wrote out
+          }
+          flushed = q_end;
+          if (p == p0) Q_TS(4);
+          if (!more) break;
+          fresh = true;
+        }
+        sG = q64_lds + ((q + 1u) % (u32)R) * PD;
+      }
+      p = pn; d = dx; bs = bsn;
+    }
+#undef Q_SEGMENT
 #undef Q_EAT
 #undef Q_LOADS
 #undef Q_LOADU
-    }
-    __syncthreads();
-    i64* out = part + (size_t)p * PD;
-    if (ABL == 2 || ABL == 4) sG[tid] += sink;
-    if (ABL == 1) { if (sG[tid] == 0x1234567ull) out[tid] = 1; }
-    else for (u32 i = tid; i < PD; i += 1024) out[i] = (i64)sG[i];
   }
+  Q_TS(5);
   asm volatile("" :: "v"((u32)s_warm), "v"((u32)(s_warm >> 32)));       // keeps the warming load alive
 }
 
-template <int CB, bool NT, int A, int B, int ABL = 0>
+template <int CB, bool NT, int A, int B, int R, int ABL = 0>
 static int launch_sweep_q64(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
-  const size_t lds_bytes = (size_t)8 << CB;
+  // one workgroup per CU: the request is padded past half of the CU's 160 KiB, so the dispatcher cannot put two
+  // workgroups on one CU while another CU stays empty (it does: with 256 workgroups of 32 - 64 KiB on 256 CUs part of
+  // them ran in pairs and finished 15 % later than the rest, tools/q64_phases.py)
+  size_t lds_bytes = (size_t)R * ((size_t)8 << CB);
+  if ((int)mat->nwg <= ctx->n_cu) {
+    const char* e = getenv("KLR_Q64_LDS_KIB");
+    lds_bytes = std::max(lds_bytes, (size_t)(e ? atoi(e) : 96) << 10);
+  }
   static bool attr_done = false;
   if (!attr_done) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_q64<CB, NT, A, B, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_q64<CB, NT, A, B, R, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
     attr_done = true;
   }
-  hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, ABL>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+  hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
                         (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)mat->t_piece,
                         (const uint4*)mat->t_wgpiece, S, part);
   return KLR_OK;
@@ -755,15 +817,27 @@ static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64*
   if (ABL == 0) {
     const char* e = getenv("KLR_Q64_DEPTH");                // A/B: pipeline depths
     const int dsel = e ? atoi(e) : 0;
-    if (dsel == 31) return launch_sweep_q64<CB, NT, 3, 1, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 52) return launch_sweep_q64<CB, NT, 5, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 73) return launch_sweep_q64<CB, NT, 7, 3, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 115) return launch_sweep_q64<CB, NT, 11, 5, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 71) return launch_sweep_q64<CB, NT, 7, 1, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 10) return launch_sweep_q64<CB, NT, 1, 0, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 20) return launch_sweep_q64<CB, NT, 2, 0, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 21) return launch_sweep_q64<CB, NT, 2, 1, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 30) return launch_sweep_q64<CB, NT, 3, 0, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 32) return launch_sweep_q64<CB, NT, 3, 2, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 41) return launch_sweep_q64<CB, NT, 4, 1, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 42) return launch_sweep_q64<CB, NT, 4, 2, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 31) return launch_sweep_q64<CB, NT, 3, 1, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 52) return launch_sweep_q64<CB, NT, 5, 2, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 73) return launch_sweep_q64<CB, NT, 7, 3, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 115) return launch_sweep_q64<CB, NT, 11, 5, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 71) return launch_sweep_q64<CB, NT, 7, 1, 2, 0>(ctx, mat, S, part, e0, e1);
   }
 #endif
-  if ((int)mat->nwg <= ctx->n_cu) return launch_sweep_q64<CB, NT, 7, 3, ABL>(ctx, mat, S, part, e0, e1);
-  return launch_sweep_q64<CB, NT, 3, 1, ABL>(ctx, mat, S, part, e0, e1);
+  if ((int)mat->nwg <= ctx->n_cu) {
+#ifdef KLR_ABLATIONS
+    if (getenv("KLR_Q64_REGIONS") && atoi(getenv("KLR_Q64_REGIONS")) == 1) return launch_sweep_q64<CB, NT, 2, 1, 1, ABL>(ctx, mat, S, part, e0, e1);
+#endif
+    return launch_sweep_q64<CB, NT, 2, 1, 2, ABL>(ctx, mat, S, part, e0, e1);   // one workgroup per CU: two accumulator regions
+  }
+  return launch_sweep_q64<CB, NT, 1, 0, 1, ABL>(ctx, mat, S, part, e0, e1);
 }
 
 template <int THREADS, int UNROLL, bool NT, int ABL = 0, int FMT = FMT_U32>

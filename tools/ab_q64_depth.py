@@ -14,25 +14,27 @@ for sh in (sys.argv[1:] or ["c2", "c3"]):
     os.environ["KLR_ENTRY_FORMAT"] = fmt
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
     mats = {}
-    for w in (1, 2):
+    for w in (int(v) for v in os.environ.get("AB_WGS", "1").split(",")):
         os.environ["KLR_Q64_WGS"] = str(w)
         mats[w] = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     del rowptr, col, val
     cw = mats[1].class_weights()
-    combos = [(w, d) for w in (1, 2) for d in (31, 52, 73, 115, 71)]
-    res = {c: [] for c in combos}
-    for r in range(4):
+    combos = [(w, d) for w in mats for d in (int(v) for v in os.environ.get("AB_DEPTHS", "10,20,21,30,31,32,41,42,52,73").split(","))]
+    res = {(c, mode): [] for c in combos for mode in ("res", "cold")}
+    for r in range(int(os.environ.get("AB_ROUNDS", "4")) + 1):
         for (w, d) in combos:
             os.environ["KLR_Q64_DEPTH"] = str(d)
-            ctx.prof_enable(True); ctx.prof_read(reset=True)
-            for _ in range(6):
-                ctx.evict(1 << 30)
-                K.sweep_select(ctx, mats[w], None, None, np.zeros(1), cw, N)
-            nl, ms = ctx.prof_read(reset=True)
-            ctx.prof_enable(False)
-            if r:
-                res[(w, d)].append(ms / nl * 1e3)
+            for mode in ("res", "cold"):
+                ctx.prof_enable(True); ctx.prof_read(reset=True)
+                for _ in range(6):
+                    if mode == "cold":
+                        ctx.evict(1 << 30)
+                    K.sweep_select(ctx, mats[w], None, None, np.zeros(1), cw, N)
+                nl, ms = ctx.prof_read(reset=True)
+                ctx.prof_enable(False)
+                if r:
+                    res[((w, d), mode)].append(ms / nl * 1e3)
     for c in combos:
-        print("%s wgs/cu %d depth %3d  cold %7.2f us" % (sh, c[0], c[1], np.median(res[c])), flush=True)
+        print("%s wgs/cu %d depth %3d  resident %7.2f us  cold %7.2f us" % (sh, c[0], c[1], np.median(res[(c, "res")]), np.median(res[(c, "cold")])), flush=True)
     for w in mats:
         mats[w].close()
