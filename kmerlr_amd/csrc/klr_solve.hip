@@ -1448,13 +1448,13 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // KLR_GRAM_PATH=lds|global forces the privatised (LDS / tiled) or the global-atomics build (tests)
   const char* gram_env = getenv("KLR_GRAM_PATH");
   const bool gram_many = gram_env ? (gram_env[0] == 'l') : est_pairs > 4e6;
-  const bool gram_lds = (size_t)d * d * 8 <= 128 * 1024 && gram_many;
+  // one Gram row per workgroup once there are enough columns to fill the chip with workgroups (KLR_GRAM_ROWS_MIN)
+  const int gram_rows_min = getenv("KLR_GRAM_ROWS_MIN") ? atoi(getenv("KLR_GRAM_ROWS_MIN")) : 384;
+  const bool gram_rows = d >= gram_rows_min && gram_many && (size_t)d * 8 <= 128 * 1024 && red->d_collen != nullptr;
+  const bool gram_lds = !gram_rows && (size_t)d * d * 8 <= 128 * 1024 && gram_many;
   const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
   // 128 < d <= 1024 with many pairs: tile pairs privatised in LDS (k_gram_offdiag_tiled)
   const int gram_nt = (d + GT - 1) / GT, gram_npairs = gram_nt * (gram_nt + 1) / 2;
-  // one Gram row per workgroup once there are enough columns to fill the chip with workgroups (KLR_GRAM_ROWS_MIN)
-  const int gram_rows_min = getenv("KLR_GRAM_ROWS_MIN") ? atoi(getenv("KLR_GRAM_ROWS_MIN")) : 384;
-  const bool gram_rows = !gram_lds && d > 128 && d >= gram_rows_min && gram_many && (size_t)d * 8 <= 128 * 1024 && red->d_collen != nullptr;
   // every row stores all d columns (dense score tables): the value array is the n x d panel -> Gram on the matrix cores
   const bool gram_dense_ok = red->nnz == n * (i64)d && d >= 2 && d <= GD_MAXD && n >= 256 && !getenv("KLR_GRAM_NO_MFMA");
   const bool gram_dense = gram_dense_ok && (!gram_env || gram_env[0] == 'm');

@@ -374,6 +374,44 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled, entry_format):
     np.testing.assert_array_equal(g, g2)
 
 
+@pytest.mark.parametrize("fmt,dim", [("q64c12", 4_200_000), ("q64c13", 8_300_000)])
+def test_q64_many_strips_per_workgroup(ctx, monkeypatch, fmt, dim):
+    # > 1000 column strips on 256 workgroups: every workgroup streams four or five pieces, so the second accumulator
+    # region is written out and reused in mid-stream (a piece boundary with and without a barrier), and most strips hold
+    # only a block or two.  g at theta = 0 is an exact function of the integer column sums: bitwise against numpy.
+    monkeypatch.setenv("KLR_ENTRY_FORMAT", fmt)
+    rng = np.random.default_rng(11)
+    n, per_row = 6000, 400
+    cols = np.sort(rng.integers(1, dim, size=(n, per_row)), axis=1)
+    keep = np.ones_like(cols, dtype=bool); keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    counts = rng.integers(1, 4, size=(n, per_row)).astype(np.float64)
+    rowlen = 1 + keep.sum(axis=1)
+    rowptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(rowlen, out=rowptr[1:])
+    col = np.zeros(rowptr[-1], dtype=np.int64); val = np.ones(rowptr[-1])
+    pos = (rowptr[:-1, None] + 1 + np.cumsum(keep, axis=1) - 1)[keep]
+    col[pos] = cols[keep]; val[pos] = counts[keep]
+    labels = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+    m = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
+    lay = m.layout()
+    assert lay["format"] == fmt and lay["nseg"] > 1000
+    cw = m.class_weights()
+    out = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, 50, want_g=True)
+    # s_i = cw_i (0.5 - y_i) / n at theta = 0 -> exact fixed-point sums; compare with the f64 column sums within 1e-11 max|g|,
+    # and bitwise with a second build in the other order of the same sums (the CSC path)
+    r = (0.5 - labels.astype(np.float64)) * np.where(labels > 0, cw[1], cw[0]) / n
+    g_ref = np.zeros(dim); np.add.at(g_ref, col, val * np.repeat(r, rowlen))
+    assert np.max(np.abs(out["g"] - g_ref)) <= 1e-11 * np.max(np.abs(g_ref))
+    out2 = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, 50, want_g=True)
+    np.testing.assert_array_equal(out["g"], out2["g"])
+    monkeypatch.setenv("KLR_ENTRY_FORMAT", "u32")
+    m2 = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
+    out3 = K.sweep_select(ctx, m2, None, None, np.zeros(1), cw, 50, want_g=True)
+    np.testing.assert_array_equal(out["g"], out3["g"])
+    np.testing.assert_array_equal(out["b"], out3["b"])
+    assert out["lam"] == out3["lam"] and out["c"] == out3["c"] == 50
+    m.close(); m2.close()
+
+
 def test_tiled_dense_counts(ctx, entry_format):
     # dense count data: every (row, column) pair present, many same-column LDS atomics per wave
     rng = np.random.default_rng(2)

@@ -25,7 +25,7 @@ def main():
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     draws = 993
     ctx = K.Context(0)
-    rowptr, col, val, labels = K.synth_csr(20240229, 0, n, n, m, draws, 2 * N)
+    rowptr, col, val, labels = K.synth_csr(int(os.environ.get("EST_SEED", "20240229")), 0, n, n, m, draws, 2 * N)
     full = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels, n)
     ctx.synchronize()
     out = []

@@ -13,7 +13,7 @@ for f in glob.glob(d + "/**/*_memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r["Direction"][:24]))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if "k_sweep_coo" in r[2]]
+idx = [i for i, r in enumerate(rows) if "k_sweep_" in r[2]]
 i0, i1 = idx[-8], idx[-6]
 t0 = rows[i0 - 3][0]
 prev_end = None
