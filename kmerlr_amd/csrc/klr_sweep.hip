@@ -608,14 +608,15 @@ __global__ __launch_bounds__(THREADS) void k_sweep_coo(const u32* __restrict__ e
 // field is relative to the first row of its 64-unit block (blkrow, 4 bytes per KiB of stream), and the fixed-point
 // weight S[row] is NOT staged in LDS -- consecutive lanes hold consecutive rows, so the S reads are short
 // sequential global loads that hit L1/L2 (a few cache lines per wavefront and trip).  What that buys:
-//   * LDS holds only the 2^CB column accumulators (32 or 64 KiB): no s-tile load, no barrier, no drain anywhere
-//     in mid-stream -- a 1M-column shard (7,967 tiles of ~15.6k entries in the tiled layout, each paying
-//     barrier + s-tile reload) streams without a stop; the 16 wavefronts of a workgroup run on their own between
-//     the piece boundaries;
+//   * LDS holds only column accumulators (R regions of 2^CB: 32 or 64 KiB each): no s-tile load, no barrier, no drain
+//     anywhere in mid-stream -- a 1M-column shard (7,967 tiles of ~15.6k entries in the tiled layout, each paying
+//     barrier + s-tile reload) streams without a stop; the 16 wavefronts of a workgroup run on their own, and with
+//     R = 2 even across the first strip boundary of the workgroup's share;
 //   * strips twice as wide at CB = 13: runs of a 1M-column shard are ~7.7 entries instead of ~3.9, padding
 //     19 % instead of 40 %;
-//   * every wavefront keeps three stream units (16 bytes per lane each) and one pair of S values in flight: a stream that
-//     comes from HBM rather than the Infinity Cache is still covered.
+//   * the ingest orders the columns inside every lane's unit so that no LDS bank pair is wanted by three or more lanes
+//     of a 16-lane group in the same slot (k_q64_bank_order, klr_ingest.hip): the atomics then run at the rate of
+//     their address / data transfer and the HBM stream sets the pace.
 // Accumulation as in k_sweep_coo: exact int64 LDS atomics, one 2^CB-wide partial vector per (strip, workgroup) piece.
 // ---------------------------------------------------------------------------------------------
 // ABL (timing-only ablations, builds with -DKLR_ABLATIONS; results wrong by construction): 1 no write-out,
