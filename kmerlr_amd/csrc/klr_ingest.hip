@@ -581,21 +581,43 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
   }
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)std::max<u32>(npiece, 1) * 16));
-  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 32));
+  KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 48));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
   KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
   {
-    // per workgroup: {first piece, end piece, first unit, end unit of the first piece} {first row of its first block, -, -, -}
-    std::vector<u32> rec((size_t)nwg * 8, 0u);
+    // per workgroup (48 bytes): {first piece, end piece, first unit, end unit of the first piece} {first row of its first
+    // block, -, -, -} {first row, rows of its first piece; first row, rows of its second piece}.  The last four let the
+    // sweep keep the S values of the workgroup's rows in LDS (SLDS) when EVERY workgroup has at most two pieces and its
+    // rows fit beside the two accumulator regions: dense strips (configs[2]: ~6.7k rows per workgroup).
+    std::vector<u32> rec((size_t)nwg * 12, 0u);
+    const int CBm = m->fmt == FMT_Q64C13 ? 13 : 12;
+    const size_t lds_rows_cap = (((size_t)159 << 10) - 2 * ((size_t)8 << CBm)) / 8;
+    bool slds = per_cu == 1 && !(getenv("KLR_Q64_SLDS") && atoi(getenv("KLR_Q64_SLDS")) == 0);
+    u32 most_rows = 0;
     for (u32 w = 0; w < nwg; w++) {
-      rec[(size_t)w * 8] = wgp[w]; rec[(size_t)w * 8 + 1] = wgp[w + 1];
+      rec[(size_t)w * 12] = wgp[w]; rec[(size_t)w * 12 + 1] = wgp[w + 1];
       if (wgp[w] < wgp[w + 1]) {
-        rec[(size_t)w * 8 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 8 + 3] = piece[(size_t)wgp[w] * 4 + 2];
-        rec[(size_t)w * 8 + 4] = h_blkrow_at(piece[(size_t)wgp[w] * 4 + 1] / 64);
+        rec[(size_t)w * 12 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 12 + 3] = piece[(size_t)wgp[w] * 4 + 2];
+        rec[(size_t)w * 12 + 4] = h_blkrow_at(piece[(size_t)wgp[w] * 4 + 1] / 64);
       }
+      if (wgp[w + 1] - wgp[w] > 2) slds = false;
+      u32 rows = 0;
+      for (u32 q = wgp[w]; q < wgp[w + 1] && q < wgp[w] + 2; q++) {
+        const u32 t = piece[(size_t)q * 4], b_first = piece[(size_t)q * 4 + 1] / 64, b_end = piece[(size_t)q * 4 + 2] / 64;
+        const i64 lo = (i64)h_blkrow[b_first];
+        // rows ascend inside a strip: the piece's last row is at most the first row of the block after it
+        const i64 hi = (u64)b_end >= sb[(size_t)t + 1] ? n_rows : std::min<i64>(n_rows, (i64)h_blkrow[b_end] + 1);
+        const i64 nr = std::max<i64>(hi - lo, 0);
+        if (nr > (i64)lds_rows_cap) { slds = false; break; }
+        rec[(size_t)w * 12 + 8 + 2 * (q - wgp[w])] = (u32)lo; rec[(size_t)w * 12 + 9 + 2 * (q - wgp[w])] = (u32)nr;
+        rows += (u32)nr;
+      }
+      if (rows > lds_rows_cap) slds = false;
+      most_rows = std::max(most_rows, rows);
     }
-    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 32, hipMemcpyHostToDevice));
+    m->q64_slds_rows = slds ? std::max<u32>(most_rows, 1u) : 0u;
+    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 48, hipMemcpyHostToDevice));
   }
   KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));

@@ -640,7 +640,7 @@ constexpr int q64_gcd(int a, int b) { return b == 0 ? a : q64_gcd(b, a % b); }
 // whole kernel (16 wavefronts x 256 workgroups share ~200k - 290k blocks), so the pipeline is never in a steady state:
 // deeper rings ((7, 3) was the choice while the LDS atomics set the pace) now only lengthen the start and the drain --
 // measured 41.7 / 43.0 / 44.0 / 44.9 us at (2,1) / (3,1) / (5,2) / (7,3) on configs[2] (tools/ab_q64_depth.py).
-template <int CB, bool NT, int A, int B, int R, int ABL = 0>
+template <int CB, bool NT, int A, int B, int R, int ABL = 0, bool SLDS = false>
 __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ ent, u32 ent_bytes, const u32* __restrict__ blkrow,
                                                     const uint4* __restrict__ piece, const uint4* __restrict__ wgrec,
                                                     const i64* __restrict__ S, i64* __restrict__ part) {
@@ -657,14 +657,14 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
   // its first block} -- the first stream loads are one memory round trip away, not three (record -> piece -> stream), and
   // the accumulators are zeroed while the record is on its way
   Q_TS(0);
-  const uint4 wr = wgrec[2 * blockIdx.x];
-  const u32 rb_first = wgrec[2 * blockIdx.x + 1].x;
+  const uint4 wr = wgrec[3 * blockIdx.x];
+  const u32 rb_first = wgrec[3 * blockIdx.x + 1].x;
   for (u32 i = tid; i < (u32)R * PD; i += 1024) q64_lds[i] = 0ull;
   const u32 p0 = wr.x, p1 = wr.y;
   // the s values of the workgroup's first rows are requested now, beside the first stream units: the first S loads of
   // the pipeline (which need a stream unit to have landed) then find them in the cache instead of going to HBM in turn
   unsigned long long s_warm = 0ull;
-  if (p0 < p1 && ABL < 3) s_warm = (unsigned long long)S[rb_first + tid];
+  if (p0 < p1 && ABL < 3 && !SLDS) s_warm = (unsigned long long)S[rb_first + tid];
   unsigned long long sink = 0ull;
   // the stream as a buffer resource: a unit index past the wavefront's last block becomes an out-of-range offset, which
   // loads zeros without touching memory -- no branch around a load (the wait counts stay exact), no duplicate traffic
@@ -697,9 +697,11 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
           const u32 off_ = k_ < nb ? ((((b0 + (k_ << 4)) << 6) + lane) << 4) : 0xFFFFFFF0u;                                   \
           const q64_i32x4 t_ = q64_raw_buffer_load_x4(rsrc, (int)off_, 0, NT ? 2 : 0);                                       \
           U[SLOT] = make_uint4((u32)t_.x, (u32)t_.y, (u32)t_.z, (u32)t_.w); }
-#define Q_LOADS(SLOT, USLOT, K) { const i64* sb_ = S + (u32)__builtin_amdgcn_readlane((int)rbv, (int)min((u32)(K), last)); \
+#define Q_LOADS(SLOT, USLOT, K) { const u32 rb_ = (u32)__builtin_amdgcn_readlane((int)rbv, (int)min((u32)(K), last));        \
           if (ABL >= 3) { Sa[SLOT] = U[USLOT].y; Sb[SLOT] = U[USLOT].w; }                                                     \
-          else { Sa[SLOT] = (unsigned long long)sb_[U[USLOT].y >> RSH]; Sb[SLOT] = (unsigned long long)sb_[U[USLOT].w >> RSH]; } }
+          else if (SLDS) { Sa[SLOT] = Sl[rb_ + soff + (U[USLOT].y >> RSH)]; Sb[SLOT] = Sl[rb_ + soff + (U[USLOT].w >> RSH)]; }  \
+          else { const i64* sb_ = S + rb_;                                                                                   \
+                 Sa[SLOT] = (unsigned long long)sb_[U[USLOT].y >> RSH]; Sb[SLOT] = (unsigned long long)sb_[U[USLOT].w >> RSH]; } }
 #define Q_EAT(E, SA, SB) {                                                                                                   \
           if (ABL == 2 || ABL == 4) { sink += (E).x + (E).z + (SA) + (SB); } else {                                           \
           atomicAdd(&sG[(E).x & CM], SA); atomicAdd(&sG[((E).x >> CB) & CM], SA);                                            \
@@ -712,12 +714,49 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
           b0 = (BS) + wave; nb = b0 < e_ ? (e_ - b0 + 15u) >> 4 : 0u; last = nb ? nb - 1u : 0u;                                \
           rbv = blkrow[min(b0 + (min(lane, last) << 4), blk_last)];                                                          \
           _Pragma("unroll") for (int j_ = 0; j_ < A; j_++) { Q_LOADU(j_, j_); __builtin_amdgcn_sched_barrier(0); } }
-    Q_SEGMENT(d, bs);
+    // SLDS (dense strips: every workgroup's rows fit LDS beside its accumulators): the S values of the rows of the
+    // workgroup's one or two pieces are copied to LDS once, [piece 0 | piece 1] behind the accumulator regions; a step
+    // then reads its S pair with two ds_read_b64 right before it adds -- no global S loads, nothing but stream units in
+    // the vector-memory queue.  soff: what turns (block row base + row field) into an index of that copy.
+    unsigned long long* const Sl = q64_lds + (u32)R * PD;
+    u32 soff = 0, soff1 = 0;
+    Q_SEGMENT(d, bs);                                    // the first stream units are on their way while S is copied
+    if (SLDS) {
+      const uint4 sr = wgrec[3 * blockIdx.x + 2];        // {first row, rows} of piece 0 and of piece 1
+      soff = 0u - sr.x; soff1 = sr.y - sr.z;
+      const i64* s0 = S + sr.x; const i64* s1 = S + sr.z;
+      for (u32 i0 = 0; i0 < sr.y; i0 += 8192u) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 i = i0 + (u32)u * 1024u + tid; v[u] = i < sr.y ? (unsigned long long)s0[i] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 i = i0 + (u32)u * 1024u + tid; if (i < sr.y) Sl[i] = v[u]; }
+      }
+      for (u32 i0 = 0; i0 < sr.w; i0 += 8192u) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 i = i0 + (u32)u * 1024u + tid; v[u] = i < sr.w ? (unsigned long long)s1[i] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const u32 i = i0 + (u32)u * 1024u + tid; if (i < sr.w) Sl[sr.y + i] = v[u]; }
+      }
+    }
     bool fresh = true;
     for (;;) {
       if (fresh) __syncthreads();                        // the accumulators are zero
       fresh = false;
-      if (nb) {
+      if (nb && SLDS) {
+        // step k: request U(k + A), then read the S pair of unit k from LDS and add
+        for (u32 k0 = 0; k0 < nb; k0 += (u32)NU) {
+#pragma unroll
+          for (int j = 0; j < NU; j++) {
+            const u32 k = k0 + (u32)j;
+            Q_LOADU((j + A) % NU, k + (u32)A);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k < nb) { Q_LOADS(0, j, k); Q_EAT(U[j], Sa[0], Sb[0]); }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if (nb) {
         // the S pairs of steps 0 .. B-1; the loop's step k then requests S(k + B) and U(k + A) and consumes step k
 #pragma unroll
         for (int j = 0; j < B; j++) { Q_LOADS(j % NS, j % NU, (u32)j); __builtin_amdgcn_sched_barrier(0); }
@@ -778,6 +817,7 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
           fresh = true;
         }
         sG = q64_lds + ((q + 1u) % (u32)R) * PD;
+        soff = soff1;                                                      // SLDS: at most two pieces
       }
       p = pn; d = dx; bs = bsn;
     }
@@ -790,22 +830,22 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
   asm volatile("" :: "v"((u32)s_warm), "v"((u32)(s_warm >> 32)));       // keeps the warming load alive
 }
 
-template <int CB, bool NT, int A, int B, int R, int ABL = 0>
+template <int CB, bool NT, int A, int B, int R, int ABL = 0, bool SLDS = false>
 static int launch_sweep_q64(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   // one workgroup per CU: the request is padded past half of the CU's 160 KiB, so the dispatcher cannot put two
   // workgroups on one CU while another CU stays empty (it does: with 256 workgroups of 32 - 64 KiB on 256 CUs part of
   // them ran in pairs and finished 15 % later than the rest, tools/q64_phases.py)
-  size_t lds_bytes = (size_t)R * ((size_t)8 << CB);
+  size_t lds_bytes = (size_t)R * ((size_t)8 << CB) + (SLDS ? (size_t)mat->q64_slds_rows * 8 : 0);
   if ((int)mat->nwg <= ctx->n_cu) {
     const char* e = getenv("KLR_Q64_LDS_KIB");
     lds_bytes = std::max(lds_bytes, (size_t)(e ? atoi(e) : 96) << 10);
   }
   static bool attr_done = false;
   if (!attr_done) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_q64<CB, NT, A, B, R, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
     attr_done = true;
   }
-  hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+  hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
                         (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)mat->t_piece,
                         (const uint4*)mat->t_wgpiece, S, part);
   return KLR_OK;
@@ -836,6 +876,10 @@ static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64*
 #ifdef KLR_ABLATIONS
     if (getenv("KLR_Q64_REGIONS") && atoi(getenv("KLR_Q64_REGIONS")) == 1) return launch_sweep_q64<CB, NT, 2, 1, 1, ABL>(ctx, mat, S, part, e0, e1);
 #endif
+    if (mat->q64_slds_rows && ABL == 0) {                    // dense strips: the workgroup's S values in LDS
+      if (getenv("KLR_Q64_SLDS_A") && atoi(getenv("KLR_Q64_SLDS_A")) == 2) return launch_sweep_q64<CB, NT, 2, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
+      return launch_sweep_q64<CB, NT, 3, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
+    }
     return launch_sweep_q64<CB, NT, 2, 1, 2, ABL>(ctx, mat, S, part, e0, e1);   // one workgroup per CU: two accumulator regions
   }
   return launch_sweep_q64<CB, NT, 1, 0, 1, ABL>(ctx, mat, S, part, e0, e1);
