@@ -251,3 +251,36 @@ def test_complement_and_reverse_classes(ctx):
                 cnt = sum(sq[p:p + len(a)] in members for p in range(len(sq) - len(a) + 1))
                 row = dict(zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]]))
                 assert row.get(c + 1, 0.0) == cnt
+
+
+def test_kmers2_counter_restricted_to_a_class_list(ctx):
+    """TestKmers2 (kmerLr_test.go:70-97): a counter rebuilt from the class list a first pass observed
+    (NewKmerCounter(..., data1.Kmers...)) gives every sequence the same counts.  Here the list travels by NAME
+    (KmerClass.String() -> klr_kmer_class_find, what ImportConfig does) and the restriction is the column sub-select."""
+    seqs, cur = [], []
+    for line in open(os.path.join(GOLDEN, "kmerLr_test.fa")):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur)); cur = []
+        elif line:
+            cur.append(line)
+    seqs.append("".join(cur))
+    labels = np.array([1, 0], dtype=np.uint8)
+    kc = K.KmerClasses(4, 8, revcomp=True, alphabet="gapped-nucleotide")
+    m = K.Matrix.from_sequences(ctx, seqs, labels, classes=kc)
+    rp, col, val = m.to_csr()
+    observed = np.unique(col[col > 0]) - 1                     # data1.Kmers: the classes seen in either sequence
+    observed = np.sort(np.random.default_rng(5).choice(observed, size=min(3000, len(observed)), replace=False))   # a sample keeps the name round trips short
+    names = [kc.name(int(c)) for c in observed]
+    kc2 = K.KmerClasses(4, 8, revcomp=True, alphabet="gapped-nucleotide")
+    again = np.array([kc2.find(nm) for nm in names])            # the list as a second counter resolves it
+    np.testing.assert_array_equal(again, observed)
+    red = m.select_columns(np.concatenate(([0], again + 1)))
+    rr, rc, rv = red.to_csr()
+    assert red.dim == len(observed) + 1
+    for i in range(2):
+        full = np.zeros(m.dim); full[col[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+        sub = np.zeros(red.dim); sub[rc[rr[i]:rr[i + 1]]] = rv[rr[i]:rr[i + 1]]
+        np.testing.assert_array_equal(sub[1:], full[observed + 1])
+        assert sub[0] == full[0] == 1.0
