@@ -575,6 +575,8 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
   }
   std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(std::max<u32>(npiece, 1));
   for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
+  m->max_ct_pieces = 0;
+  for (i64 c = 0; c < nct; c++) m->max_ct_pieces = std::max(m->max_ct_pieces, ctptr[(size_t)c + 1]);
   for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
   {
     std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);

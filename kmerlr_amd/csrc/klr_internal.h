@@ -138,6 +138,7 @@ struct klr_mat {
                                  // FMT_R64: 8-byte quads (row:12 | 4 x col:12), a row's run padded to 4 columns: 2 bytes per unit entry
   u32 tile_r = 4096, tile_c = 4096;   // rows / columns per tile (<= TILE_DIM), chosen at ingest (tile_geometry)
   u32* t_blkrow = nullptr;       // q64: first row of every 64-unit block of the stream (row fields are relative to it)
+  u32  max_ct_pieces = 0;        // most pieces of one column tile / strip (0: not recorded): k_finish_coo's FLAT form up to 8
   u32  q64_slds_rows = 0;        // q64: > 0 = every workgroup's rows fit LDS beside its accumulators (k_sweep_q64 SLDS): the most rows of one
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile

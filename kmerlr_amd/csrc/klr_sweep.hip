@@ -994,7 +994,11 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
 // 256 columns x 4 piece lanes per block: every lane adds every 4th piece of its column tile (4 independent
 // loads in flight), LDS combines.  FUSE (no all-reduce between the two steps, i.e. one rank and no hook): the
 // sums are converted to f64 right here and the selection keys + coarse histogram are emitted, as k_int_to_g does.
-template <bool FUSE>
+// FLAT (at most 8 pieces per column tile -- a q64 stream of a wide matrix has two or three per strip -- and ITER a
+// multiple of 4): a thread sums ALL pieces of its column (8 guarded loads in flight) and a workgroup's ITER x 256 columns
+// go in ITER / 4 passes of 1024 with nothing between them; the four-lane form spends a barrier pair and three dependent
+// round trips per 256 columns, 17 us for the 1M columns of a configs[3] shard.
+template <bool FUSE, bool FLAT = false>
 __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
                                                      const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
                                                      const i64* __restrict__ rowblk, i64 nrowblk, u32 CT, u32 PSTRIDE,
@@ -1041,25 +1045,8 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
   }
   const int cx = threadIdx.x & 255, ly = threadIdx.x >> 8;
   if (FUSE && hist) { for (int i = threadIdx.x; i < FAST_BINS; i += 1024) shh[i] = 0u; }
-  for (u32 it = 0; it < ITER; it++) {
-  const i64 j = ((i64)blockIdx.x * ITER + it) * 256 + cx;
-  i64 v = 0;
-  if (j < dim) {
-    const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
-    const u32 k1 = ctptr[ct + 1];
-    for (u32 k = ctptr[ct] + ly; k < k1; k += 32) {      // 8 guarded loads in flight per lane
-      u32 p[8]; i64 a[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) p[u] = (k + 4u * u < k1) ? ctlist[k + 4u * u] : 0xFFFFFFFFu;
-#pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = (p[u] != 0xFFFFFFFFu) ? part[(i64)p[u] * PSTRIDE + c] : 0;
-      v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-  }
-  sh[ly][cx] = v;
-  __syncthreads();
-  if (ly == 0 && j < dim && j > 0) {
-    const i64 sum = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+  // what happens to a finished column sum
+  auto emit = [&](i64 j, i64 sum) {
     if (FUSE) {
       const double gv = (double)sum * inv_scale;                // inv_scale is a power of two: exact
       g[j] = gv;
@@ -1077,7 +1064,47 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
         }
       }
     } else ibuf[j] = sum;
+  };
+  if (FLAT) {
+    if (FUSE) __syncthreads();                                  // wcnt and the histogram are zero
+    i64 jv[2], sums[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) {
+      const i64 j = (i64)blockIdx.x * ITER * 256 + (i64)ps * 1024 + threadIdx.x;
+      jv[ps] = j; sums[ps] = 0;
+      if ((u32)ps * 4u < ITER && j < dim) {
+        const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
+        const u32 k0 = ctptr[ct], k1 = ctptr[ct + 1];
+        u32 p[8]; i64 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p[u] = (k0 + (u32)u < k1) ? ctlist[k0 + (u32)u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = (p[u] != 0xFFFFFFFFu) ? part[(i64)p[u] * PSTRIDE + c] : 0;
+        sums[ps] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ps++) if ((u32)ps * 4u < ITER && jv[ps] < dim && jv[ps] > 0) emit(jv[ps], sums[ps]);
+    __syncthreads();
+  } else
+  for (u32 it = 0; it < ITER; it++) {
+  const i64 j = ((i64)blockIdx.x * ITER + it) * 256 + cx;
+  i64 v = 0;
+  if (j < dim) {
+    const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
+    const u32 k1 = ctptr[ct + 1];
+    for (u32 k = ctptr[ct] + ly; k < k1; k += 32) {      // 8 guarded loads in flight per lane
+      u32 p[8]; i64 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) p[u] = (k + 4u * u < k1) ? ctlist[k + 4u * u] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = (p[u] != 0xFFFFFFFFu) ? part[(i64)p[u] * PSTRIDE + c] : 0;
+      v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
   }
+  sh[ly][cx] = v;
+  __syncthreads();
+  if (ly == 0 && j < dim && j > 0) emit(j, (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]));
   __syncthreads();                                            // sh is reused by the next column group
   }
   if (FUSE && tau != 0ull) {
@@ -1260,14 +1287,20 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
   // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
   const u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
+  // (one pass of 1024 columns per workgroup, 8x the workgroups, measured 3x slower on the 1M-column step: keep ITER)
+  const bool flat = mat->max_ct_pieces >= 1 && mat->max_ct_pieces <= 8 && fiter % 4 == 0 && !getenv("KLR_FINISH_NO_FLAT");
   const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
   if (!ctx->ar_fn) {
     // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
-    hipLaunchKernelGGL(k_finish_coo<true>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
+    if (flat) hipLaunchKernelGGL((k_finish_coo<true, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+                                 nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
+    else hipLaunchKernelGGL((k_finish_coo<true, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+                            nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
   } else {
-    hipLaunchKernelGGL(k_finish_coo<false>, fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
-                       nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
+    if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+                                 nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
+    else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+                            nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
     KLR_HIP(ctx, hipGetLastError());
     if (ibuf_out) {                                // the caller runs the collective (reduce-scatter form, klr_select.hip)
       if (ibuf_elems > dim + IB_EXTRA) KLR_HIP(ctx, hipMemsetAsync(ibuf + dim + IB_EXTRA, 0, (size_t)(ibuf_elems - dim - IB_EXTRA) * 8, st));
