@@ -1286,7 +1286,8 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1));
   if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
   // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
-  const u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
+  u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
+  if (const char* e = getenv("KLR_FINISH_ITER")) fiter = (u32)std::max(1, std::min(8, atoi(e)));          // A/B tooling
   // (one pass of 1024 columns per workgroup, 8x the workgroups, measured 3x slower on the 1M-column step: keep ITER)
   const bool flat = mat->max_ct_pieces >= 1 && mat->max_ct_pieces <= 8 && fiter % 4 == 0 && !getenv("KLR_FINISH_NO_FLAT");
   const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
