@@ -13,7 +13,8 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def first(pattern):
-    return sorted(glob.glob(os.path.join(SRC, pattern)))[0]
+    # gpurun merges every call's files into gpurun_out/ and never deletes: the newest match is this collection's
+    return max(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
 
 
 def line(path):
