@@ -1362,8 +1362,15 @@ __global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict
     const i64 b = rowptr[i], e = rowptr[i + 1];
     const int y = labels[i] != 0;
     double r = 0.0;
-    if (LDS) { for (i64 p = b + 1; p < e; p++) r += val[p] * lm_lds[(size_t)col[p] * KSPEC + k]; }
-    else     { for (i64 p = b + 1; p < e; p++) r += val[p] * hist[(i64)k * d + col[p]]; }
+    // four entries requested at a time (a row is otherwise one dependent round trip per entry); added in entry order
+    for (i64 p = b + 1; p < e; p += 4) {
+      u32 c4[4]; double v4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const bool h = p + u < e; c4[u] = h ? col[p + u] : 0u; v4[u] = h ? val[p + u] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (p + u < e) r += v4[u] * (LDS ? lm_lds[(size_t)c4[u] * KSPEC + k] : hist[(i64)k * d + c4[u]]);
+    }
     const double rr = (LDS ? lm_lds[k] : hist[(i64)k * d]) + r;            // theta[0] + sum
     const double l1p = log1p(exp(-fabs(rr)));
     // y: -log sigma(r) = LogAdd(0,-r);  !y: LogAdd(0,r)
