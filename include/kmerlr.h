@@ -107,6 +107,9 @@ int  klr_mat_from_sequences(klr_ctx* ctx, const char* seqs, const int64_t* seq_o
  * ignored, like KmerLrFeatures.ImportConfig, kmerLr_features.go:207-209) and returns the 0-based class or -1. */
 #define KLR_ALPHABET_NUCLEOTIDE 0
 #define KLR_ALPHABET_GAPPED     1    /* "gapped-nucleotide" */
+#define KLR_ALPHABET_IUPAC      2    /* "iupac-nucleotide": a c g t r y s w k m b d h v n, every code matching its nucleotide set; an
+                                      * ambiguous code counts towards max_ambiguous and, like the gap letter, never stands first or
+                                      * last; k-mers up to 6 letters.  No fixture of the reference covers this alphabet: parity unpinned. */
 #define KLR_KMER_MAX_LEN        12
 #define KLR_KMER_INVALID        0xFFFFFFFFu
 typedef struct {

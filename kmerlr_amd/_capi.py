@@ -215,7 +215,7 @@ def rccl_unique_id():
     return buf.raw
 
 
-ALPHABETS = {"nucleotide": 0, "gapped-nucleotide": 1}
+ALPHABETS = {"nucleotide": 0, "gapped-nucleotide": 1, "iupac-nucleotide": 2}
 
 
 class KmerClasses:

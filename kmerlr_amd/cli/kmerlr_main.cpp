@@ -78,7 +78,7 @@ static void read_scores(const std::string& fn, bool header, uint8_t label, DataS
 struct KmerSpec {
   int M = 0, N = 0;
   bool revcomp = false, reverse = false, complement = false, binarize = false;
-  std::string alphabet = "nucleotide";          // nucleotide | gapped-nucleotide  (Alphabet.String(): "<name> alphabet")
+  std::string alphabet = "nucleotide";          // nucleotide | gapped-nucleotide | iupac-nucleotide  (Alphabet.String(): "<name> alphabet")
   std::vector<int> max_ambiguous{-1};           // --max-ambiguous: one value or one per length
   klr_kmer_classes* kc = nullptr;
   int64_t m = 0;
@@ -99,9 +99,9 @@ static void kmer_prepare(KmerSpec& s, std::vector<std::string>* names) {
   const std::string key = alphabet_key(s.alphabet);
   if (key == "nucleotide alphabet") sp.alphabet = KLR_ALPHABET_NUCLEOTIDE;
   else if (key == "gapped nucleotide alphabet") sp.alphabet = KLR_ALPHABET_GAPPED;
-  else if (key == "iupac nucleotide alphabet" || key == "ambiguous nucleotide alphabet") die("the iupac-nucleotide alphabet is not part of this build");
+  else if (key == "iupac nucleotide alphabet" || key == "ambiguous nucleotide alphabet") sp.alphabet = KLR_ALPHABET_IUPAC;
   else die("invalid alphabet");
-  s.alphabet = key;
+  s.alphabet = sp.alphabet == KLR_ALPHABET_IUPAC ? "iupac nucleotide alphabet" : key;
   // a scalar -1 (the default) bounds nothing; other values go to the class tables
   const bool unbounded = s.max_ambiguous.size() == 1 && s.max_ambiguous[0] < 0;
   sp.n_max_ambiguous = unbounded ? 0 : (int)s.max_ambiguous.size();

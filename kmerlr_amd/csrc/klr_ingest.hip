@@ -32,7 +32,14 @@ __device__ __forceinline__ int base_code(unsigned char ch) {
 // Candidate k-mers of a window.  Nucleotide alphabet: the window itself.  Gapped alphabet: the window with every subset
 // of its inner positions replaced by the gap letter (2^(k-2) candidates); the class table says which of them are
 // k-mers of the alphabet (gaps never first or last, at most max-ambiguous of them) -- the others map to INVALID_ID.
-__host__ __device__ static inline u32 window_variants(int k, int gapped) { return gapped && k > 2 ? 1u << (k - 2) : 1u; }
+// Iupac alphabet (alpha = 2): every inner position carries its nucleotide or one of the 7 ambiguous codes that hold it
+// (8^(k-2) candidates, three bits of the variant number per inner position).
+__host__ __device__ static inline u32 window_variants(int k, int alpha) {
+  return k > 2 ? (alpha == 2 ? 1u << (3 * (k - 2)) : (alpha == 1 ? 1u << (k - 2) : 1u)) : 1u;
+}
+// the ambiguous iupac codes (letters a c g t r y s w k m b d h v n = 0 .. 14) that hold nucleotide b
+__device__ static const unsigned char IUPAC_HOLDS[4][7] = {{4, 7, 9, 11, 12, 13, 14}, {5, 6, 9, 10, 12, 13, 14},
+                                                           {4, 6, 8, 10, 11, 13, 14}, {5, 7, 8, 10, 11, 12, 14}};
 
 // ids of row i for k = M..N are laid out k-major: [k=M windows x variants | k=M+1 ... | ...]
 __global__ __launch_bounds__(256) void k_row_windows(const i64* __restrict__ seq_off, i64 n, int M, int N, int gapped,
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void k_emit_ids(const unsigned char* __restric
   // one block per row; threads stride over the row's (window, variant) pairs
   const i64 i = blockIdx.x;
   const i64 s0 = seq_off[i], len = seq_off[i + 1] - s0;
-  const u32 B = gapped ? 5u : 4u;
+  const u32 B = gapped == 2 ? 15u : (gapped ? 5u : 4u);
   i64 o = woff[i];
   for (int k = M; k <= N; k++) {
     if (len < k) continue;
@@ -67,6 +74,13 @@ __global__ __launch_bounds__(256) void k_emit_ids(const unsigned char* __restric
       for (int q = 0; q < k; q++) {
         const unsigned char ch = seqs[s0 + p + q];
         int b = base_code(ch);
+        if (gapped == 2) {                                 // iupac: three bits per inner position, 0 = the nucleotide itself
+          const u32 sel = q > 0 && q < k - 1 ? (mask >> (3 * (q - 1))) & 7u : 0u;
+          ok = ok && b >= 0;
+          if (b >= 0 && sel) b = IUPAC_HOLDS[b][sel - 1];
+          code = code * B + (u32)(b < 0 ? 0 : b);
+          continue;
+        }
         const bool gap = q > 0 && q < k - 1 && ((mask >> (q - 1)) & 1u);
         if (gapped && (ch | 0x20) == 'n') { b = 4; ok = ok && gap; }     // a gap in the sequence only matches a gap
         else if (gap) b = 4;
@@ -906,7 +920,7 @@ extern "C" int klr_mat_from_sequences_classes(klr_ctx* ctx, const char* seqs, co
   KLR_ARG(ctx, seqs != nullptr && seq_off != nullptr && labels != nullptr && classes != nullptr && n >= 1 && seq_off[0] == 0);
   const klr_kmer_spec* spec = klr_kmer_classes_spec(classes);
   const int M = spec->M, N = spec->N;
-  const int gapped = spec->alphabet == KLR_ALPHABET_GAPPED ? 1 : 0;
+  const int gapped = spec->alphabet == KLR_ALPHABET_IUPAC ? 2 : (spec->alphabet == KLR_ALPHABET_GAPPED ? 1 : 0);   // window_variants' alpha
   if (n_total == 0) n_total = n;
   KLR_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;

@@ -7,11 +7,14 @@
 // aacgcgna|tncgcgtt = 1, tgaatgca|tgcattca = 1 on sequence 0 of kmerLr_test.fa):
 //
 //   * a class is the orbit of a k-mer under the enabled operations (complement, reverse, reverse complement); its
-//     count in a sequence is the number of windows that match ANY member (a window matching two members -- a
-//     palindrome -- counts once);
+//     count in a sequence is the number of (window, member) matches: a window counts once for every DISTINCT member
+//     it matches (a k-mer equal to its own reverse complement is one member and counts once per window);
 //   * gapped alphabet: a k-mer may hold the gap letter 'n' at inner positions (never first or last); 'n' matches
 //     any nucleotide; max-ambiguous bounds the number of gaps per k-mer (-1: no bound; one value for all lengths or
 //     one per length M..N);
+//   * iupac alphabet (no fixture in the reference: unpinned): the 15 codes a c g t r y s w k m b d h v n, a code matching
+//     its nucleotide set; every code beyond a c g t is "ambiguous" in the sense of max-ambiguous and, like the gap
+//     letter, never first or last; complements r<->y, k<->m, b<->v, d<->h, s, w, n fixed; k-mers up to 6 letters;
 //   * class name: the members joined by '|', the canonical member first -- "kmer|revcomp" with --revcomp, both
 //     printed even when equal.  Canonical member and the class order inside a length are by code (a < c < g < t < n,
 //     first letter most significant); lengths ascend.  gonetics' own enumeration order cannot be checked offline:
@@ -24,7 +27,11 @@
 #include "klr_kmers.h"
 #include <cstdio>
 
-static const char LETTERS[] = "acgtn";
+static const char LETTERS5[] = "acgtn";
+// iupac: a c g t | r = ag, y = ct, s = cg, w = at, k = gt, m = ac | b = cgt, d = agt, h = act, v = acg | n
+static const char LETTERS15[] = "acgtryswkmbdhvn";
+static const int COMP15[15] = {3, 2, 1, 0, 5, 4, 6, 7, 9, 8, 13, 12, 11, 10, 14};
+static inline const char* letters_of(int base) { return base == 15 ? LETTERS15 : LETTERS5; }
 
 struct klr_kmer_classes {
   klr_kmer_spec spec;
@@ -47,7 +54,7 @@ static uint64_t encode(const int* d, int k, int base) {
   for (int i = 0; i < k; i++) c = c * (uint64_t)base + (uint64_t)d[i];
   return c;
 }
-static inline int comp_digit(int x) { return x == 4 ? 4 : 3 - x; }
+static inline int comp_digit(int x, int base) { return base == 15 ? COMP15[x] : (x == 4 ? 4 : 3 - x); }
 
 // members of the orbit of d under the enabled operations, in the order the name prints them:
 // the k-mer, its complement, its reverse, its reverse complement
@@ -57,11 +64,11 @@ static int orbit(const klr_kmer_spec& s, const int* d, int k, int base, uint64_t
   enabled[0] = true; enabled[1] = c; enabled[2] = r; enabled[3] = rc;
   int t[KLR_KMER_MAX_LEN];
   out[0] = encode(d, k, base);
-  for (int i = 0; i < k; i++) t[i] = comp_digit(d[i]);
+  for (int i = 0; i < k; i++) t[i] = comp_digit(d[i], base);
   out[1] = encode(t, k, base);
   for (int i = 0; i < k; i++) t[i] = d[k - 1 - i];
   out[2] = encode(t, k, base);
-  for (int i = 0; i < k; i++) t[i] = comp_digit(d[k - 1 - i]);
+  for (int i = 0; i < k; i++) t[i] = comp_digit(d[k - 1 - i], base);
   out[3] = encode(t, k, base);
   return 4;
 }
@@ -71,9 +78,10 @@ extern "C" int klr_kmer_classes_create(const klr_kmer_spec* spec, klr_kmer_class
   if (!spec || !out) return fail("klr_kmer_classes_create: NULL argument");
   *out = nullptr;
   if (spec->M < 1 || spec->N < spec->M) return fail("invalid k-mer lengths");
-  if (spec->alphabet != KLR_ALPHABET_NUCLEOTIDE && spec->alphabet != KLR_ALPHABET_GAPPED)
-    return fail("invalid alphabet (this build counts the nucleotide and the gapped-nucleotide alphabets; iupac-nucleotide is not part of it)");
-  const int base = spec->alphabet == KLR_ALPHABET_GAPPED ? 5 : 4;
+  if (spec->alphabet != KLR_ALPHABET_NUCLEOTIDE && spec->alphabet != KLR_ALPHABET_GAPPED && spec->alphabet != KLR_ALPHABET_IUPAC)
+    return fail("invalid alphabet");
+  const int base = spec->alphabet == KLR_ALPHABET_IUPAC ? 15 : (spec->alphabet == KLR_ALPHABET_GAPPED ? 5 : 4);
+  if (base == 15 && spec->N > 6) return fail("iupac k-mers longer than 6 are not part of this build (15^k codes per length)");
   if (spec->N > (base == 5 ? 10 : KLR_KMER_MAX_LEN)) return fail(base == 5 ? "gapped k-mers longer than 10 are not part of this build" : "k-mers longer than 12 are not part of this build");
   if (spec->n_max_ambiguous != 0 && spec->n_max_ambiguous != 1 && spec->n_max_ambiguous != spec->N - spec->M + 1)
     return fail("max-ambiguous: give one value or one per k-mer length");
@@ -98,9 +106,9 @@ extern "C" int klr_kmer_classes_create(const klr_kmer_spec* spec, klr_kmer_class
     int d[KLR_KMER_MAX_LEN];
     for (uint64_t c = 0; c < nc; c++) {
       decode(c, k, base, d);
-      int gaps = 0;
-      for (int i = 0; i < k; i++) gaps += d[i] == 4;
-      if (d[0] == 4 || d[k - 1] == 4 || (amax >= 0 && gaps > amax)) continue;      // not a k-mer of this alphabet
+      int gaps = 0;                                                                  // ambiguous letters: the gap letter, or any iupac code
+      for (int i = 0; i < k; i++) gaps += d[i] >= 4;
+      if (d[0] >= 4 || d[k - 1] >= 4 || (amax >= 0 && gaps > amax)) continue;      // not a k-mer of this alphabet
       uint64_t o[4]; bool en[4];
       orbit(kc->spec, d, k, base, o, en);
       uint64_t rep = c;
@@ -148,7 +156,7 @@ extern "C" int klr_kmer_class_name(const klr_kmer_classes* kc, int64_t cls, char
     int t[KLR_KMER_MAX_LEN];
     decode(o[j], k, kc->base, t);
     if (!s.empty()) s += '|';
-    for (int i = 0; i < k; i++) s += LETTERS[t[i]];
+    for (int i = 0; i < k; i++) s += letters_of(kc->base)[t[i]];
   }
   if ((int64_t)s.size() + 1 > cap) return 1;
   memcpy(buf, s.c_str(), s.size() + 1);
@@ -163,9 +171,10 @@ extern "C" int64_t klr_kmer_class_find(const klr_kmer_classes* kc, const char* k
   int k = 0;
   for (const char* p = kmer; *p && *p != '|'; p++) {
     if (k >= KLR_KMER_MAX_LEN) return -1;
-    int v;
-    switch (*p | 0x20) { case 'a': v = 0; break; case 'c': v = 1; break; case 'g': v = 2; break; case 't': v = 3; break;
-                         case 'n': v = 4; break; default: return -1; }
+    const char* L = letters_of(kc->base);
+    const char* q = strchr(L, *p | 0x20);
+    if (!q || !*q) return -1;
+    const int v = (int)(q - L);
     if (v >= kc->base) return -1;
     d[k++] = v;
   }

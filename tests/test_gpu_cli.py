@@ -284,3 +284,18 @@ def test_kmers_gapped_alphabet_cli_round_trip(tmp_path):
     lam = float(trace[-1].split()[-2])
     out = run(["loss", "--lambda=%r" % lam, "gp.json", fg, bg], tmp_path).stdout
     assert abs(float(out) - last_loss) < 1e-6
+
+
+def test_kmers_iupac_alphabet_cli_round_trip(tmp_path):
+    """--alphabet=iupac-nucleotide (kmerLr_features.go:254-270 accepts it; no fixture of the reference covers it: parity
+    unpinned): the counter travels in the model like the gapped one."""
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
+    run(["-v", "learn", "--lambda-auto=5", "--alphabet=iupac-nucleotide", "--revcomp", "--max-ambiguous=1", "--save-trace",
+         "4", "5", fg, bg, "iu"], tmp_path)
+    P = json.load(open(tmp_path / "iu.json"))["Parameters"]
+    assert P["Alphabet"] == "iupac nucleotide alphabet" and P["MaxAmbiguous"] == [1] and (P["M"], P["N"]) == (4, 5)
+    assert len(P["Kmers"]) == 5 and all(k.count("|") == 1 and sum(ch not in "acgt|" for ch in k) <= 2 for k in P["Kmers"])
+    trace = open(tmp_path / "iu.trace").read().splitlines()
+    last_loss, lam = float(trace[-1].split()[-1]), float(trace[-1].split()[-2])
+    out = run(["loss", "--lambda=%r" % lam, "iu.json", fg, bg], tmp_path).stdout
+    assert abs(float(out) - last_loss) < 1e-6

@@ -284,3 +284,38 @@ def test_kmers2_counter_restricted_to_a_class_list(ctx):
         sub = np.zeros(red.dim); sub[rc[rr[i]:rr[i + 1]]] = rv[rr[i]:rr[i + 1]]
         np.testing.assert_array_equal(sub[1:], full[observed + 1])
         assert sub[0] == full[0] == 1.0
+
+
+def test_iupac_alphabet_counts_by_brute_force(ctx):
+    """--alphabet=iupac-nucleotide: every code matches its nucleotide set, ambiguous codes (anything but a c g t) only at
+    inner positions and at most max-ambiguous of them; complements r<->y, k<->m, b<->v, d<->h.  The reference holds no
+    fixture for this alphabet (parity unpinned): counts against a regular-expression matcher."""
+    import re
+    sets = {"a": "a", "c": "c", "g": "g", "t": "t", "r": "ag", "y": "ct", "s": "cg", "w": "at", "k": "gt", "m": "ac",
+            "b": "cgt", "d": "agt", "h": "act", "v": "acg", "n": "acgt"}
+    comp = {"a": "t", "c": "g", "g": "c", "t": "a", "r": "y", "y": "r", "s": "s", "w": "w", "k": "m", "m": "k",
+            "b": "v", "v": "b", "d": "h", "h": "d", "n": "n"}
+    rng = np.random.default_rng(12)
+    seqs = ["".join("acgt"[v] for v in rng.integers(0, 4, size=90)) for _ in range(4)]
+    labels = np.array([1, 1, 0, 0], dtype=np.uint8)
+    kc = K.KmerClasses(3, 5, revcomp=True, alphabet="iupac-nucleotide", max_ambiguous=[2])
+    m = K.Matrix.from_sequences(ctx, seqs, labels, classes=kc)
+    assert m.dim == len(kc) + 1
+    rp, col, val = m.to_csr()
+    rows = [np.zeros(m.dim) for _ in seqs]
+    for i in range(len(seqs)):
+        rows[i][col[rp[i]:rp[i + 1]]] = val[rp[i]:rp[i + 1]]
+    for c in rng.choice(len(kc), size=400, replace=False):
+        a, b = kc.name(int(c)).split("|")
+        assert b == "".join(comp[ch] for ch in reversed(a)) and a[0] in "acgt" and a[-1] in "acgt"
+        assert sum(ch not in "acgt" for ch in a) <= 2 and kc.find(b) == c
+        pa = "".join("[%s]" % sets[ch] for ch in a); pb = "".join("[%s]" % sets[ch] for ch in b)
+        for i, sq in enumerate(seqs):
+            # a window counts once per member it matches (the gapped counter's rule, test_kmers1_known_answers_gapped_revcomp)
+            cnt = len(re.findall("(?=%s)" % pa, sq)) + (len(re.findall("(?=%s)" % pb, sq)) if a != b else 0)
+            assert rows[i][int(c) + 1] == cnt, (a, b, i)
+    # no ambiguous letters allowed: the plain --revcomp counter
+    m0 = K.Matrix.from_sequences(ctx, seqs, labels, classes=K.KmerClasses(3, 5, revcomp=True, alphabet="iupac-nucleotide", max_ambiguous=[0]))
+    mp = K.Matrix.from_sequences(ctx, seqs, labels, 3, 5, revcomp=True)
+    for x, y in zip(m0.to_csr(), mp.to_csr()):
+        np.testing.assert_array_equal(x, y)
