@@ -14,6 +14,8 @@ SHAPES = {"c2": (100000, 65536, 100), "c3": (125000, 1048576, 500)}
 n, m, N = SHAPES[sys.argv[1] if len(sys.argv) > 1 else "c2"]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ctx = K.Context(0)
+if os.environ.get("STEPS_COMM"):                       # the library's own RCCL communicator, one rank: the multi-GPU code path
+    ctx.init_rccl(K.rccl_unique_id(), 0, 1)
 rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
 mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
 del rowptr, col, val
