@@ -671,3 +671,46 @@ def test_dense_panel_mfma_gram(ctx, n, m, monkeypatch):
     th2, recs2 = K.cd_solve(ctx, red, np.zeros(m + 1), cw=cw, l1reg=l1, eps_loss=1e-10, max_iter=80)
     assert len(recs2) == len(recs)
     np.testing.assert_allclose(th, th2, rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,dim,per_row,fmt", [
+    (3700, 9000, 300, "q64c12"),        # 3 strips, ~10 rows per block: every workgroup's rows fit LDS (S copied there)
+    (3700, 9000, 300, "q64c13"),
+    (3000, 40000, 3000, "q64c13"),      # 5 wide strips, dense rows: the LDS copy beside two 64 KiB regions
+    (40000, 5000, 60, "q64c12"),        # 2 strips, 20k rows per strip: too many rows per workgroup for the LDS copy
+    (2100, 600000, 520, "q64c12"),      # 149 sparse strips of ~16 blocks: more strips than half the workgroups, short pieces
+    (9000, 4033, 500, "q64c12"),        # the second strip holds a single column
+])
+def test_q64_shapes_bitwise_against_u32(ctx, monkeypatch, n, dim, per_row, fmt):
+    """The row-streamed kernel in its variants (S from global memory or copied to LDS, one or two pieces per workgroup,
+    strips of a few blocks) against the tiled u32 format: the same integers, bit for bit, and the f64 column sums."""
+    rng = np.random.default_rng(n + dim)
+    cols = np.sort(rng.integers(1, dim, size=(n, per_row)), axis=1)
+    keep = np.ones_like(cols, dtype=bool); keep[:, 1:] = cols[:, 1:] != cols[:, :-1]
+    counts = rng.integers(1, 5, size=(n, per_row)).astype(np.float64)
+    rowlen = 1 + keep.sum(axis=1)
+    rowptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(rowlen, out=rowptr[1:])
+    col = np.zeros(rowptr[-1], dtype=np.int64); val = np.ones(rowptr[-1])
+    pos = (rowptr[:-1, None] + np.cumsum(keep, axis=1))[keep]
+    col[pos] = cols[keep]; val[pos] = counts[keep]
+    labels = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    if rowptr[-1] < (1 << 20):
+        pytest.skip("below the packed stream's size threshold")
+    monkeypatch.setenv("KLR_ENTRY_FORMAT", fmt)
+    m = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
+    assert m.layout()["format"] == fmt
+    cw = m.class_weights()
+    monkeypatch.setenv("KLR_ENTRY_FORMAT", "u32")
+    m2 = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
+    assert m2.layout()["format"] == "u32"
+    theta = np.zeros(dim); theta[0] = 0.3
+    idx = 1 + rng.choice(dim - 1, size=25, replace=False); theta[idx] = rng.normal(size=25) * 0.05
+    for th in (np.zeros(dim), theta):
+        g1 = K.gradient_dense(ctx, m, th, cw=cw)
+        g2 = K.gradient_dense(ctx, m2, th, cw=cw)
+        np.testing.assert_array_equal(g1, g2)
+    r = (0.5 - labels.astype(np.float64)) * np.where(labels > 0, cw[1], cw[0]) / n
+    g_ref = np.zeros(dim); np.add.at(g_ref, col, val * np.repeat(r, rowlen))
+    g0 = K.gradient_dense(ctx, m, np.zeros(dim), cw=cw)
+    assert np.max(np.abs(g0 - g_ref)) <= 1e-11 * np.max(np.abs(g_ref))
+    m.close(); m2.close()
