@@ -714,3 +714,24 @@ def test_q64_shapes_bitwise_against_u32(ctx, monkeypatch, n, dim, per_row, fmt):
     g0 = K.gradient_dense(ctx, m, np.zeros(dim), cw=cw)
     assert np.max(np.abs(g0 - g_ref)) <= 1e-11 * np.max(np.abs(g_ref))
     m.close(); m2.close()
+
+
+@pytest.mark.parametrize("switch", ["KLR_Q64_SLDS=0", "KLR_Q64_WGS=2", "KLR_Q64_BANK=0", "KLR_FINISH_NO_FLAT=1", "KLR_Q64_CUT=snap",
+                                    "KLR_Q64_PIECE_COST=0", "KLR_Q64_SNAP_TOL=0", "KLR_Q64_LDS_KIB=0"])
+def test_q64_switches_leave_the_sums_alone(ctx, synth_tiled, monkeypatch, switch):
+    """Every ingest / launch switch of the row-streamed sweep (column order, cuts, S in LDS, regions per workgroup,
+    finish form) changes the schedule only: the gradient is the same, bit for bit."""
+    x, labels = synth_tiled
+    monkeypatch.setenv("KLR_ENTRY_FORMAT", "q64c12")
+    m0 = upload(ctx, x, labels)
+    cw = O.class_weights(labels)
+    rng = np.random.default_rng(4)
+    theta = np.zeros(x.dim); theta[0] = 0.1
+    theta[1 + rng.choice(x.dim - 1, size=30, replace=False)] = rng.normal(size=30) * 0.1
+    g0 = K.gradient_dense(ctx, m0, theta, cw=cw)
+    name, value = switch.split("=")
+    monkeypatch.setenv(name, value)
+    m1 = upload(ctx, x, labels)
+    assert m1.layout()["format"] == "q64c12"
+    np.testing.assert_array_equal(K.gradient_dense(ctx, m1, theta, cw=cw), g0)
+    assert_g_close(g0, O.gradient(x, labels, theta, cw=cw))
