@@ -118,6 +118,10 @@ __device__ __forceinline__ void dpp_pairs(bool ha, int ja, double wa, int jc_own
   }
 }
 
+// packed upper triangle without the bias row: cells (j, k), 1 <= j < k < d, row after row
+__host__ __device__ __forceinline__ int gram_tri_count(int d) { return d >= 3 ? (d - 1) * (d - 2) / 2 : 0; }
+__host__ __device__ __forceinline__ int gram_tri_index(int j, int k, int d) { return (j - 1) * (d - 1) - (j - 1) * j / 2 + (k - j - 1); }
+
 template <bool LDSACC>
 __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                        const double* __restrict__ val, const double* __restrict__ w,
@@ -180,8 +184,13 @@ __global__ __launch_bounds__(1024) void k_gram_offdiag(const i64* __restrict__ r
   }
   if (LDSACC) {
     __syncthreads();
-    unsigned long long* out = Gi + (size_t)(blockIdx.x + 1) * dd;      // per-workgroup partial, coalesced stores
-    for (int t = threadIdx.x; t < dd; t += 1024) out[t] = gl[t];
+    // per-workgroup partial: only the cells that carry integers, j < k with j >= 1, packed row after row
+    // (gram_tri_index) -- half the bytes of the d x d square, written here and read back by the reduce
+    unsigned long long* out = Gi + (size_t)dd + (size_t)blockIdx.x * gram_tri_count(d);
+    for (int t = threadIdx.x; t < dd; t += 1024) {
+      const int j = t / d, k = t - j * d;
+      if (j >= 1 && j < k) out[gram_tri_index(j, k, d)] = gl[t];
+    }
   }
 }
 
@@ -333,16 +342,21 @@ __global__ __launch_bounds__(256) void k_gram_tiled_reduce(const unsigned long l
 
 // 64 cells x 4 partial lanes per block, 8 loads in flight per lane (one lane walking all 256 partials of a cell
 // took 66 us for 21 MB)
-__global__ __launch_bounds__(256) void k_gram_reduce(unsigned long long* __restrict__ Gi, int dd, int nblk) {
+__global__ __launch_bounds__(256) void k_gram_reduce(unsigned long long* __restrict__ Gi, int d, int nblk) {
   __shared__ unsigned long long sh[4][64];
+  const int dd = d * d;
   const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + cx;
+  const int j = t < dd ? t / d : 0, k = t < dd ? t % d : 0;
+  const bool upper = t < dd && j >= 1 && j < k;
+  const size_t ntri = (size_t)gram_tri_count(d);
+  const unsigned long long* part = Gi + dd + (upper ? gram_tri_index(j, k, d) : 0);
   unsigned long long v = 0ull;
-  if (t < dd) {
+  if (upper) {
     for (int b = 1 + ly; b <= nblk; b += 32) {
       unsigned long long x[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) x[u] = (b + 4 * u <= nblk) ? Gi[(size_t)(b + 4 * u) * dd + t] : 0ull;
+      for (int u = 0; u < 8; u++) x[u] = (b + 4 * u <= nblk) ? part[(size_t)(b + 4 * u - 1) * ntri] : 0ull;
       v += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     }
   }
@@ -363,12 +377,14 @@ __global__ __launch_bounds__(256) void k_gram_reduce_assemble(const unsigned lon
   const int t = blockIdx.x * 64 + cx;
   const int j = t < dd ? t / d : 0, k = t < dd ? t % d : 0;
   const bool upper = t < dd && j >= 1 && j < k;
+  const size_t ntri = (size_t)gram_tri_count(d);
+  const unsigned long long* part = Gi + dd + (upper ? gram_tri_index(j, k, d) : 0);
   unsigned long long v = 0ull;
   if (upper) {
     for (int b = 1 + ly; b <= nblk; b += 32) {
       unsigned long long x[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) x[u] = (b + 4 * u <= nblk) ? Gi[(size_t)(b + 4 * u) * dd + t] : 0ull;
+      for (int u = 0; u < 8; u++) x[u] = (b + 4 * u <= nblk) ? part[(size_t)(b + 4 * u - 1) * ntri] : 0ull;
       v += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     }
   }
@@ -1576,7 +1592,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
           assembled = true;
         } else
           hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
-                             d * d, (int)gram_blocks);
+                             d, (int)gram_blocks);
       } else if (gram_rows) {
         static bool attr = false;
         if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr = true; }
