@@ -23,6 +23,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
 # timing-only ablations of the sweep kernels (tools/ab_sweep.py, tools/ab_formats.py); never the shipped library
 if os.environ.get("KLR_ABLATIONS"):
     FLAGS.append("-DKLR_ABLATIONS")
+if os.environ.get("KLR_BUILD_DEFINES"):                     # development: extra -D switches, e.g. KLR_BUILD_DEFINES="KLR_GRAM_RB=4"
+    FLAGS += ["-D" + d for d in os.environ["KLR_BUILD_DEFINES"].split()]
 
 
 def hipcc():
