@@ -113,8 +113,10 @@ class Rank:
         if self.comm:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            import datetime
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", self.local_rank))
+                                    device_id=torch.device("cuda", self.local_rank),
+                                    timeout=datetime.timedelta(seconds=300))      # a rank that never arrives fails the run, not hangs it
         self.ctx = K.Context(self.local_rank)
         if self.comm:
             # RCCL communicator owned by the library: one all-reduce per sweep on the library's stream
