@@ -7,8 +7,8 @@ g = X'(cw (sigma - y))/n over the packed k-mer count stream, ONE all-reduce of [
 and the top-2N |g| selection + lambda rule.  Inputs are resident in HBM before the timed region.
 
 Workload (BASELINE.json configs[2]): synthetic 100k sequences x 65,536 8-mers per GPU (weak
-scaling: rows grow with N), --lambda-auto=100, theta on 100 selected columns.  At N = 8 (or with
---configs3) the line also carries configs[3]: 125,000 x 1,048,576 per GPU, --lambda-auto=500.
+scaling: rows grow with N), --lambda-auto=100, theta on 100 selected columns.  At every N the line also
+carries configs[3]'s per-GPU shard: 125,000 x 1,048,576, --lambda-auto=500 (--no-configs3 skips it).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -48,9 +48,9 @@ def parse(argv=None):
     ap.add_argument("--cd-sweeps", type=int, default=64, help="reduced-problem CD sweeps timed for cd_sweeps_per_s")
     ap.add_argument("--force-comm", action="store_true",
                     help="set up the process group and the library's RCCL communicator even for one rank (plumbing check)")
-    ap.add_argument("--configs3", action="store_true",
-                    help="also run BASELINE configs[3]'s per-GPU shard (125,000 x 1,048,576, --lambda-auto=500); default at 8 GPUs")
-    ap.add_argument("--no-configs3", action="store_true")
+    ap.add_argument("--configs3", action="store_true", help="(default since round 3) kept for old command lines")
+    ap.add_argument("--no-configs3", action="store_true",
+                    help="skip BASELINE configs[3]'s per-GPU shard (125,000 x 1,048,576, --lambda-auto=500), which every N runs by default")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous rehearsal on the CPU (gloo): no GPU work, the line says dry_run")
     return ap.parse_args(argv)
@@ -119,10 +119,13 @@ class Rank:
                                     timeout=datetime.timedelta(seconds=300))      # a rank that never arrives fails the run, not hangs it
         self.ctx = K.Context(self.local_rank)
         if self.comm:
-            # RCCL communicator owned by the library: one all-reduce per sweep on the library's stream
+            # RCCL communicator owned by the library: one collective per sweep on the library's stream.  klr_ctx_init_rccl
+            # ends with the collective self-check ([1, rank] as int64 must come back as [N, N(N-1)/2]; f64, reduce-scatter
+            # and all-gather alike) and raises if the communicator does not reduce over the ranks it claims
             ids = [K.rccl_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             self.ctx.init_rccl(ids[0], self.rank, self.world)
+            assert self.ctx.comm_stats()["checked"]
 
     def fence(self):
         self.ctx.synchronize()
@@ -299,9 +302,10 @@ def main(argv=None):
                                    frac=round(alg_bytes / (in_situ["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if in_situ["kernel_avg_ms"] > 0 else 0.0)
     info = ctx.comm_info()
     ar_ms = ctx.allreduce_time(m + 6, dtype=1, iters=20) if R.comm else 0.0
+    stats_c2 = ctx.comm_stats()
 
     configs3 = None
-    if (world == 8 or args.configs3) and not args.no_configs3:
+    if not args.no_configs3:                   # at EVERY N: the 1 -> 8 curve of the 1M-column shape needs all its points
         full.close(); red.close()
         full = red = None
         configs3 = configs3_leg(R, estimate_leg)
@@ -323,7 +327,8 @@ def main(argv=None):
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
-                     "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N)},
+                     "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N),
+                     "selfcheck": "passed" if R.comm else "no communicator", "stats": stats_c2},
             "cd_sweeps_per_s": cd["sweeps_per_s"], "cd_sweeps": cd,
             "cd_solve": {"sweeps_to_converge": n_sweeps_solve, "seconds": round(t_solve, 4), "nonzero": int(np.count_nonzero(theta[1:]))},
             "estimate_lambda_auto": estimate,
@@ -395,6 +400,7 @@ def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, w
     in_situ = sweep_kernel_in_estimate(R, full, [N])
     roofline["in_estimate"] = dict(in_situ, frac=round(alg_bytes / (in_situ["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if in_situ["kernel_avg_ms"] > 0 else 0.0)
     info = ctx.comm_info()
+    stats = ctx.comm_stats()
     full.close(); red.close()
     return {"config": {"workload": "synthetic %d seqs/GPU x %d k-mer columns, %d draws/row, --lambda-auto=%d (BASELINE configs[3]: "
                                    "1M x 1M over 8 GPUs)" % (n_local, m, draws, N),
@@ -404,7 +410,7 @@ def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, w
             "roofline": roofline,
             "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
                      "allreduce_elements": m + 6 if R.comm else 0,
-                     "sweep_collective": sweep_collective(world, m, N)},
+                     "sweep_collective": sweep_collective(world, m, N), "stats": stats},
             "estimate_lambda_auto": est,
             "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]}}
 

@@ -78,9 +78,37 @@ int         klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_
 int         klr_rccl_unique_id(void* id128);
 int         klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int nranks);
 
+/* built-in hooks for ranks that are processes of ONE host without a device interconnect between them (several ranks
+ * on one GPU in tests; `kmerlr --ranks=N --transport=shm`): host-staged through a shared memory region of
+ * klr_shm_region_bytes(nranks) bytes that the launcher maps MAP_SHARED (before fork, or by name) and initialises once
+ * with klr_shm_region_init before any rank attaches.  Installs all-reduce, reduce-scatter and all-gather and runs the
+ * collective self-check.  Sums are taken in rank order by every rank: all ranks hold bitwise the same result. */
+int64_t     klr_shm_region_bytes(int nranks);
+int         klr_shm_region_init(void* region, int64_t bytes, int nranks);
+void        klr_shm_region_abort(void* region);      /* releases ranks waiting at a barrier of the region (a rank died) */
+int         klr_ctx_init_shm(klr_ctx* ctx, void* region, int64_t bytes, int rank, int nranks);
+/* sums a HOST buffer over the ranks through the installed hook (no-op without one): how a launcher collects per-row
+ * results of the shards (each rank fills its own rows, zeros elsewhere).  dtype KLR_F64 | KLR_I64. */
+int         klr_allreduce_host(klr_ctx* ctx, void* host_buf, int64_t count, int dtype);
+
 /* what the ctx will reduce over: rank / nranks as given to the setters above; rccl_ranks = ncclCommCount of the built-in
  * communicator (0 when there is none).  Any output may be NULL. */
 int         klr_ctx_comm_info(const klr_ctx* ctx, int* rank, int* nranks, int* rccl_ranks);
+
+/* Collective self-check of whatever hooks are installed (klr_ctx_init_rccl runs it by itself and fails if it fails):
+ * all-reduce of [1, rank, ...] as int64 and f64 must return [N, N(N-1)/2, ...], reduce-scatter and all-gather their
+ * documented slices.  Every rank must call it.  The reduce-scatter form of the sweep's collective is used only on a
+ * context that passed. */
+int         klr_ctx_comm_selfcheck(klr_ctx* ctx);
+/* full-width sweeps by the collective they posted, and how many reduce-scatter sweeps had to repeat as an all-reduce
+ * (a rank's candidate list could not prove lambda: klr_ctx_set_collectives); checked = the self-check passed */
+int         klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce, int64_t* sweeps_scatter,
+                               int64_t* scatter_fallbacks, int* checked);
+
+/* KLR_* switches.  A context reads the process environment ONCE, in klr_ctx_create; later changes
+ * go through these calls (value NULL unsets).  klr_ctx_reload_env re-reads the environment. */
+int         klr_ctx_set_option(klr_ctx* ctx, const char* name, const char* value);
+int         klr_ctx_reload_env(klr_ctx* ctx);
 
 /* ---- sparse k-mer / score matrix ------------------------------------------------------- */
 /* Replaces the []ConstVector the reference hands to SetSparseData (kmerLr_estimator.go:152)

@@ -43,6 +43,7 @@ typedef struct klr_backend {
   int  (*set_active_rows)(klr_ctx*, klr_mat*, const uint8_t*, int64_t);
   int  (*log_pdf)(klr_ctx*, const klr_mat*, const double*, double*);
   int  (*expand_cooccurrence)(klr_ctx*, const klr_mat*, klr_mat**);      /* co-occurrence mode only; may be NULL */
+  int  (*transform_fit)(klr_ctx*, const klr_mat*, int, double*, double*, int*);   /* per-fold TransformFull.Fit (validation sets only); may be NULL */
 } klr_backend;
 
 /* the HIP table for an existing context */
@@ -66,6 +67,11 @@ typedef struct klr_config {
   double  l2reg;             /* L2Reg of the estimator (0 in the reference's CLI)    */
   int     cooccurrence;      /* --co-occurrence (used by klr_cooccurrence_prepare's callers) */
   int64_t copreselection;    /* --co-preselection, 0 = none                          */
+  double  validation_size;   /* --validation-size: fraction of the rows set aside to choose among the lambda_auto
+                              * classifiers (getCvGroups, kmerLr_crossvalidation.go:56-90); 0 = none        */
+  int     data_transform;    /* --data-transform as KLR_TR_* (0 none): only read where the driver has to FIT the
+                              * transform itself, i.e. per fold when a validation set is split off
+                              * (kmerLr_estimator_ensemble.go:116-117 fits on train + test rows)            */
 } klr_config;
 
 void klr_config_default(klr_config* cfg);
@@ -115,6 +121,19 @@ int  klr_estimator_crossvalidate(klr_estimator* est, klr_mat* data, int64_t row0
                                  double* loss_test);
 /* fold assignment alone: groups[i] for global rows [row0, row0+n_local) */
 void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t row0, int64_t n_local, int32_t* groups);
+/* getCvGroups in full (kmerLr_crossvalidation.go:56-94): groups as above (-1 everywhere for k_fold <= 1) and the
+ * validation flags -- row i of block [i0, i0 + fold) is flagged while i0 < val_ratio * n and i0 + fold < n --, both
+ * permuted by the same shuffle.  validation may be NULL.  A row is in fold f's test set when groups == f, else in
+ * its validation set when flagged, else in its training set (filterCvGroup :96-120). */
+void klr_cv_groups_val(int64_t n_all, int k_fold, double val_ratio, int64_t seed, int64_t row0, int64_t n_local,
+                       int32_t* groups, uint8_t* validation);
+/* With cfg.validation_size > 0 klr_estimator_crossvalidate also accepts k_fold = 1 (no test set: the `learn` run of
+ * kmerLr_learn.go:89-108 with --validation-size), estimates every lambda_auto on the training rows, keeps for each
+ * fold ONLY the classifier with the lowest loss on the fold's validation rows (kmerLr_estimator_ensemble.go:119-135)
+ * and fills row 0 of predictions / loss_train / loss_test alone; klr_estimator_n_classifiers is then k_fold (or 1).
+ * Estimator of fold f after a cross-validation (its trace, path and classifiers: learn_parameters writes one
+ * `_cv<f+1>` file set per fold, kmerLr_learn.go:45-66); owned by `est`, valid until its next call. */
+klr_estimator* klr_estimator_fold(const klr_estimator* est, int fold);
 /* SaveCrossvalidation / SaveCrossvalidationLoss (kmerLr_crossvalidation.go:122-165): rows in fold order */
 int  klr_save_crossvalidation(const char* filename, const double* predictions, const uint8_t* labels,
                               const int32_t* groups, int64_t n, int k_fold);

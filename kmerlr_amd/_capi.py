@@ -38,6 +38,15 @@ SIGNATURES = {
     "klr_ctx_init_rccl": (_int, [_vp, _vp, _int, _int]),
     "klr_ctx_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int), C.POINTER(_int)]),
     "klr_allreduce_time": (_int, [_vp, _i64, _int, _int, C.POINTER(_dbl)]),
+    "klr_shm_region_bytes": (_i64, [_int]),
+    "klr_shm_region_init": (_int, [_vp, _i64, _int]),
+    "klr_shm_region_abort": (None, [_vp]),
+    "klr_ctx_init_shm": (_int, [_vp, _vp, _i64, _int, _int]),
+    "klr_allreduce_host": (_int, [_vp, _vp, _i64, _int]),
+    "klr_ctx_comm_selfcheck": (_int, [_vp]),
+    "klr_ctx_comm_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
+    "klr_ctx_set_option": (_int, [_vp, C.c_char_p, C.c_char_p]),
+    "klr_ctx_reload_env": (_int, [_vp]),
     "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
     "klr_mat_from_sequences": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _i64, _PVP]),
     "klr_kmer_classes_create": (_int, [_vp, _PVP, _vp, _i64]),
@@ -115,12 +124,23 @@ def _check(ctx_handle, rc):
 class Context:
     """klr_ctx: one GPU, one stream, single-threaded."""
 
+    _live = None
+
     def __init__(self, device_id=0):
         self._h = C.c_void_p()
         rc = lib().klr_ctx_create(device_id, C.byref(self._h))
         if rc != 0:
             raise KlrError("klr_ctx_create failed (%d): %s" % (rc, (lib().klr_last_error(None) or b"").decode()))
         self._cb = None
+        if Context._live is None:
+            import weakref
+            Context._live = weakref.WeakSet()
+        Context._live.add(self)
+
+    @staticmethod
+    def live():
+        """Contexts that have not been closed (tests set KLR_* switches on all of them)."""
+        return [c for c in (Context._live or ()) if c._h]
 
     def close(self):
         if self._h:
@@ -183,6 +203,31 @@ class Context:
         r, n, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self.check(lib().klr_ctx_comm_info(self._h, C.byref(r), C.byref(n), C.byref(c)))
         return dict(rank=r.value, nranks=n.value, rccl_ranks=c.value)
+
+    def init_shm(self, region_addr, nbytes, rank, nranks):
+        """Host-staged collectives through a shared region (klr_ctx_init_shm); region_addr = its address in this process."""
+        self.check(lib().klr_ctx_init_shm(self._h, C.c_void_p(region_addr), int(nbytes), rank, nranks))
+
+    def allreduce_host(self, arr):
+        """Sums a float64 / int64 numpy array over the ranks in place (klr_allreduce_host)."""
+        assert arr.dtype in (np.float64, np.int64) and arr.flags["C_CONTIGUOUS"]
+        self.check(lib().klr_allreduce_host(self._h, _p(arr), arr.size, 1 if arr.dtype == np.int64 else 0))
+
+    def comm_selfcheck(self):
+        """Collective: runs every installed hook on small known buffers; raises when a result is wrong."""
+        self.check(lib().klr_ctx_comm_selfcheck(self._h))
+
+    def comm_stats(self):
+        a, s_, f, c = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        self.check(lib().klr_ctx_comm_stats(self._h, C.byref(a), C.byref(s_), C.byref(f), C.byref(c)))
+        return dict(sweeps_allreduce=a.value, sweeps_scatter=s_.value, scatter_fallbacks=f.value, checked=bool(c.value))
+
+    def set_option(self, name, value):
+        """KLR_* switch of this context (value None unsets); contexts read the environment only when they are created."""
+        self.check(lib().klr_ctx_set_option(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def reload_env(self):
+        self.check(lib().klr_ctx_reload_env(self._h))
 
     def allreduce_time(self, count, dtype=1, iters=20):
         ms = C.c_double(0.0)

@@ -12,7 +12,7 @@ from . import _capi
 class Backend(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ctx", "last_error", "mat_shape", "mat_destroy", "class_weights", "gradient",
                                           "loss", "select_columns", "sweep_select", "cd_solve", "set_active_rows",
-                                          "log_pdf", "expand_cooccurrence")]
+                                          "log_pdf", "expand_cooccurrence", "transform_fit")]
 
 
 class Config(C.Structure):
@@ -21,7 +21,8 @@ class Config(C.Structure):
                 ("max_iterations", C.c_int64), ("epsilon", C.c_double), ("epsilon_lambda", C.c_double),
                 ("epsilon_loss", C.c_double), ("eval_loss", C.c_int), ("balance", C.c_int), ("penalty_free", C.c_int),
                 ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double),
-                ("cooccurrence", C.c_int), ("copreselection", C.c_int64)]
+                ("cooccurrence", C.c_int), ("copreselection", C.c_int64), ("validation_size", C.c_double),
+                ("data_transform", C.c_int)]
 
 
 def bind_driver(L):
@@ -52,6 +53,9 @@ def bind_driver(L):
     L.klr_estimator_crossvalidate.restype = C.c_int
     L.klr_estimator_crossvalidate.argtypes = [vp, vp, i64, i64, C.c_int, i64, vp, i64, vp, vp, vp, vp, vp, vp]
     L.klr_cv_groups.argtypes = [i64, C.c_int, i64, i64, i64, vp]
+    L.klr_cv_groups_val.argtypes = [i64, C.c_int, C.c_double, i64, i64, i64, vp, vp]
+    L.klr_estimator_fold.restype = vp
+    L.klr_estimator_fold.argtypes = [vp, C.c_int]
     L.klr_save_crossvalidation.restype = C.c_int
     L.klr_save_crossvalidation.argtypes = [C.c_char_p, vp, vp, vp, i64, C.c_int]
     L.klr_save_crossvalidation_loss.restype = C.c_int

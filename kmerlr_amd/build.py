@@ -13,9 +13,9 @@ LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libkmerlr_hip.so")
 
 SOURCES = ["klr_ctx.hip", "klr_mat.hip", "klr_sweep.hip", "klr_select.hip", "klr_solve.hip",
-           "klr_synth.cpp", "klr_driver.cpp", "klr_ingest.hip", "klr_kmers.cpp"]
+           "klr_synth.cpp", "klr_driver.cpp", "klr_ingest.hip", "klr_kmers.cpp", "klr_shm.hip"]
 HEADERS = [os.path.join(CSRC, "klr_internal.h"), os.path.join(HERE, "..", "include", "kmerlr.h"),
-           os.path.join(HERE, "..", "include", "kmerlr_driver.h")]
+           os.path.join(HERE, "..", "include", "kmerlr_driver.h"), os.path.join(CSRC, "klr_kmers.h")]
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
          "-Wno-unused-result", "-fno-gpu-rdc"]

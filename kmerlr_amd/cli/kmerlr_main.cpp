@@ -1,11 +1,26 @@
-// kmerlr -- command line of the MI355X build: `learn` and `loss` for --type=kmerLr|scoresLr, mirroring the
+// kmerlr -- command line of the MI355X build: `learn`, `loss` and `predict` for --type=kmerLr|scoresLr, mirroring the
 // reference CLI for the hot path (kmerLr.go:79-175, kmerLr_learn.go:112-338, scoresLr_learn.go:106-286,
-// kmerLr_loss.go:32-106).  Host-side ingest (CSV tables, FASTA k-mer counts, transform fitting) feeds the
-// C ABI of libkmerlr_hip.so; all training arithmetic runs on the GPU.  There is no CPU fallback.
+// kmerLr_loss.go:32-106).  Host-side ingest (CSV tables, FASTA records) feeds the C ABI of libkmerlr_hip.so; k-mer
+// counting, transform fitting and all training arithmetic run on the GPU.  There is no CPU fallback.
 //
-//   kmerlr [--type=kmerLr|scoresLr] [-v|-vv] [--device=N] learn [options] [<M> <N>] FG BG BASENAME
-//   kmerlr [--type=...] loss [--lambda=F] MODEL.json FG BG
+//   kmerlr [--type=kmerLr|scoresLr] [-v|-vv] [--seed=S] [--device=N] learn [options] <<M> <N>|<MODEL.json>> FG BG BASENAME
+//   kmerlr [--type=...] loss [--lambda=F] [--balance] MODEL.json FG BG [RESULT.table]
+//   kmerlr [--type=...] predict MODEL.json DATA [RESULT.table]
+//
+// Several GPUs of one node (north_star: "samples shard naturally across the 8 GPUs of one node"):
+//   kmerlr --ranks=N [--transport=rccl|shm] [--devices=a,b,..] learn ...
+// The process parses its arguments and then, BEFORE anything touches HIP, forks N ranks.  Rank r reads only its
+// contiguous block of the rows of FG followed by BG, builds its shard on its own GPU (rank r -> device r; with
+// --transport=shm every rank on --device unless --devices says otherwise) with n_total = all rows, joins the
+// collectives -- RCCL over xGMI (the ncclUniqueId travels through a shared page) or the library's host-staged shared
+// memory hooks -- and runs the same replicated driver; rank 0 alone writes .json / .trace / .path / .table.
+// Options are the reference's (getopt: `--opt=value` and `--opt value`); an unknown option ends the run.
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdarg>
 #include <cmath>
@@ -20,7 +35,7 @@
 
 #include "../../include/kmerlr_driver.h"
 
-struct DataSet {                       // ScoresDataSet / KmerDataSet: fg rows first (labels true)
+struct DataSet {                       // ScoresDataSet / KmerDataSet: fg rows first (labels true); rows of THIS rank
   std::vector<int64_t> rowptr{0}, col;
   std::vector<double> val;
   std::vector<uint8_t> labels;
@@ -28,27 +43,48 @@ struct DataSet {                       // ScoresDataSet / KmerDataSet: fg rows f
   std::vector<std::string> names;
 };
 
+static int g_verbose = 0;
+static int g_rank = 0, g_nranks = 1;
+static std::string g_seed = "1";
+
 [[noreturn]] static void die(const char* fmt, ...) {
+  if (g_nranks > 1) fprintf(stderr, "[rank %d] ", g_rank);
   va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
   fputc('\n', stderr);
-  exit(1);
+  fflush(stderr);
+  _exit(1);                              // a forked rank must not run the parent's exit handlers
 }
 
-static int g_verbose = 0;
-static std::string g_seed = "1";
-static void say(int level, const char* fmt, ...) {
-  if (g_verbose < level) return;
+static void say(int level, const char* fmt, ...) {   // PrintStderr (kmerLr_io.go:30-34); one voice: rank 0
+  if (g_verbose < level || g_rank != 0) return;
   va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
+}
+
+// rows [r0, r1) of `n` rows for rank `rank` of `world` (kmerlr_amd/sharding.py: contiguous, balanced)
+static void shard_rows(int64_t n, int rank, int world, int64_t* r0, int64_t* r1) {
+  *r0 = n * rank / world; *r1 = n * (rank + 1) / world;
+}
+
+// reduce_samples (kmerLr_data.go:288-303, scoresLr_data.go:230-245): the first m1 fg and m2 bg samples
+static void reduce_samples(int64_t max_samples, int64_t* n1, int64_t* n2) {
+  if (max_samples == 0 || *n1 + *n2 <= max_samples) return;
+  const int64_t m1 = (int64_t)((double)*n1 / (double)(*n1 + *n2) * (double)max_samples);
+  const int64_t m2 = max_samples - m1;
+  if (m1 <= 0 || m2 <= 0) die("cannot reduce samples");
+  say(1, "Reduced training data from (%lld,%lld) to (%lld,%lld) samples\n", (long long)*n1, (long long)*n2, (long long)m1, (long long)m2);
+  *n1 = m1; *n2 = m2;
 }
 
 // ---- scores tables: read_scores_table + convert_scores (scoresLr_data.go:56-145) ---------------------
-static void read_scores(const std::string& fn, bool header, uint8_t label, DataSet& d) {
+// rows [first, last) of the table go into d (a rank's block); every row is parsed for the checks the reference makes.
+// Returns the number of data rows in the file.
+static int64_t read_scores(const std::string& fn, bool header, uint8_t label, DataSet& d, int64_t first = 0, int64_t last = INT64_MAX) {
   say(1, "Reading scores from `%s'... ", fn.c_str());
   std::ifstream f(fn);
   if (!f) die("failed\ncannot open `%s'", fn.c_str());
   std::string line;
   bool need_header = header;
-  int64_t lineno = 0;
+  int64_t lineno = 0, row = 0;
   while (std::getline(f, line)) {
     lineno++;
     if (line.empty()) continue;
@@ -57,7 +93,8 @@ static void read_scores(const std::string& fn, bool header, uint8_t label, DataS
     if (need_header) { if (d.names.empty()) d.names = fields; need_header = false; continue; }
     if (d.dim == 0) d.dim = (int64_t)fields.size() + 1;
     if ((int64_t)fields.size() + 1 != d.dim) die("failed\nError: data has variable number of features");
-    d.col.push_back(0); d.val.push_back(1.0);                      // bias
+    const bool keep = row >= first && row < last;
+    if (keep) { d.col.push_back(0); d.val.push_back(1.0); }        // bias
     for (size_t j = 0; j < fields.size(); j++) {
       char* end = nullptr;
       std::string t = fields[j];
@@ -65,12 +102,21 @@ static void read_scores(const std::string& fn, bool header, uint8_t label, DataS
       t = a == std::string::npos ? "" : t.substr(a, b - a + 1);
       const double v = strtod(t.c_str(), &end);
       if (t.empty() || *end) die("failed\nparsing scores failed at line `%lld'", (long long)lineno);
-      d.col.push_back((int64_t)j + 1); d.val.push_back(v);         // every column stored, zeros included
+      if (keep) { d.col.push_back((int64_t)j + 1); d.val.push_back(v); }   // every column stored, zeros included
     }
-    d.rowptr.push_back((int64_t)d.col.size());
-    d.labels.push_back(label);
+    if (keep) { d.rowptr.push_back((int64_t)d.col.size()); d.labels.push_back(label); }
+    row++;
   }
   say(1, "done\n");
+  return row;
+}
+
+static int64_t count_scores_rows(const std::string& fn, bool header) {
+  std::ifstream f(fn);
+  if (!f) die("cannot open `%s'", fn.c_str());
+  std::string line; int64_t n = 0; bool need_header = header;
+  while (std::getline(f, line)) { if (line.empty()) continue; if (need_header) { need_header = false; continue; } n++; }
+  return n;
 }
 
 // ---- k-mer classes (klr_kmer_classes: NewKmerCounter's arguments, kmerLr_learn.go:94,116-122,193-214); the counting
@@ -125,31 +171,45 @@ static void parse_max_ambiguous(const std::string& v, int M, int N, std::vector<
 
 struct SeqSet { std::string blob; std::vector<int64_t> off{0}; std::vector<uint8_t> labels; };
 
-// import_fasta (kmerLr_data.go:101-123): sequences only; counting happens on the device
-static void read_fasta(const std::string& fn, uint8_t label, SeqSet& q) {
+// import_fasta (kmerLr_data.go:101-123): sequences only; counting happens on the device.  Records [first, last) are
+// kept (a rank's block of the file); returns the number of records in the file.
+static int64_t read_fasta(const std::string& fn, uint8_t label, SeqSet& q, int64_t first = 0, int64_t last = INT64_MAX) {
   say(1, "Reading sequences from `%s'... ", fn.c_str());
   std::ifstream f(fn);
   if (!f) die("failed\ncannot open `%s'", fn.c_str());
   std::string line; bool have = false;
+  int64_t rec = -1;
+  bool keep = false;
+  auto close_rec = [&]() { if (have && keep) { q.off.push_back((int64_t)q.blob.size()); q.labels.push_back(label); } };
   while (std::getline(f, line)) {
     if (!line.empty() && line[0] == '>') {
-      if (have) { q.off.push_back((int64_t)q.blob.size()); q.labels.push_back(label); }
-      have = true; continue;
+      close_rec();
+      have = true; rec++; keep = rec >= first && rec < last;
+      continue;
     }
-    if (have) for (char c : line) if (!isspace((unsigned char)c)) q.blob.push_back(c);
+    if (have && keep) for (char c : line) if (!isspace((unsigned char)c)) q.blob.push_back(c);
   }
-  if (have) { q.off.push_back((int64_t)q.blob.size()); q.labels.push_back(label); }
+  close_rec();
   say(1, "done\n");
+  return rec + 1;
+}
+
+static int64_t count_fasta_records(const std::string& fn) {
+  std::ifstream f(fn);
+  if (!f) die("cannot open `%s'", fn.c_str());
+  std::string line; int64_t n = 0;
+  while (std::getline(f, line)) if (!line.empty() && line[0] == '>') n++;
+  return n;
 }
 
 // scan_sequences + convert_counts on the device (klr_mat_from_sequences)
-static klr_mat* count_kmers(klr_ctx* ctx, const SeqSet& q, const KmerSpec& ks) {
-  if (q.labels.empty()) die("Error: no training data given");
+static klr_mat* count_kmers(klr_ctx* ctx, const SeqSet& q, const KmerSpec& ks, int64_t n_total = 0) {
+  if (q.labels.empty()) die(g_nranks > 1 ? "Error: this rank holds no rows (fewer samples than ranks?)" : "Error: no training data given");
   say(1, "Counting k-mers on the device... ");
   klr_mat* mat = nullptr;
   const std::string& blob = q.blob.empty() ? std::string("N") : q.blob;
   if (klr_mat_from_sequences_classes(ctx, blob.data(), q.off.data(), (int64_t)q.labels.size(), ks.kc, ks.binarize ? 1 : 0,
-                                     q.labels.data(), 0, &mat) != KLR_OK)
+                                     q.labels.data(), n_total, &mat) != KLR_OK)
     die("failed\n%s", klr_last_error(ctx));
   say(1, "done\n");
   return mat;
@@ -198,7 +258,6 @@ static size_t json_key(const std::string& s, const std::string& key, size_t from
   const size_t p = s.find("\"" + key + "\"", from);
   return p == std::string::npos ? p : s.find(':', p) + 1;
 }
-static bool json_has(const std::string& s, const std::string& key) { return json_key(s, key) != std::string::npos; }
 static long json_int(const std::string& s, const std::string& key) {
   const size_t p = json_key(s, key);
   if (p == std::string::npos) die("invalid config file: missing %s", key.c_str());
@@ -347,117 +406,355 @@ static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& 
   return red;
 }
 
+// ---- options: the reference's getopt tables (kmerLr.go:85-90, kmerLr_learn.go:116-149, scoresLr_learn.go:109-136,
+// kmerLr_loss.go:71-73, scoresLr_loss.go:47-50, scoresLr_predict.go:48-49) plus this build's launcher options ----------
+struct OptSpec { const char* name; bool takes_value; };
+static const OptSpec GLOBAL_OPTS[] = {
+  {"type", true}, {"threads", true}, {"seed", true}, {"help", false}, {"verbose", false}, {"version", false},
+  {"device", true}, {"devices", true}, {"ranks", true}, {"transport", true}, {nullptr, false}};
+static const OptSpec LEARN_OPTS[] = {
+  {"lambda", true}, {"lambda-auto", true}, {"max-features", true}, {"balance", false}, {"co-occurrence", false},
+  {"co-preselection", true}, {"ensemble-size", true}, {"ensemble-summary", true}, {"max-epochs", true},
+  {"max-iterations", true}, {"max-samples", true}, {"epsilon", true}, {"epsilon-lambda", true}, {"epsilon-loss", true},
+  {"save-trace", false}, {"save-path", false}, {"eval-loss", false}, {"data-transform", true}, {"k-fold-cv", true},
+  {"validation-size", true}, {"scale-step-size", true}, {"penalty-free", false}, {"adaptive-step-size", false},
+  {"threads-cv", true}, {"threads-saga", true}, {"threads-lr", true}, {"help", false}, {"seed", true},
+  // kmerLr only
+  {"alphabet", true}, {"binarize", false}, {"complement", false}, {"max-ambiguous", true}, {"reverse", false}, {"revcomp", false},
+  // scoresLr only
+  {"header", false}, {nullptr, false}};
+static const OptSpec LOSS_OPTS[] = {{"balance", false}, {"lambda", true}, {"header", false}, {"help", false}, {nullptr, false}};
+static const OptSpec PREDICT_OPTS[] = {{"header", false}, {"help", false}, {nullptr, false}};
+static const char* KMER_ONLY[] = {"alphabet", "binarize", "complement", "max-ambiguous", "reverse", "revcomp", nullptr};
+static const char* SCORES_ONLY[] = {"header", nullptr};
+
 struct Options { std::map<std::string, std::string> kv; std::vector<std::string> pos; };
-static Options parse(int argc, char** argv, int from) {
+static const OptSpec* find_opt(const OptSpec* table, const std::string& name) {
+  for (const OptSpec* o = table; o->name; o++) if (name == o->name) return o;
+  return nullptr;
+}
+// getopt as the reference uses it: `--name=value`, `--name value`, `-v` / `-vv` / `-h`, `--` ends the options; an
+// option the table does not hold ends the run (the reference prints its usage and exits).  stop_at_positional: the
+// global options end at the command word.
+static Options parse(int argc, char** argv, int from, const OptSpec* table, bool stop_at_positional, int* next) {
   Options o;
-  for (int i = from; i < argc; i++) {
+  int i = from;
+  bool only_pos = false;
+  for (; i < argc; i++) {
     std::string a = argv[i];
+    if (only_pos) { o.pos.push_back(a); continue; }
+    if (a == "--") { only_pos = true; continue; }
     if (a.rfind("--", 0) == 0) {
-      size_t eq = a.find('=');
-      if (eq == std::string::npos) o.kv[a.substr(2)] = "true"; else o.kv[a.substr(2, eq - 2)] = a.substr(eq + 1);
-    } else if (a == "-v") g_verbose = std::max(g_verbose, 1);
-    else if (a == "-vv") g_verbose = 2;
-    else o.pos.push_back(a);
+      const size_t eq = a.find('=');
+      const std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+      const OptSpec* sp = find_opt(table, name);
+      if (!sp) die("unknown option `--%s'", name.c_str());
+      if (!sp->takes_value) {
+        if (eq != std::string::npos) die("option `--%s' takes no value", name.c_str());
+        if (name == "verbose") g_verbose++;
+        o.kv[name] = "true";
+      } else if (eq != std::string::npos) o.kv[name] = a.substr(eq + 1);
+      else {
+        if (i + 1 >= argc) die("option `--%s' needs a value", name.c_str());
+        o.kv[name] = argv[++i];
+      }
+    } else if (a.size() > 1 && a[0] == '-' && !isdigit((unsigned char)a[1]) && a[1] != '.') {
+      for (size_t k = 1; k < a.size(); k++) {
+        if (a[k] == 'v') g_verbose++;
+        else if (a[k] == 'h') o.kv["help"] = "true";
+        else die("unknown option `-%c'", a[k]);
+      }
+    } else {
+      if (stop_at_positional) break;
+      o.pos.push_back(a);
+    }
   }
+  if (next) *next = i;
   return o;
 }
 static std::string opt(const Options& o, const char* k, const char* def) { auto it = o.kv.find(k); return it == o.kv.end() ? def : it->second; }
 static bool flag(const Options& o, const char* k) { return o.kv.count(k) != 0; }
+static double opt_float(const Options& o, const char* k, const char* def) {           // strconv.ParseFloat + log.Fatal
+  const std::string v = opt(o, k, def);
+  char* end = nullptr;
+  const double x = strtod(v.c_str(), &end);
+  if (v.empty() || *end) die("option `--%s': invalid number `%s'", k, v.c_str());
+  return x;
+}
+static long long opt_int(const Options& o, const char* k, const char* def) {
+  const std::string v = opt(o, k, def);
+  char* end = nullptr;
+  const long long x = strtoll(v.c_str(), &end, 10);
+  if (v.empty() || *end) die("option `--%s': invalid integer `%s'", k, v.c_str());
+  return x;
+}
+
+static int transform_kind(const std::string& kind_) {
+  std::string kind = kind_;
+  for (auto& c : kind) c = (char)tolower((unsigned char)c);
+  if (kind.empty() || kind == "none") return 0;
+  if (kind == "standardizer") return KLR_TR_STANDARDIZER;
+  if (kind == "variance-scaler") return KLR_TR_VARIANCE;
+  if (kind == "max-abs-scaler") return KLR_TR_MAXABS;
+  if (kind == "mean-scaler") return KLR_TR_MEAN;
+  die("invalid data transform");
+}
+
+static std::string slurp(const std::string& fn) {
+  std::ifstream jf(fn);
+  if (!jf) die("cannot open `%s'", fn.c_str());
+  std::stringstream buf; buf << jf.rdbuf();
+  return buf.str();
+}
+
+// ---- the ranks of a multi-GPU run -----------------------------------------------------------------------------
+// One page shared by the ranks (mapped before fork): rank 0 publishes the ncclUniqueId there, every rank reports a
+// failure there so that nobody waits for a rank that died before it joined the communicator.
+struct Boot {
+  std::atomic<int> id_ready;
+  std::atomic<int> failed;
+  char id[128];
+};
+struct Launch {
+  int ranks = 1;
+  std::string transport = "rccl";
+  std::vector<int> devices;
+  Boot* boot = nullptr;
+  void* shm = nullptr;
+  int64_t shm_bytes = 0;
+};
+
+// forks ranks 1 .. N-1 ... and rank 0: the caller stays the parent that only waits (it never touches HIP).  Returns in
+// the children (g_rank set); the parent exits here with the ranks' worst status.
+static void fork_ranks(Launch& L) {
+  L.boot = (Boot*)mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (L.boot == MAP_FAILED) die("mmap failed");
+  new (&L.boot->id_ready) std::atomic<int>(0);
+  new (&L.boot->failed) std::atomic<int>(0);
+  if (L.transport == "shm") {
+    L.shm_bytes = klr_shm_region_bytes(L.ranks);
+    L.shm = mmap(nullptr, (size_t)L.shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (L.shm == MAP_FAILED) die("mmap of the shared region (%lld bytes) failed", (long long)L.shm_bytes);
+    if (klr_shm_region_init(L.shm, L.shm_bytes, L.ranks) != KLR_OK) die("%s", klr_last_error(nullptr));
+  }
+  fflush(stdout); fflush(stderr);
+  std::vector<pid_t> pids;
+  for (int r = 0; r < L.ranks; r++) {
+    const pid_t pid = fork();
+    if (pid < 0) die("fork failed");
+    if (pid == 0) { g_rank = r; g_nranks = L.ranks; return; }
+    pids.push_back(pid);
+  }
+  int worst = 0;
+  size_t left = pids.size();
+  while (left > 0) {
+    int st = 0;
+    const pid_t p = wait(&st);
+    if (p < 0) break;
+    left--;
+    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    if (code != 0) {
+      if (worst == 0) worst = code;
+      L.boot->failed.store(1);                        // ranks still waiting for the id or at a shm barrier give up
+      if (L.shm) klr_shm_region_abort(L.shm);       // ... and so do ranks waiting at a barrier of the shared region
+    }
+  }
+  _exit(worst);
+}
+
+static void join_collectives(klr_ctx* ctx, const Launch& L) {
+  if (L.ranks <= 1) return;
+  if (L.transport == "shm") {
+    if (klr_ctx_init_shm(ctx, L.shm, L.shm_bytes, g_rank, L.ranks) != KLR_OK) { L.boot->failed.store(1); die("%s", klr_last_error(ctx)); }
+    return;
+  }
+  char id[128];
+  if (g_rank == 0) {
+    if (klr_rccl_unique_id(id) != KLR_OK) { L.boot->failed.store(1); die("%s", klr_last_error(nullptr)); }
+    memcpy(L.boot->id, id, 128);
+    L.boot->id_ready.store(1, std::memory_order_release);
+  } else {
+    for (long spins = 0; !L.boot->id_ready.load(std::memory_order_acquire); spins++) {
+      if (L.boot->failed.load()) die("another rank failed before the communicator was set up");
+      if (spins > 600000) die("timed out waiting for rank 0's ncclUniqueId");     // 10 minutes
+      usleep(1000);
+    }
+    memcpy(id, L.boot->id, 128);
+  }
+  if (klr_ctx_init_rccl(ctx, id, g_rank, L.ranks) != KLR_OK) { L.boot->failed.store(1); die("%s", klr_last_error(ctx)); }
+}
 
 int main(int argc, char** argv) {
-  std::string type = "kmerLr";
-  int device = 0;
   int ci = 1;
-  for (; ci < argc; ci++) {
-    std::string a = argv[ci];
-    if (a.rfind("--type=", 0) == 0) type = a.substr(7);
-    else if (a.rfind("--device=", 0) == 0) device = atoi(a.c_str() + 9);
-    else if (a == "-v") g_verbose = std::max(g_verbose, 1);
-    else if (a == "-vv") g_verbose = 2;
-    else if (a.rfind("--threads", 0) == 0) continue;                                     // accepted, unused
-    else if (a.rfind("--seed=", 0) == 0) g_seed = a.substr(7);
-    else break;
-  }
-  if (ci >= argc) {
-    printf("usage: kmerlr [--type=kmerLr|scoresLr] [-v] [--device=N] <learn|loss|predict> ...\n");
-    return 0;
+  Options go = parse(argc, argv, 1, GLOBAL_OPTS, true, &ci);
+  const std::string type = opt(go, "type", "kmerLr");
+  const int device = (int)opt_int(go, "device", "0");
+  g_seed = opt(go, "seed", "1");
+  if (opt_int(go, "threads", "1") < 1) die("invalid number of threads `%s'", opt(go, "threads", "1").c_str());
+  if (flag(go, "version")) { printf("%s\n", klr_version()); return 0; }
+  if (ci >= argc || flag(go, "help")) {
+    printf("usage: kmerlr [--type=kmerLr|scoresLr] [-v] [--seed=S] [--device=N] [--ranks=N [--transport=rccl|shm] [--devices=a,b,..]] <learn|loss|predict> ...\n");
+    return ci >= argc && !flag(go, "help") ? 1 : 0;
   }
   const std::string cmd = argv[ci];
-  Options o = parse(argc, argv, ci + 1);
   const bool scores = type == "scoresLr" || type == "scoreslr";
-  if (!scores && type != "kmerLr" && type != "kmerlr") die("invalid type `%s'", type.c_str());
+  if (!scores && type != "kmerLr" && type != "kmerlr") die("invalid classifier type");
+  const OptSpec* table = cmd == "learn" ? LEARN_OPTS : cmd == "loss" ? LOSS_OPTS : cmd == "predict" ? PREDICT_OPTS : nullptr;
+  if (!table) die("unknown command `%s' (this build provides learn, loss and predict)", cmd.c_str());
+  Options o = parse(argc, argv, ci + 1, table, false, nullptr);
+  for (const char** k = scores ? KMER_ONLY : SCORES_ONLY; *k; k++)
+    if (flag(o, *k)) die("unknown option `--%s' for --type=%s", *k, scores ? "scoresLr" : "kmerLr");
+  if (flag(o, "seed")) g_seed = opt(o, "seed", "1");
+
+  Launch L;
+  L.ranks = (int)opt_int(go, "ranks", "1");
+  L.transport = opt(go, "transport", "rccl");
+  if (L.ranks < 1 || L.ranks > 64) die("invalid --ranks");
+  if (L.transport != "rccl" && L.transport != "shm") die("invalid --transport `%s' (rccl or shm)", L.transport.c_str());
+  { std::stringstream ss(opt(go, "devices", "")); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) L.devices.push_back(atoi(t.c_str())); }
+  if (!L.devices.empty() && (int)L.devices.size() != L.ranks) die("--devices needs one device per rank");
+  if (L.ranks > 1 && cmd != "learn") die("--ranks applies to `learn'");
+  if (L.ranks > 1) fork_ranks(L);                       // returns in the ranks only; nothing has touched HIP so far
+  const int my_device = !L.devices.empty() ? L.devices[(size_t)g_rank] : (L.ranks > 1 && L.transport == "rccl") ? g_rank : device;
 
   klr_ctx* ctx = nullptr;
-  if (klr_ctx_create(device, &ctx) != KLR_OK) die("%s", klr_last_error(nullptr));
+  if (klr_ctx_create(my_device, &ctx) != KLR_OK) { if (L.boot) L.boot->failed.store(1); die("%s", klr_last_error(nullptr)); }
+  join_collectives(ctx, L);
   klr_backend be;
   if (klr_hip_backend(ctx, &be) != KLR_OK) die("%s", klr_last_error(ctx));
 
   if (cmd == "learn") {
     klr_config cfg;
     klr_config_default(&cfg);
-    cfg.lambda = strtod(opt(o, "lambda", "NaN").c_str(), nullptr);
+    cfg.lambda = opt_float(o, "lambda", "NaN");
     std::vector<int64_t> la;
-    { std::stringstream ss(opt(o, "lambda-auto", "0")); std::string t; while (std::getline(ss, t, ',')) la.push_back(atoll(t.c_str())); }
+    { std::stringstream ss(opt(o, "lambda-auto", "0")); std::string t;
+      while (std::getline(ss, t, ',')) { char* end = nullptr; la.push_back(strtoll(t.c_str(), &end, 10)); if (t.empty() || *end) die("option `--lambda-auto': invalid integer `%s'", t.c_str()); } }
+    if (la.empty()) die("option `--lambda-auto' is empty");
     std::sort(la.begin(), la.end());
     if (!std::isnan(cfg.lambda) && !(la.size() == 1 && la[0] == 0)) die("options --lambda and --lambda-auto are incompatible");
-    cfg.max_features = atoll(opt(o, "max-features", "0").c_str());
-    cfg.max_epochs = atoll(opt(o, "max-epochs", "0").c_str());
-    cfg.max_iterations = atoll(opt(o, "max-iterations", "0").c_str());
-    cfg.epsilon = strtod(opt(o, "epsilon", "0").c_str(), nullptr);
-    cfg.epsilon_lambda = strtod(opt(o, "epsilon-lambda", "0").c_str(), nullptr);
-    cfg.epsilon_loss = strtod(opt(o, "epsilon-loss", "1e-8").c_str(), nullptr);
+    cfg.max_features = opt_int(o, "max-features", "0");
+    cfg.max_epochs = opt_int(o, "max-epochs", "0");
+    cfg.max_iterations = opt_int(o, "max-iterations", "0");
+    const int64_t max_samples = opt_int(o, "max-samples", "0");
+    cfg.epsilon = opt_float(o, "epsilon", "0");
+    cfg.epsilon_lambda = opt_float(o, "epsilon-lambda", "0");
+    cfg.epsilon_loss = opt_float(o, "epsilon-loss", "1e-8");
     cfg.eval_loss = flag(o, "eval-loss") || cfg.epsilon_loss != 0.0;
     cfg.balance = flag(o, "balance");
     cfg.penalty_free = flag(o, "penalty-free");
     cfg.save_trace = flag(o, "save-trace");
     cfg.save_path = flag(o, "save-path");
-    cfg.verbose = g_verbose;
-    const int kfold = atoi(opt(o, "k-fold-cv", "1").c_str());
-    const long long seed = atoll(opt(o, "seed", g_seed.c_str()).c_str());
+    cfg.verbose = g_rank == 0 ? g_verbose : 0;
+    cfg.validation_size = opt_float(o, "validation-size", "0.0");
+    if (cfg.validation_size < 0.0 || cfg.validation_size > 1.0) die("invalid --validation-size");
+    cfg.data_transform = transform_kind(opt(o, "data-transform", ""));
+    // SAGA's knobs (step size, its thread pools): accepted like the reference's, without effect on the coordinate-descent solver
+    (void)opt_float(o, "scale-step-size", "1.0");
+    for (const char* k : {"threads-cv", "threads-saga", "threads-lr"}) (void)opt_int(o, k, "1");
+    if (flag(o, "adaptive-step-size") || flag(o, "scale-step-size")) say(1, "note: the step-size options belong to the reference's SAGA solver and have no effect here\n");
+    const int kfold = (int)opt_int(o, "k-fold-cv", "1");
+    const long long seed = atoll(g_seed.c_str());
     if (kfold < 1) die("invalid --k-fold-cv");
-    const int ensemble = atoi(opt(o, "ensemble-size", "1").c_str());
+    const int ensemble = (int)opt_int(o, "ensemble-size", "1");
     const std::string summary = opt(o, "ensemble-summary", "mean");
     if (ensemble < 1) die("invalid --ensemble-size");
-    if (summary != "mean" && summary != "product" && summary != "min" && summary != "max") die("invalid --ensemble-summary");
-    if (ensemble > 1 && kfold > 1) die("--ensemble-size together with --k-fold-cv is not part of this build");
+    if (summary != "mean" && summary != "product" && summary != "min" && summary != "max" && !summary.empty()) die("invalid --ensemble-summary");
+    const bool cv_path = kfold > 1 || cfg.validation_size > 0.0;
+    if (ensemble > 1 && cv_path) die("--ensemble-size together with --k-fold-cv / --validation-size is not part of this build");
     if (ensemble > 1 && !std::isnan(cfg.lambda)) die("--ensemble-size needs --lambda-auto in this build");
     cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;
-    cfg.copreselection = atoll(opt(o, "co-preselection", "0").c_str());
+    cfg.copreselection = opt_int(o, "co-preselection", "0");
     if (cfg.copreselection != 0 && !cfg.cooccurrence) die("--co-preselection needs --co-occurrence");
-    if (cfg.cooccurrence && cfg.copreselection > 0 && kfold > 1)
+    if (cfg.cooccurrence && cfg.copreselection > 0 && cv_path)
       die("--co-preselection together with --k-fold-cv is not part of this build (the pre-selection would have to run per fold)");
 
+    // positionals: <M> <N> | <MODEL.json>, FG, BG, BASENAME (kmerLr_learn.go:153-189; scoresLr: [MODEL.json] FG BG BASENAME)
     DataSet d;
     SeqSet sq;
-    std::string base;
+    std::string base, model_fn, fn_fg, fn_bg;
     KmerSpec ks;
     if (scores) {
-      if (o.pos.size() != 3) die("usage: kmerlr --type=scoresLr learn [options] FG.table BG.table BASENAME");
-      read_scores(o.pos[0], flag(o, "header"), 1, d);
-      read_scores(o.pos[1], flag(o, "header"), 0, d);
-      base = o.pos[2];
+      if (o.pos.size() != 3 && o.pos.size() != 4) die("usage: kmerlr --type=scoresLr learn [options] [MODEL.json] FG.table BG.table BASENAME");
+      const size_t k = o.pos.size() - 3;
+      if (k) model_fn = o.pos[0];
+      fn_fg = o.pos[k]; fn_bg = o.pos[k + 1]; base = o.pos[k + 2];
     } else {
-      if (o.pos.size() != 5) die("usage: kmerlr learn [options] M N FG.fa BG.fa BASENAME");
-      ks.M = atoi(o.pos[0].c_str()); ks.N = atoi(o.pos[1].c_str());
-      if (ks.M < 1 || ks.N < ks.M) die("invalid k-mer lengths");
-      ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
-      ks.reverse = flag(o, "reverse"); ks.complement = flag(o, "complement");
-      ks.alphabet = opt(o, "alphabet", "nucleotide");
-      parse_max_ambiguous(opt(o, "max-ambiguous", "-1"), ks.M, ks.N, ks.max_ambiguous);
-      kmer_prepare(ks, &d.names);
-      read_fasta(o.pos[2], 1, sq);
-      read_fasta(o.pos[3], 0, sq);
+      if (o.pos.size() != 4 && o.pos.size() != 5) die("usage: kmerlr learn [options] <<M> <N>|<MODEL.json>> FG.fa BG.fa BASENAME");
+      if (o.pos.size() == 5) {
+        char *e1 = nullptr, *e2 = nullptr;
+        ks.M = (int)strtol(o.pos[0].c_str(), &e1, 10); ks.N = (int)strtol(o.pos[1].c_str(), &e2, 10);
+        if (*e1 || *e2 || ks.M < 1 || ks.N < ks.M) die("invalid k-mer lengths");
+        fn_fg = o.pos[2]; fn_bg = o.pos[3]; base = o.pos[4];
+      } else { model_fn = o.pos[0]; fn_fg = o.pos[1]; fn_bg = o.pos[2]; base = o.pos[3]; }
+    }
+    // warm start (learn, kmerLr_learn.go:89-92; NewKmerLrEstimator :45-67): the model's counter / feature names and the
+    // coefficients of its first member; the k-mer set is NOT fixed and the transform is fitted anew on the data
+    std::vector<int64_t> warm_cols;
+    std::vector<double> warm_theta;
+    if (!model_fn.empty()) {
+      const std::string js = slurp(model_fn);
+      if (json_bool(js, "Cooccurrence", false, false)) die("warm start from a co-occurrence model is not part of this build");
+      const size_t dpos = js.find("\"Distributions\"");
+      if (dpos == std::string::npos) die("invalid config file");
+      warm_theta = json_numbers_after(js, "Parameters", js.find("vector:logistic regression", dpos), nullptr);
+      std::vector<double> index;
+      if (scores) index = json_numbers_after(js, "Index", 0, nullptr);
+      else kmer_spec_from_model(js, ks, index);                   // M, N, flags, alphabet, Binarize: the model's, not the command line's
+      if (warm_theta.size() != index.size() + 1) die("invalid config file");
+      std::vector<std::pair<int64_t, double>> ct;
+      for (size_t k = 0; k < index.size(); k++) ct.emplace_back((int64_t)index[k] + 1, warm_theta[k + 1]);
+      std::sort(ct.begin(), ct.end());
+      warm_cols.push_back(0);
+      const double t0 = warm_theta[0];
+      warm_theta.assign(1, t0);
+      for (auto& pr : ct) { if (pr.first == warm_cols.back()) die("invalid config file: a feature is listed twice"); warm_cols.push_back(pr.first); warm_theta.push_back(pr.second); }
+    }
+    if (!scores) {
+      if (model_fn.empty()) {
+        ks.revcomp = flag(o, "revcomp"); ks.binarize = flag(o, "binarize");
+        ks.reverse = flag(o, "reverse"); ks.complement = flag(o, "complement");
+        ks.alphabet = opt(o, "alphabet", "nucleotide");
+        parse_max_ambiguous(opt(o, "max-ambiguous", "-1"), ks.M, ks.N, ks.max_ambiguous);
+        kmer_prepare(ks, &d.names);
+      } else {
+        d.names.clear();
+        char buf[128];
+        for (int64_t c = 0; c < ks.m; c++) { klr_kmer_class_name(ks.kc, c, buf, sizeof(buf)); d.names.push_back(buf); }
+      }
+    }
+    // the rows: all fg samples, then all bg samples (compile_training_data :305-335); --max-samples keeps the first
+    // m1 / m2 of them; this rank reads its contiguous block of that order
+    int64_t nfg = scores ? count_scores_rows(fn_fg, flag(o, "header")) : count_fasta_records(fn_fg);
+    int64_t nbg = scores ? count_scores_rows(fn_bg, flag(o, "header")) : count_fasta_records(fn_bg);
+    reduce_samples(max_samples, &nfg, &nbg);
+    const int64_t n_all = nfg + nbg;
+    if (n_all == 0) die("Error: no training data given");
+    if (n_all < L.ranks) die("fewer samples (%lld) than ranks (%d)", (long long)n_all, L.ranks);
+    int64_t row0 = 0, row1 = n_all;
+    shard_rows(n_all, g_rank, g_nranks, &row0, &row1);
+    const int64_t f0 = std::min(row0, nfg), f1 = std::min(row1, nfg);            // fg records [f0, f1)
+    const int64_t b0 = std::max(row0, nfg) - nfg, b1 = std::max(row1, nfg) - nfg;  // bg records [b0, b1)
+    if (scores) {
+      read_scores(fn_fg, flag(o, "header"), 1, d, f0, f1);
+      read_scores(fn_bg, flag(o, "header"), 0, d, b0, b1);
+    } else {
+      read_fasta(fn_fg, 1, sq, f0, f1);
+      read_fasta(fn_bg, 0, sq, b0, b1);
       d.dim = ks.m + 1; d.labels = sq.labels;
-      base = o.pos[4];
     }
     const int64_t n = (int64_t)d.labels.size();
-    if (n == 0) die("Error: no training data given");
+    if (n != row1 - row0) die("internal error: read %lld rows for the block [%lld, %lld)", (long long)n, (long long)row0, (long long)row1);
+    std::vector<uint8_t> labels_all((size_t)n_all, 0);
+    for (int64_t i = 0; i < nfg; i++) labels_all[(size_t)i] = 1;
+    if (g_nranks > 1) say(1, "Rows [%lld, %lld) of %lld on rank 0; %d ranks over %s\n", (long long)row0, (long long)row1, (long long)n_all, g_nranks, L.transport.c_str());
+    for (int64_t c : warm_cols) if (c >= d.dim) die("invalid config file: feature %lld outside the data", (long long)(c - 1));
     klr_mat* mat = nullptr;
     if (scores) {
-      if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), 0, &mat) != KLR_OK)
+      if (klr_mat_from_csr(ctx, n, d.dim, d.rowptr.data(), d.col.data(), d.val.data(), d.labels.data(), n_all, &mat) != KLR_OK)
         die("%s", klr_last_error(ctx));
     } else {
-      mat = count_kmers(ctx, sq, ks);
+      mat = count_kmers(ctx, sq, ks, n_all);
     }
     // co-occurrence mode ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:98-117): optional
     // pre-selection with the transform fitted on the base data, then the pair matrix takes the place of the data
@@ -465,6 +762,7 @@ int main(int argc, char** argv) {
     std::vector<int64_t> base_cols;
     int64_t nb1 = 0;
     if (cfg.cooccurrence) {
+      if (!warm_cols.empty()) die("warm start together with --co-occurrence is not part of this build");
       std::vector<double> ps, po;
       if (cfg.copreselection > 0) fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), ps, po);
       base_cols.assign((size_t)d.dim, 0);
@@ -480,10 +778,10 @@ int main(int argc, char** argv) {
       d.dim = klr_coeff_dim(nb1 - 1);
     }
     // 0-based original features of expanded column j >= 1
-    auto pair_of = [&](int64_t j, int64_t* f1, int64_t* f2) {
+    auto pair_of = [&](int64_t j, int64_t* f1_, int64_t* f2_) {
       int64_t k1, k2;
       klr_coeff_sub2ind(nb1 - 1, j - 1, &k1, &k2);
-      *f1 = base_cols[(size_t)k1 + 1] - 1; *f2 = base_cols[(size_t)k2 + 1] - 1;
+      *f1_ = base_cols[(size_t)k1 + 1] - 1; *f2_ = base_cols[(size_t)k2 + 1] - 1;
     };
     auto save_model = [&](klr_estimator* e, int64_t i, const char* fn, const std::vector<const char*>& nm) {
       const char* tn = scores ? "scoresLr" : "kmerLr";
@@ -491,7 +789,7 @@ int main(int argc, char** argv) {
       int64_t c1 = 0; const int64_t* cc = nullptr;
       klr_estimator_classifier(e, i, &c1, &cc, nullptr, nullptr, nullptr, nullptr);
       std::vector<int64_t> pairs;
-      for (int64_t k = 1; k < c1; k++) { int64_t f1, f2; pair_of(cc[k], &f1, &f2); pairs.push_back(f1); pairs.push_back(f2); }
+      for (int64_t k = 1; k < c1; k++) { int64_t f1_, f2_; pair_of(cc[k], &f1_, &f2_); pairs.push_back(f1_); pairs.push_back(f2_); }
       if (pairs.empty()) pairs.push_back(0);
       return klr_estimator_save_model_pairs(e, i, fn, tn, nm.empty() ? nullptr : nm.data(), pairs.data());
     };
@@ -508,63 +806,86 @@ int main(int argc, char** argv) {
       kf.alphabet = ks.alphabet.c_str();
       klr_estimator_set_kmer_features(est, &kf);
     }
+    if (!warm_cols.empty() && klr_estimator_set_model(est, warm_cols.data(), warm_theta.data(), (int64_t)warm_cols.size()) != KLR_OK)
+      die("%s", klr_estimator_error(est));
     std::vector<const char*> names;
     for (auto& s : d.names) names.push_back(s.c_str());
-    if (kfold > 1) {
-      // learn_cv (kmerLr_learn.go:71-87): k folds, per-fold models, joined prediction / loss tables
-      if (!std::isnan(cfg.lambda)) die("--k-fold-cv needs --lambda-auto in this build");
+    const bool writer = g_rank == 0;                                   // one rank writes the result files
+    auto export_trace_path = [&](klr_estimator* e, const std::string& stem) {   // learn_parameters :45-55
+      if (!writer) return;
+      if (cfg.save_trace) {
+        const std::string fn = stem + ".trace";
+        say(1, "Exporting trace to `%s'... ", fn.c_str());
+        if (klr_estimator_save_trace(e, fn.c_str()) != KLR_OK) die("failed");
+        say(1, "done\n");
+      }
+      if (cfg.save_path) {
+        const std::string fn = stem + ".path";
+        say(1, "Exporting regularization path to `%s'... ", fn.c_str());
+        if (klr_estimator_save_path(e, fn.c_str()) != KLR_OK) die("failed");
+        say(1, "done\n");
+      }
+    };
+    if (cv_path) {
+      // learn_cv (kmerLr_learn.go:71-87): k folds (one pass without folds when only a validation set is split off),
+      // per-fold models, joined prediction / loss tables
       const int64_t nla = (int64_t)la.size();
-      std::vector<double> pred((size_t)(nla * n)), ltr((size_t)(nla * kfold)), lte((size_t)(nla * kfold));
-      std::vector<int32_t> groups((size_t)n);
-      if (klr_estimator_crossvalidate(est, mat, 0, n, kfold, seed, la.data(), nla, scale.empty() ? nullptr : scale.data(),
+      const int nfold = kfold > 1 ? kfold : 1;
+      const int64_t ncol = cfg.validation_size > 0.0 ? 1 : nla;          // classifiers kept per fold
+      std::vector<double> pred((size_t)(nla * std::max<int64_t>(n, 1))), ltr((size_t)(nla * nfold)), lte((size_t)(nla * nfold));
+      std::vector<int32_t> groups((size_t)std::max<int64_t>(n, 1));
+      if (klr_estimator_crossvalidate(est, mat, row0, n_all, kfold, seed, la.data(), nla, scale.empty() ? nullptr : scale.data(),
                                       offset.empty() ? nullptr : offset.data(), pred.data(), groups.data(), ltr.data(), lte.data()) != KLR_OK)
         die("%s", klr_estimator_error(est));
       char fn[4096];
-      for (int f = 0; f < kfold; f++) for (int64_t j = 0; j < nla; j++) {                  // learn_parameters :42-66
-        if (nla == 1) snprintf(fn, sizeof(fn), "%s_cv%d.json", base.c_str(), f + 1);
-        else snprintf(fn, sizeof(fn), "%s_cv%d_%lld.json", base.c_str(), f + 1, (long long)la[(size_t)j]);
-        say(1, "Exporting model to `%s'... ", fn);
-        if (save_model(est, f * nla + j, fn, names) != KLR_OK) die("failed");
-        say(1, "done\n");
+      for (int f = 0; f < nfold; f++) {                                                     // learn_parameters :42-66
+        const std::string stem = kfold > 1 ? base + "_cv" + std::to_string(f + 1) : base;
+        klr_estimator* fe = klr_estimator_fold(est, f);
+        if (fe) export_trace_path(fe, stem);
+        for (int64_t j = 0; j < ncol && writer; j++) {
+          const std::string mfn = ncol == 1 ? stem + ".json" : stem + "_" + std::to_string((long long)la[(size_t)j]) + ".json";
+          say(1, "Exporting model to `%s'... ", mfn.c_str());
+          if (save_model(est, f * ncol + j, mfn.c_str(), names) != KLR_OK) die("failed");
+          say(1, "done\n");
+        }
       }
-      for (int64_t j = 0; j < nla; j++) {                                                    // learn_cv :78-86
-        if (nla == 1) snprintf(fn, sizeof(fn), "%s.table", base.c_str()); else snprintf(fn, sizeof(fn), "%s_%lld.table", base.c_str(), (long long)la[(size_t)j]);
-        say(1, "Exporting cross-validation results to `%s'... ", fn);
-        if (klr_save_crossvalidation(fn, pred.data() + j * n, d.labels.data(), groups.data(), n, kfold) != KLR_OK) die("failed");
-        say(1, "done\n");
-        if (nla == 1) snprintf(fn, sizeof(fn), "%s_loss.table", base.c_str()); else snprintf(fn, sizeof(fn), "%s_%lld_loss.table", base.c_str(), (long long)la[(size_t)j]);
-        say(1, "Exporting cross-validation loss to `%s'... ", fn);
-        if (klr_save_crossvalidation_loss(fn, ltr.data() + j * kfold, lte.data() + j * kfold, kfold) != KLR_OK) die("failed");
-        say(1, "done\n");
+      if (kfold > 1) {
+        // every rank holds the predictions of its own rows: summed over the ranks into the whole table (zeros elsewhere)
+        std::vector<int32_t> groups_all((size_t)n_all);
+        klr_cv_groups_val(n_all, kfold, cfg.validation_size, seed, 0, n_all, groups_all.data(), nullptr);
+        for (int64_t j = 0; j < ncol; j++) {                                                  // learn_cv :78-86
+          std::vector<double> pa((size_t)n_all, 0.0);
+          for (int64_t i = 0; i < n; i++) pa[(size_t)(row0 + i)] = pred[(size_t)(j * n + i)];
+          if (klr_allreduce_host(ctx, pa.data(), n_all, KLR_F64) != KLR_OK) die("%s", klr_last_error(ctx));
+          if (!writer) continue;
+          if (ncol == 1) snprintf(fn, sizeof(fn), "%s.table", base.c_str()); else snprintf(fn, sizeof(fn), "%s_%lld.table", base.c_str(), (long long)la[(size_t)j]);
+          say(1, "Exporting cross-validation results to `%s'... ", fn);
+          if (klr_save_crossvalidation(fn, pa.data(), labels_all.data(), groups_all.data(), n_all, kfold) != KLR_OK) die("failed");
+          say(1, "done\n");
+          if (ncol == 1) snprintf(fn, sizeof(fn), "%s_loss.table", base.c_str()); else snprintf(fn, sizeof(fn), "%s_%lld_loss.table", base.c_str(), (long long)la[(size_t)j]);
+          say(1, "Exporting cross-validation loss to `%s'... ", fn);
+          if (klr_save_crossvalidation_loss(fn, ltr.data() + j * kfold, lte.data() + j * kfold, kfold) != KLR_OK) die("failed");
+          say(1, "done\n");
+        }
       }
       klr_estimator_destroy(est);
       klr_mat_destroy(mat);
       if (base_mat) klr_mat_destroy(base_mat);
       klr_ctx_destroy(ctx);
-      return 0;
+      fflush(stdout); fflush(stderr);
+      _exit(0);
     }
     if (ensemble > 1) {
       if (cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
-      if (klr_estimator_estimate_ensemble(est, mat, 0, n, ensemble, seed, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
+      if (klr_estimator_estimate_ensemble(est, mat, row0, n_all, ensemble, seed, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
                                           offset.empty() ? nullptr : offset.data()) != KLR_OK)
         die("%s", klr_estimator_error(est));
     } else if (klr_estimator_estimate(est, mat, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
                                       offset.empty() ? nullptr : offset.data()) != KLR_OK)
       die("%s", klr_estimator_error(est));
-    if (cfg.save_trace) {
-      const std::string fn = base + ".trace";
-      say(1, "Exporting trace to `%s'... ", fn.c_str());
-      if (klr_estimator_save_trace(est, fn.c_str()) != KLR_OK) die("failed");
-      say(1, "done\n");
-    }
-    if (cfg.save_path) {
-      const std::string fn = base + ".path";
-      say(1, "Exporting regularization path to `%s'... ", fn.c_str());
-      if (klr_estimator_save_path(est, fn.c_str()) != KLR_OK) die("failed");
-      say(1, "done\n");
-    }
+    export_trace_path(est, base);
     const int64_t nc = ensemble > 1 ? (int64_t)la.size() : klr_estimator_n_classifiers(est);
-    for (int64_t i = 0; i < nc; i++) {                                    // kmerLr_learn.go:60-66
+    for (int64_t i = 0; i < nc && writer; i++) {                          // kmerLr_learn.go:60-66
       char fn[4096];
       if (nc == 1) snprintf(fn, sizeof(fn), "%s.json", base.c_str());
       else snprintf(fn, sizeof(fn), "%s_%lld.json", base.c_str(), (long long)la[(size_t)i]);
@@ -579,11 +900,8 @@ int main(int argc, char** argv) {
     klr_mat_destroy(mat);
     if (base_mat) klr_mat_destroy(base_mat);
   } else if (cmd == "loss") {
-    if (o.pos.size() != 3) die("usage: kmerlr loss [--lambda=F] MODEL.json FG BG");
-    std::ifstream jf(o.pos[0]);
-    if (!jf) die("cannot open `%s'", o.pos[0].c_str());
-    std::stringstream buf; buf << jf.rdbuf();
-    const std::string js = buf.str();
+    if (o.pos.size() != 3 && o.pos.size() != 4) die("usage: kmerlr loss [--lambda=F] [--balance] MODEL.json FG BG [RESULT.table]");
+    const std::string js = slurp(o.pos[0]);
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
     std::vector<double> kindex;
@@ -600,22 +918,24 @@ int main(int argc, char** argv) {
     }
     std::vector<std::vector<double>> members; std::string summary;
     red = model_data(ctx, mat, js, members, summary, scores ? nullptr : &kindex);
-    const double cw[2] = {1.0, 1.0};
-    std::vector<double> lv;                                             // {Kmer,Scores}LrEnsemble.Loss: summary of the members' losses
+    double cw[2] = {1.0, 1.0};                                          // {Kmer,Scores}LrEnsemble.Loss :108-116
+    if (flag(o, "balance") && klr_class_weights(ctx, red, cw) != KLR_OK) die("%s", klr_last_error(ctx));
+    std::vector<double> lv;                                             // summary of the members' losses
+    const double lambda = opt_float(o, "lambda", "0.0");
     for (auto& th : members) {
       double out = 0.0;
-      if (klr_loss(ctx, red, th.data(), cw, strtod(opt(o, "lambda", "NaN").c_str(), nullptr), &out) != KLR_OK) die("%s", klr_last_error(ctx));
+      if (klr_loss(ctx, red, th.data(), cw, lambda, &out) != KLR_OK) die("%s", klr_last_error(ctx));
       lv.push_back(out);
     }
-    printf("%15e\n", summarize(summary, lv));                            // saveLoss, kmerLr_loss.go:48
+    FILE* f = o.pos.size() == 4 ? fopen(o.pos[3].c_str(), "w") : stdout;
+    if (!f) die("cannot write `%s'", o.pos[3].c_str());
+    fprintf(f, "%15e\n", summarize(summary, lv));                       // saveLoss, kmerLr_loss.go:48
+    if (f != stdout) fclose(f);
     klr_mat_destroy(red); klr_mat_destroy(mat);
   } else if (cmd == "predict") {
     // predict_ / predict_scores_ (kmerLr_predict.go:125-139, scoresLr_predict.go:28-37): log sigma(x . theta) per row
     if (o.pos.size() != 2 && o.pos.size() != 3) die("usage: kmerlr predict MODEL.json DATA [RESULT.table]");
-    std::ifstream jf(o.pos[0]);
-    if (!jf) die("cannot open `%s'", o.pos[0].c_str());
-    std::stringstream buf; buf << jf.rdbuf();
-    const std::string js = buf.str();
+    const std::string js = slurp(o.pos[0]);
     DataSet d;
     klr_mat *mat = nullptr, *red = nullptr;
     std::vector<double> kindex;
@@ -649,9 +969,9 @@ int main(int argc, char** argv) {
     for (int64_t i = 0; i < n; i++) fprintf(f, "%15e\n", out[(size_t)i]);
     if (f != stdout) fclose(f);
     klr_mat_destroy(red); klr_mat_destroy(mat);
-  } else {
-    die("unknown command `%s' (this build provides learn, loss and predict)", cmd.c_str());
   }
   klr_ctx_destroy(ctx);
+  fflush(stdout); fflush(stderr);
+  if (g_nranks > 1) _exit(0);
   return 0;
 }

@@ -21,7 +21,64 @@ int klr_fail(klr_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" const char* klr_version(void) { return "kmerlr-hip 0.1 (gfx950)"; }
+extern "C" const char* klr_version(void) { return "kmerlr-hip 0.3 (gfx950)"; }
+
+// ---- switches: read from the environment ONCE per context, changed through klr_ctx_set_option -------------------
+extern char** environ;
+
+const char* ctx_opt(const klr_ctx* ctx, const char* name) {
+  if (!ctx) return nullptr;
+  auto it = ctx->opts.find(name);
+  return it == ctx->opts.end() ? nullptr : it->second.c_str();
+}
+
+void ctx_parse_switches(klr_ctx* ctx) {
+  klr_ctx::Switches d;
+  auto geti = [&](const char* k, long long def) { const char* v = ctx_opt(ctx, k); return v ? atoll(v) : def; };
+  d.q64_lds_kib = (int)geti("KLR_Q64_LDS_KIB", d.q64_lds_kib);
+  d.q64_slds_a = (int)geti("KLR_Q64_SLDS_A", d.q64_slds_a);
+  d.stream_nt = (int)geti("KLR_STREAM_NT", d.stream_nt);
+  d.finish_iter = (int)geti("KLR_FINISH_ITER", 0);
+  d.finish_no_flat = ctx_opt(ctx, "KLR_FINISH_NO_FLAT") != nullptr;
+  d.rs_min_dim = geti("KLR_RS_MIN_DIM", d.rs_min_dim);
+  d.rs_force = ctx_opt(ctx, "KLR_RS_FORCE") != nullptr;
+  d.rs = (int)geti("KLR_RS", -1);
+  d.overlap = (int)geti("KLR_SWEEP_RANGES", -1);
+  ctx->sw = d;
+}
+
+static void ctx_load_env(klr_ctx* ctx) {
+  ctx->opts.clear();
+  for (char** e = environ; e && *e; e++) {
+    if (strncmp(*e, "KLR_", 4) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    if (!eq) continue;
+    ctx->opts[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+  }
+  ctx_parse_switches(ctx);
+}
+
+extern "C" int klr_ctx_set_option(klr_ctx* ctx, const char* name, const char* value) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, name != nullptr && strncmp(name, "KLR_", 4) == 0);
+  if (value) ctx->opts[name] = value; else ctx->opts.erase(name);
+  ctx_parse_switches(ctx);
+  return KLR_OK;
+}
+
+extern "C" int klr_ctx_reload_env(klr_ctx* ctx) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  ctx_load_env(ctx);
+  return KLR_OK;
+}
+
+int ctx_func_lds(klr_ctx* ctx, const void* fn, int bytes) {
+  if (ctx->lds_attr.count(fn)) return KLR_OK;
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  KLR_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  ctx->lds_attr.insert(fn);
+  return KLR_OK;
+}
 
 extern "C" const char* klr_last_error(const klr_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_klr_err.c_str();
@@ -54,6 +111,7 @@ extern "C" int klr_ctx_create(int device_id, klr_ctx** out) {
     return klr_fail(nullptr, KLR_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
   }
   ctx->own_stream = true;
+  ctx_load_env(ctx);
   ctx_register(ctx);
   *out = ctx;
   return KLR_OK;
@@ -164,7 +222,9 @@ extern "C" int klr_ctx_init_rccl(klr_ctx* ctx, const void* id128, int rank, int 
   if (st->ReduceScatter && st->AllGather) { ctx->rs_fn = rccl_reduce_scatter_hook; ctx->ag_fn = rccl_allgather_hook; ctx->coll_user = st; }
   ctx->rank = rank;
   ctx->nranks = nranks;
-  return KLR_OK;
+  // does the communicator really reduce over the ranks it claims?  [1, rank] as int64 must come back as [N, N(N-1)/2]
+  // (and the same for f64, reduce-scatter, all-gather); a failure here ends the run before any gradient is summed
+  return klr_ctx_comm_selfcheck(ctx);
 }
 
 extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* user, int rank, int nranks) {
@@ -175,6 +235,7 @@ extern "C" int klr_ctx_set_allreduce(klr_ctx* ctx, klr_allreduce_fn fn, void* us
   ctx->rank = rank;
   ctx->nranks = nranks;
   ctx->rs_fn = nullptr; ctx->ag_fn = nullptr; ctx->coll_user = nullptr;     // belong to the previous hook
+  ctx->comm_checked = false;
   return KLR_OK;
 }
 
@@ -219,10 +280,78 @@ extern "C" int klr_allreduce_time(klr_ctx* ctx, int64_t count, int dtype, int it
   return KLR_OK;
 }
 
+// Collective self-check: every installed hook is run once on small buffers whose sums every rank can predict --
+// all-reduce as int64 and f64, and (when installed) reduce-scatter and all-gather -- and the results are compared on
+// the host.  A communicator that does not really span `nranks` ranks, a hook that reduces the wrong element type or
+// scatters the wrong slice fails here, before any gradient goes through it.  Collective: every rank must call it.
+extern "C" int klr_ctx_comm_selfcheck(klr_ctx* ctx) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  ctx->comm_checked = false;
+  if (!ctx->ar_fn) { ctx->comm_checked = true; return KLR_OK; }
+  KLR_HIP(ctx, hipSetDevice(ctx->device));
+  const i64 R = ctx->nranks, me = ctx->rank;
+  const i64 tri = R * (R + 1) / 2;                      // sum of (rank + 1)
+  i64* buf;
+  const i64 C3 = 3;
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(64 + C3 * R + C3 + 16 * (R + 1)) * 8, (void**)&buf));
+  // int64 all-reduce
+  i64 hi[3] = {1, me, (me + 1) << 40};
+  KLR_TRY(h2d(ctx, buf, hi, sizeof(hi)));
+  KLR_TRY(klr_allreduce(ctx, buf, 3, KLR_I64));
+  KLR_TRY(d2h_sync(ctx, hi, buf, sizeof(hi)));
+  if (hi[0] != R || hi[1] != R * (R - 1) / 2 || hi[2] != (tri << 40))
+    return klr_fail(ctx, KLR_ECOMM, "collective self-check: int64 all-reduce over %lld ranks returned [%lld, %lld, %lld], expected [%lld, %lld, %lld]",
+                    (long long)R, (long long)hi[0], (long long)hi[1], (long long)hi[2], (long long)R, (long long)(R * (R - 1) / 2), (long long)(tri << 40));
+  // f64 all-reduce
+  double hd[2] = {0.5, (double)me};
+  KLR_TRY(h2d(ctx, buf, hd, sizeof(hd)));
+  KLR_TRY(klr_allreduce(ctx, buf, 2, KLR_F64));
+  KLR_TRY(d2h_sync(ctx, hd, buf, sizeof(hd)));
+  if (hd[0] != 0.5 * (double)R || hd[1] != (double)(R * (R - 1) / 2))
+    return klr_fail(ctx, KLR_ECOMM, "collective self-check: f64 all-reduce over %lld ranks returned [%g, %g]", (long long)R, hd[0], hd[1]);
+  if (ctx->rs_fn && ctx->ag_fn) {
+    // reduce-scatter: send[q * C3 + i] = (rank + 1) * (1000 q + i + 1)  ->  recv[i] = (1000 me + i + 1) * tri
+    std::vector<i64> send((size_t)(C3 * R));
+    for (i64 q = 0; q < R; q++) for (i64 i = 0; i < C3; i++) send[(size_t)(q * C3 + i)] = (me + 1) * (1000 * q + i + 1);
+    i64* dsend = buf + 64; i64* drecv = dsend + C3 * R;
+    KLR_TRY(h2d(ctx, dsend, send.data(), send.size() * 8));
+    if (ctx->rs_fn(ctx->coll_user, dsend, drecv, C3, KLR_I64, (void*)ctx->stream) != 0) return klr_fail(ctx, KLR_ECOMM, "collective self-check: reduce-scatter hook failed");
+    i64 got[3];
+    KLR_TRY(d2h_sync(ctx, got, drecv, sizeof(got)));
+    for (i64 i = 0; i < C3; i++)
+      if (got[i] != (1000 * me + i + 1) * tri)
+        return klr_fail(ctx, KLR_ECOMM, "collective self-check: reduce-scatter gave %lld at element %lld of rank %lld's slice, expected %lld",
+                        (long long)got[i], (long long)i, (long long)me, (long long)((1000 * me + i + 1) * tri));
+    // all-gather: 16 bytes per rank, byte b of rank r's block = (31 r + b) mod 251
+    unsigned char blk[16];
+    for (int b = 0; b < 16; b++) blk[b] = (unsigned char)((31 * me + b) % 251);
+    char* dblk = (char*)(drecv + C3); char* dall = dblk + 16;
+    KLR_TRY(h2d(ctx, dblk, blk, 16));
+    if (ctx->ag_fn(ctx->coll_user, dblk, dall, 16, (void*)ctx->stream) != 0) return klr_fail(ctx, KLR_ECOMM, "collective self-check: all-gather hook failed");
+    std::vector<unsigned char> all((size_t)(16 * R));
+    KLR_TRY(d2h_sync(ctx, all.data(), dall, all.size()));
+    for (i64 r = 0; r < R; r++) for (int b = 0; b < 16; b++)
+      if (all[(size_t)(r * 16 + b)] != (unsigned char)((31 * r + b) % 251))
+        return klr_fail(ctx, KLR_ECOMM, "collective self-check: all-gather returned a wrong block for rank %lld", (long long)r);
+  }
+  ctx->comm_checked = true;
+  return KLR_OK;
+}
+
+extern "C" int klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce, int64_t* sweeps_scatter, int64_t* scatter_fallbacks, int* checked) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  if (sweeps_allreduce) *sweeps_allreduce = ctx->n_ar_sweeps;
+  if (sweeps_scatter) *sweeps_scatter = ctx->n_rs_sweeps;
+  if (scatter_fallbacks) *scatter_fallbacks = ctx->n_rs_fallbacks;
+  if (checked) *checked = ctx->comm_checked ? 1 : 0;
+  return KLR_OK;
+}
+
 extern "C" int klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_allgather_fn ag, void* user) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, (rs == nullptr) == (ag == nullptr));
   ctx->rs_fn = rs; ctx->ag_fn = ag; ctx->coll_user = user;
+  ctx->comm_checked = false;
   return KLR_OK;
 }
 
@@ -303,6 +432,7 @@ extern "C" void klr_ctx_destroy(klr_ctx* ctx) {
   if (ctx->evict_buf) (void)hipFree(ctx->evict_buf);
   for (int i = 0; i < WS_COUNT; i++) if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  shm_release(ctx);
   if (ctx->rccl) {
     RcclState* st = (RcclState*)ctx->rccl;
     if (st->comm) st->CommDestroy(st->comm);
@@ -467,5 +597,6 @@ extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
   out->set_active_rows = klr_mat_set_active_rows;
   out->log_pdf = klr_log_pdf;
   out->expand_cooccurrence = klr_mat_expand_cooccurrence;
+  out->transform_fit = klr_transform_fit;
   return KLR_OK;
 }

@@ -71,6 +71,7 @@ struct klr_estimator {
   // k-mer counter of the data (klr_estimator_set_kmer_features): kmerLr models are written with the reference's
   // KmerLrFeatures parameters
   std::vector<klr_iter_rec> recs;     // scratch of solve_reduced
+  std::vector<klr_estimator*> folds;  // estimators of the last cross-validation / ensemble, one per fold (klr_estimator_fold)
   bool has_kmer = false;
   klr_kmer_features kf{};
   std::vector<int> kf_max_amb;
@@ -114,7 +115,31 @@ extern "C" int klr_estimator_create(const klr_backend* be, const klr_config* cfg
   return KLR_OK;
 }
 
-extern "C" void klr_estimator_destroy(klr_estimator* e) { delete e; }
+static void drop_folds(klr_estimator* e) {
+  for (klr_estimator* f : e->folds) klr_estimator_destroy(f);
+  e->folds.clear();
+}
+
+extern "C" void klr_estimator_destroy(klr_estimator* e) {
+  if (!e) return;
+  drop_folds(e);
+  delete e;
+}
+
+extern "C" klr_estimator* klr_estimator_fold(const klr_estimator* e, int fold) {
+  if (!e || fold < 0 || fold >= (int)e->folds.size()) return nullptr;
+  return e->folds[(size_t)fold];
+}
+
+// a fresh estimator for a fold or ensemble member: the configuration AND the starting model of `e`
+// (NewKmerLrEnsembleEstimator(config, classifier, icv), kmerLr_estimator_ensemble.go:35-41)
+static klr_estimator* fresh_like(klr_estimator* e) {
+  klr_estimator* fe = nullptr;
+  if (klr_estimator_create(&e->be, &e->cfg, &fe) != KLR_OK) return nullptr;
+  fe->cols = e->cols; fe->theta = e->theta;
+  fe->has_kmer = e->has_kmer; fe->kf = e->kf; fe->kf_max_amb = e->kf_max_amb; fe->kf_alphabet = e->kf_alphabet;
+  return fe;
+}
 
 extern "C" const char* klr_estimator_error(const klr_estimator* e) { return e ? e->err.c_str() : "estimator is NULL"; }
 
@@ -337,20 +362,33 @@ static inline uint64_t sm64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
-// getCvGroups (kmerLr_crossvalidation.go:56-94) without a validation set: groups = i mod fold, then the
-// shuffle of :42-52 (swap a random remaining element to the end) with Go's r.Intn(n) replaced by
-// splitmix64(seed * GOLD + draw) mod n.
-extern "C" void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t row0, int64_t n_local, int32_t* groups) {
+// getCvGroups (kmerLr_crossvalidation.go:56-94): groups = i mod fold (-1 without folds), validation flags per block of
+// `fold` rows, then the shuffle of :42-52 (swap a random remaining element to the end, both arrays alike) with Go's
+// r.Intn(n) replaced by splitmix64(seed * GOLD + draw) mod n.
+extern "C" void klr_cv_groups_val(int64_t n_all, int k_fold, double val_ratio, int64_t seed, int64_t row0, int64_t n_local,
+                                  int32_t* groups, uint8_t* validation) {
   std::vector<int32_t> g((size_t)std::max<int64_t>(n_all, 1));
-  for (int64_t i = 0; i < n_all; i++) g[(size_t)i] = k_fold <= 1 ? -1 : (int32_t)(i % k_fold);
-  if (seed != -1 && k_fold > 1) {
+  std::vector<uint8_t> v((size_t)std::max<int64_t>(n_all, 1), 0);
+  const int64_t fold = k_fold <= 1 ? 1 : k_fold;
+  for (int64_t i = 0; i < n_all; i += fold)
+    for (int64_t j = 0; j < fold && i + j < n_all; j++) {
+      g[(size_t)(i + j)] = k_fold <= 1 ? -1 : (int32_t)j;
+      v[(size_t)(i + j)] = ((double)i < val_ratio * (double)n_all && i + fold < n_all) ? 1 : 0;
+    }
+  if (seed != -1 && (k_fold > 1 || val_ratio > 0.0)) {
     uint64_t draw = 0;
     for (int64_t n = n_all; n > 0; n--) {
       const int64_t r = (int64_t)(sm64((uint64_t)seed * 0x9E3779B97F4A7C15ull + draw++) % (uint64_t)n);
       std::swap(g[(size_t)(n - 1)], g[(size_t)r]);
+      std::swap(v[(size_t)(n - 1)], v[(size_t)r]);
     }
   }
-  for (int64_t i = 0; i < n_local; i++) groups[i] = g[(size_t)(row0 + i)];
+  if (groups) for (int64_t i = 0; i < n_local; i++) groups[i] = g[(size_t)(row0 + i)];
+  if (validation) for (int64_t i = 0; i < n_local; i++) validation[i] = v[(size_t)(row0 + i)];
+}
+
+extern "C" void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t row0, int64_t n_local, int32_t* groups) {
+  klr_cv_groups_val(n_all, k_fold, 0.0, seed, row0, n_local, groups, nullptr);
 }
 
 extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int64_t row0, int64_t n_all, int k_fold,
@@ -358,58 +396,115 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
                                            const double* offset, double* predictions, int32_t* groups_out,
                                            double* loss_train, double* loss_test) {
   if (!e) return KLR_EINVAL;
-  if (!data || k_fold < 2 || !lambda_auto || nla < 1 || !predictions || !loss_train || !loss_test)
+  const double vr = e->cfg.validation_size;
+  const bool val = vr > 0.0;
+  if (!data || k_fold < 1 || (k_fold < 2 && !val) || !lambda_auto || nla < 1 || !loss_train || !loss_test || (k_fold > 1 && !predictions))
     return fail(e, KLR_EINVAL, "crossvalidate: invalid argument");
   if (!e->be.set_active_rows || !e->be.log_pdf) return fail(e, KLR_EINVAL, "backend lacks set_active_rows / log_pdf");
   int64_t n = 0, dim = 0;
   if (e->be.mat_shape(data, &n, &dim, nullptr, nullptr) != KLR_OK) return fail(e, KLR_EINVAL, "bad data matrix");
   if (n_all < k_fold) return fail(e, KLR_EINVAL, "not enough training samples (%lld) for %d-fold cross-validation", (long long)n_all, k_fold);
+  if (val && n_all < 2 * (int64_t)k_fold)
+    return fail(e, KLR_EINVAL, "not enough training samples for creating validation set with %d-fold cross-validation", k_fold);
   std::vector<int32_t> all((size_t)n_all);
-  klr_cv_groups(n_all, k_fold, seed, 0, n_all, all.data());
-  std::vector<int64_t> fold_size((size_t)k_fold, 0);
-  for (int32_t g : all) fold_size[(size_t)g]++;
+  std::vector<uint8_t> vall((size_t)n_all);
+  klr_cv_groups_val(n_all, k_fold, vr, seed, 0, n_all, all.data(), vall.data());
   const int32_t* grp = all.data() + row0;
+  const uint8_t* vfl = vall.data() + row0;
   if (groups_out) for (int64_t i = 0; i < n; i++) groups_out[i] = grp[i];
   std::vector<uint8_t> mask((size_t)std::max<int64_t>(n, 1));
   std::vector<double> lp((size_t)std::max<int64_t>(n, 1));
+  std::vector<double> fsc, fof;                       // per-fold transform (validation sets)
   int rc = KLR_OK;
   e->out.clear();
+  drop_folds(e);
   std::vector<Classifier> all_cls;
-  for (int f = 0; f < k_fold && rc == KLR_OK; f++) {
-    // training rows of fold f (filterCvGroup :96-120)
-    for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] != f;
-    if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_all - fold_size[(size_t)f]) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+  const int nfold = k_fold <= 1 ? 1 : k_fold;
+  // classifier.Loss on a row set ({Kmer,Scores}LrEnsemble.Loss, kmerLr_classifier_ensemble.go:108-123): Lambda = config.Lambda
+  // (NaN with --lambda-auto: no penalty term), class weights [1,1] unless --balance (then those of the row set itself)
+  auto set_loss = [&](klr_mat* red, const std::vector<uint8_t>& rows, int64_t n_rows, const std::vector<double>& theta, double* out) -> int {
+    if (e->be.set_active_rows(e->be.ctx, red, rows.data(), n_rows) != KLR_OK) return be_fail(e, KLR_EHIP, "set_active_rows");
+    double cwl[2] = {1.0, 1.0};
+    if (e->cfg.balance && e->be.class_weights(e->be.ctx, red, cwl) != KLR_OK) return be_fail(e, KLR_EHIP, "class_weights");
+    if (e->be.loss(e->be.ctx, red, theta.data(), cwl, e->cfg.lambda, out) != KLR_OK) return be_fail(e, KLR_EHIP, "loss");
+    return KLR_OK;
+  };
+  for (int f = 0; f < nfold && rc == KLR_OK; f++) {
+    const int32_t ff = f;             // without folds every group id is -1: no row is a test row (crossvalidation :183-186)
+    // the three row sets of fold f over the WHOLE data set (filterCvGroup :96-120): test, validation, training
+    int64_t n_test = 0, n_val = 0;
+    for (int64_t i = 0; i < n_all; i++) { if (all[(size_t)i] == ff) n_test++; else if (val && vall[(size_t)i]) n_val++; }
+    const int64_t n_train = n_all - n_test - n_val;
+    auto is_test = [&](int64_t i) { return grp[i] == ff; };
+    auto is_val = [&](int64_t i) { return !is_test(i) && val && vfl[i]; };
+    const double* sc = scale; const double* of = offset;
+    if (val && e->cfg.data_transform != 0 && e->be.transform_fit) {
+      // transform.Fit(append(data_train.Data, data_test.Data...)) (kmerLr_estimator_ensemble.go:116-117): every row but the validation set
+      for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_val(i);
+      if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_train + n_test) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+      fsc.assign((size_t)dim, 0.0); fof.assign((size_t)dim, 0.0);
+      int has_off = 0;
+      if (e->be.transform_fit(e->be.ctx, data, e->cfg.data_transform, fsc.data(), fof.data(), &has_off) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "transform_fit"); break; }
+      sc = fsc.data(); of = has_off ? fof.data() : nullptr;
+    }
+    for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i);
+    if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_train) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
     // a fresh estimator per fold (learn_parameters, kmerLr_learn.go:37-38)
-    klr_estimator* fe = nullptr;
-    if (klr_estimator_create(&e->be, &e->cfg, &fe) != KLR_OK) { rc = fail(e, KLR_EINVAL, "cannot create fold estimator"); break; }
-    if (e->cfg.verbose >= 1 && fe) fe->cfg.verbose = e->cfg.verbose;
-    rc = klr_estimator_estimate(fe, data, lambda_auto, nla, scale, offset);
-    if (rc != KLR_OK) { e->err = fe->err; klr_estimator_destroy(fe); break; }
+    klr_estimator* fe = fresh_like(e);
+    if (!fe) { rc = fail(e, KLR_EINVAL, "cannot create fold estimator"); break; }
+    e->folds.push_back(fe);
+    rc = klr_estimator_estimate(fe, data, lambda_auto, nla, sc, of);
+    if (rc != KLR_OK) { e->err = fe->err; break; }
     for (auto& r : fe->trace) e->trace.push_back(r);
-    for (int64_t j = 0; j < nla && rc == KLR_OK; j++) {
-      const Classifier& c = fe->out[(size_t)j];
-      klr_mat* red = nullptr;
+    // reduced data of every classifier (SelectData); created under the training mask, which they inherit
+    std::vector<klr_mat*> reds((size_t)fe->out.size(), nullptr);
+    for (size_t j = 0; j < fe->out.size() && rc == KLR_OK; j++) {
+      const Classifier& c = fe->out[j];
       if (e->be.select_columns(e->be.ctx, data, c.cols.data(), (int64_t)c.cols.size(), c.scale.empty() ? nullptr : c.scale.data(),
-                               c.offset.empty() ? nullptr : c.offset.data(), &red) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "select_columns"); break; }
-      const double cw1[2] = {1.0, 1.0};
-      // loss_train on the training rows (classifier.Loss, kmerLr_estimator_ensemble.go:143-145; ClassWeights [1,1])
-      if (e->be.loss(e->be.ctx, red, c.theta.data(), cw1, NAN, &loss_train[j * k_fold + f]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "loss");
-      // predictions of the test rows
-      if (rc == KLR_OK && e->be.log_pdf(e->be.ctx, red, c.theta.data(), lp.data()) != KLR_OK) rc = be_fail(e, KLR_EHIP, "log_pdf");
-      if (rc == KLR_OK) for (int64_t i = 0; i < n; i++) if (grp[i] == f) predictions[j * n + i] = lp[(size_t)i];
-      // loss_test on the test rows
-      if (rc == KLR_OK) {
-        for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] == f;
-        if (e->be.set_active_rows(e->be.ctx, red, mask.data(), fold_size[(size_t)f]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "set_active_rows");
-        else if (e->be.loss(e->be.ctx, red, c.theta.data(), cw1, NAN, &loss_test[j * k_fold + f]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "loss");
+                               c.offset.empty() ? nullptr : c.offset.data(), &reds[j]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "select_columns");
+    }
+    size_t j_first = 0, j_end = fe->out.size();
+    if (rc == KLR_OK && val) {
+      // "if validation data is available, select best classifier" (kmerLr_estimator_ensemble.go:119-135)
+      size_t best = 0; double vbest = INFINITY;
+      for (int64_t i = 0; i < n; i++) mask[(size_t)i] = is_val(i);
+      for (size_t j = 0; j < fe->out.size() && rc == KLR_OK; j++) {
+        double v = 0.0;
+        if (n_val > 0) rc = set_loss(reds[j], mask, n_val, fe->out[j].theta, &v);
+        if (rc != KLR_OK) break;
+        if (v < vbest) { vbest = v; best = j; }
+        say(e, 1, "> Classifier %zu has loss %g...\n", j, v);
       }
-      e->be.mat_destroy(red);
+      say(e, 1, "> Selecting classifier %zu\n", best);
+      j_first = best; j_end = best + 1;
+      if (rc == KLR_OK) { Classifier keep = fe->out[best]; fe->out.assign(1, keep); }
+    }
+    for (size_t j = j_first; j < j_end && rc == KLR_OK; j++) {
+      const size_t jo = val ? 0 : j;                                   // output row
+      const Classifier& c = fe->out[jo];
+      klr_mat* red = reds[j];
+      // loss_train on the training rows (classifier.Loss, kmerLr_estimator_ensemble.go:143-145)
+      for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i);
+      rc = set_loss(red, mask, n_train, c.theta, &loss_train[jo * nfold + f]);
+      // predictions of the test rows
+      if (rc == KLR_OK && n_test > 0) {
+        if (e->be.log_pdf(e->be.ctx, red, c.theta.data(), lp.data()) != KLR_OK) rc = be_fail(e, KLR_EHIP, "log_pdf");
+        if (rc == KLR_OK) for (int64_t i = 0; i < n; i++) if (is_test(i)) predictions[jo * n + i] = lp[(size_t)i];
+      }
+      // loss_test on the test rows (no rows: 0, kmerLr_logistic_regression.go:251-253)
+      if (rc == KLR_OK) {
+        loss_test[jo * nfold + f] = 0.0;
+        if (n_test > 0) {
+          for (int64_t i = 0; i < n; i++) mask[(size_t)i] = is_test(i);
+          rc = set_loss(red, mask, n_test, c.theta, &loss_test[jo * nfold + f]);
+        }
+      }
       all_cls.push_back(c);
     }
-    klr_estimator_destroy(fe);
+    for (klr_mat* r : reds) if (r) e->be.mat_destroy(r);
   }
   e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
-  if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j
+  if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j (f alone with a validation set)
   return rc;
 }
 
@@ -673,16 +768,17 @@ extern "C" int klr_estimator_estimate_ensemble(klr_estimator* e, klr_mat* data, 
   std::vector<Classifier> all_cls;
   int rc = KLR_OK;
   e->out.clear();
+  drop_folds(e);
   for (int k = 0; k < ensemble_size && rc == KLR_OK; k++) {
     for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] != k;                 // filterCvGroup(data_train, groups, nil, k) :84
     if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_all - size[(size_t)k]) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
-    klr_estimator* me = nullptr;
-    if (klr_estimator_create(&e->be, &e->cfg, &me) != KLR_OK) { rc = fail(e, KLR_EINVAL, "cannot create member estimator"); break; }
+    klr_estimator* me = fresh_like(e);
+    if (!me) { rc = fail(e, KLR_EINVAL, "cannot create member estimator"); break; }
+    e->folds.push_back(me);
     rc = klr_estimator_estimate(me, data, lambda_auto, nla, scale, offset);
-    if (rc != KLR_OK) { e->err = me->err; klr_estimator_destroy(me); break; }
+    if (rc != KLR_OK) { e->err = me->err; break; }
     for (auto& r : me->trace) e->trace.push_back(r);                               // GetTrace :56-62
     for (int64_t j = 0; j < nla; j++) all_cls.push_back(me->out[(size_t)j]);
-    klr_estimator_destroy(me);
   }
   e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
   if (rc == KLR_OK) e->out.swap(all_cls);

@@ -517,7 +517,7 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
   };
   const u64 total_blk = (u64)strip_unit[(size_t)nct] / 64;
   // one workgroup per CU (a piece vector written per (strip, workgroup): half as many as with two), KLR_Q64_WGS=2 for two
-  const int per_cu = getenv("KLR_Q64_WGS") ? std::max(1, std::min(2, atoi(getenv("KLR_Q64_WGS")))) : 1;
+  const int per_cu = ctx_opt(ctx, "KLR_Q64_WGS") ? std::max(1, std::min(2, atoi(ctx_opt(ctx, "KLR_Q64_WGS")))) : 1;
   const u32 nwg = (u32)std::max(2, per_cu * ctx->n_cu);
   std::vector<u64> sb((size_t)nct + 1);
   for (i64 t = 0; t <= nct; t++) sb[(size_t)t] = (u64)strip_unit[(size_t)t] / 64;
@@ -529,11 +529,11 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
   // KLR_Q64_CUT=snap leaves the crossing shares whole (A/B).
   std::vector<u64> cut((size_t)nwg + 1);
   {
-    const char* pc = getenv("KLR_Q64_PIECE_COST");
+    const char* pc = ctx_opt(ctx, "KLR_Q64_PIECE_COST");
     const u64 piece_cost = pc ? (u64)std::max(0, atoi(pc)) : 40;
-    const char* cs = getenv("KLR_Q64_CUT");
+    const char* cs = ctx_opt(ctx, "KLR_Q64_CUT");
     const bool plain = cs && !strcmp(cs, "snap");
-    const char* st = getenv("KLR_Q64_SNAP_TOL");
+    const char* st = ctx_opt(ctx, "KLR_Q64_SNAP_TOL");
     const double tolf = st ? atof(st) : 0.04;
     u32 crossings = 0;
     for (int pass = plain ? 1 : 0; pass < 2; pass++) {
@@ -578,7 +578,7 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     wgp[nwg] = (u32)(piece.size() / 4);
   }
   const u32 npiece = (u32)(piece.size() / 4);
-  if (getenv("KLR_Q64_DEBUG")) {
+  if (ctx_opt(ctx, "KLR_Q64_DEBUG")) {
     fprintf(stderr, "q64 cuts: %llu blocks, %lld strips, %u workgroups, %u pieces\n", (unsigned long long)total_blk, (long long)nct, nwg, npiece);
     for (u32 w = 0; w < std::min<u32>(nwg, 10u); w++) {
       fprintf(stderr, "  wg %u:", w);
@@ -609,7 +609,7 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     std::vector<u32> rec((size_t)nwg * 12, 0u);
     const int CBm = m->fmt == FMT_Q64C13 ? 13 : 12;
     const size_t lds_rows_cap = (((size_t)159 << 10) - 2 * ((size_t)8 << CBm)) / 8;
-    bool slds = per_cu == 1 && !(getenv("KLR_Q64_SLDS") && atoi(getenv("KLR_Q64_SLDS")) == 0);
+    bool slds = per_cu == 1 && !(ctx_opt(ctx, "KLR_Q64_SLDS") && atoi(ctx_opt(ctx, "KLR_Q64_SLDS")) == 0);
     u32 most_rows = 0;
     for (u32 w = 0; w < nwg; w++) {
       rec[(size_t)w * 12] = wgp[w]; rec[(size_t)w * 12 + 1] = wgp[w + 1];
@@ -648,7 +648,7 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
 // formats.  *built = false: the caller goes on with the tiled formats.
 static int build_q64(klr_ctx* ctx, klr_mat* m, TmpPool& tmp, bool* built) {
   *built = false;
-  const char* ef = getenv("KLR_ENTRY_FORMAT");
+  const char* ef = ctx_opt(ctx, "KLR_ENTRY_FORMAT");
   if (ef && (!strcmp(ef, "r64") || !strcmp(ef, "u24") || !strcmp(ef, "u32"))) return KLR_OK;
   hipStream_t st = ctx->stream;
   const i64 n = m->n, dim = m->dim, nnz = m->nnz;
@@ -700,7 +700,7 @@ static int build_q64(klr_ctx* ctx, klr_mat* m, TmpPool& tmp, bool* built) {
   hipLaunchKernelGGL(k_q64_fill, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, m->rowptr, m->col, val, n, CT, CB, rq_prefix, strip_unit,
                      (const u32*)blkrow, ent64, d_flag);
   {
-    const char* bo = getenv("KLR_Q64_BANK");             // rounds of the bank-aware column order, 0 = columns stay ascending
+    const char* bo = ctx_opt(ctx, "KLR_Q64_BANK");             // rounds of the bank-aware column order, 0 = columns stay ascending
     const int rounds = bo ? std::max(0, std::min(64, atoi(bo))) : 16;
     if (rounds > 0) hipLaunchKernelGGL(k_q64_bank_order, dim3((unsigned)(units / 64)), dim3(64), 0, st, (uint4*)ent64, CB, rounds);
   }
@@ -785,7 +785,7 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
   tile_geometry(n, dim, (u32)std::max(2, 2 * ctx->n_cu), &m->tile_r, &m->tile_c, &nrt, &nct);
   const i64 ntile = nrt * nct;
   if (ntile >= ((i64)1 << 31)) return KLR_OK;
-  const char* ord = getenv("KLR_TILE_ORDER");
+  const char* ord = ctx_opt(ctx, "KLR_TILE_ORDER");
   bool rt_major = (double)nnz / (double)ntile >= 32768.0 && ntile > 2 * (i64)ctx->n_cu;      // one tile per workgroup: column-tile major
   if (ord && ord[0] == 'r') rt_major = true;
   if (ord && ord[0] == 'c') rt_major = false;
@@ -798,10 +798,10 @@ static int finish_from_device_csr(klr_ctx* ctx, klr_mat* m, const u32* erow, Tmp
     unsigned long long h_tot[2];
     KLR_TRY(d2h_sync(ctx, h_tot, d_tot, 16));
     u24 = 3ull * h_tot[0] <= 4ull * h_tot[1];
-    if (const char* ef = getenv("KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
+    if (const char* ef = ctx_opt(ctx, "KLR_ENTRY_FORMAT")) { if (!strcmp(ef, "u24")) u24 = true; else if (!strcmp(ef, "u32")) u24 = false; }
     if (h_tot[0] >= (1ull << 31)) u24 = false;        // unit entries only while the stream stays below 6 GiB
     // r64 (8-byte quads row:12 | 4 x col:12, every (row, tile) run padded to 4 columns): needs no sort at all
-    const char* ef = getenv("KLR_ENTRY_FORMAT");
+    const char* ef = ctx_opt(ctx, "KLR_ENTRY_FORMAT");
     const bool forced_other = ef && (!strcmp(ef, "u24") || !strcmp(ef, "u32"));
     if (h_tot[0] < (1ull << 31) && !forced_other && (u64)ntile * m->tile_r < ((u64)1 << 31)) {
       const u32 RT = m->tile_r;

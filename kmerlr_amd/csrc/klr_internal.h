@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -56,6 +58,7 @@ struct klr_ctx {
   klr_allgather_fn      ag_fn = nullptr;
   void*        coll_user = nullptr;
   void*        rccl = nullptr;       // struct RcclState*
+  void*        shm = nullptr;        // struct ShmState* (klr_shm.hip)
   DevBuf       ws[WS_COUNT];
   // pinned host staging
   void*        pin = nullptr;
@@ -79,7 +82,35 @@ struct klr_ctx {
   void*        stage = nullptr;
   size_t       stage_cap = 0;
   hipEvent_t   stage_ev = nullptr;
+  // KLR_* switches: the process environment as it was at klr_ctx_create, changed afterwards only
+  // through klr_ctx_set_option -- nothing in the library reads the environment per call.  sw = parsed copies of the
+  // switches the full-width step looks at on every launch.
+  std::map<std::string, std::string> opts;
+  struct Switches {
+    int  q64_lds_kib = 96;       // KLR_Q64_LDS_KIB
+    int  q64_slds_a = 3;         // KLR_Q64_SLDS_A
+    int  stream_nt = 1;          // KLR_STREAM_NT
+    int  finish_iter = 0;        // KLR_FINISH_ITER (0: by width)
+    bool finish_no_flat = false; // KLR_FINISH_NO_FLAT
+    i64  rs_min_dim = 131072;    // KLR_RS_MIN_DIM
+    bool rs_force = false;       // KLR_RS_FORCE
+    int  rs = -1;                // KLR_RS: 1 reduce-scatter form on, 0 off, -1 default (on once the communicator passed its self-check)
+    int  overlap = -1;           // KLR_SWEEP_RANGES: strip ranges of the overlapped sweep (0/1: off; -1: default)
+  } sw;
+  // kernels whose dynamic-LDS limit was raised for THIS context's device (hipFuncSetAttribute is per device: a
+  // process-wide latch would leave a second GPU's kernels without it)
+  std::set<const void*> lds_attr;
+  // sweep collectives that fell back from the reduce-scatter form to the all-reduce (klr_ctx_comm_stats)
+  i64 n_rs_sweeps = 0, n_rs_fallbacks = 0, n_ar_sweeps = 0;
+  bool comm_checked = false;     // the installed collectives passed klr_ctx_comm_selfcheck
 };
+
+void shm_release(klr_ctx* ctx);                                  // klr_shm.hip
+// value of switch `name` ("KLR_...") on this context, nullptr when unset
+const char* ctx_opt(const klr_ctx* ctx, const char* name);
+void ctx_parse_switches(klr_ctx* ctx);
+// raise a kernel's dynamic shared memory limit once per context (device)
+int  ctx_func_lds(klr_ctx* ctx, const void* fn, int bytes);
 
 bool ctx_alive(const klr_ctx* ctx);                              // false once klr_ctx_destroy ran
 int  pool_get(klr_ctx* ctx, size_t bytes, void** p, size_t* cap);
@@ -128,6 +159,7 @@ struct klr_mat {
   i64  stored_entries = 0;       // entries before padding
   double col_abs_max = 0.0;      // max over non-bias columns of sum_i |x_ij| (local rows)
   double col_abs_max_global = -1.0;   // bound over all ranks (sweep_protocol)
+  int    rs_verified = 0;        // the reduce-scatter form of the sweep's collective was checked against the all-reduce form on this matrix
   int    sweep_int = -1;         // protocol of the full-width sweep agreed by all ranks: 1 integer stream + int64 all-reduce,
                                  // 0 plain CSC + f64 all-reduce, -1 not negotiated yet (sweep_protocol, klr_sweep.hip)
   u32* t_ent = nullptr;          // total4*4 packed entries

@@ -128,7 +128,7 @@ int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& to
   // boundary work in mid-stream; with tile_geometry's one-tile-per-workgroup grid every cut snaps)
   std::vector<u64> cut((size_t)nwg + 1);
   {
-    const char* sn = getenv("KLR_CUT_SNAP");
+    const char* sn = ctx_opt(ctx, "KLR_CUT_SNAP");
     const double tolf = sn ? atof(sn) : 0.08;
     i64 t = 0;
     cut[0] = 0;
@@ -257,7 +257,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   // per-tile writes and run column-tile major (measured: profiles/README.md).  With one tile per workgroup the
   // two orders do the same work; column-tile major measured 3-5 % faster (neighbouring workgroups then read
   // different s tiles instead of 17 of them the same one).  KLR_TILE_ORDER=rt|ct overrides.
-  const char* ord = getenv("KLR_TILE_ORDER");
+  const char* ord = ctx_opt(ctx, "KLR_TILE_ORDER");
   bool rt_major = (double)m->nnz / (double)ntile >= 32768.0 && ntile > 2 * (i64)ctx->n_cu;   // one tile per workgroup: column-tile major
   if (ord && ord[0] == 'r') rt_major = true;
   if (ord && ord[0] == 'c') rt_major = false;
@@ -316,7 +316,7 @@ static int build_tiled(klr_ctx* ctx, klr_mat* m, const i64* rowptr, const i64* c
   if (units1 < ((u64)1 << 31)) {                     // unit entries only while the stream stays small
     if (12 * tot1 <= best) { fmt = FMT_U24; best = 12 * tot1; }
     if (16 * totr <= best) { fmt = FMT_R64; best = 16 * totr; }
-    if (const char* ef = getenv("KLR_ENTRY_FORMAT")) {
+    if (const char* ef = ctx_opt(ctx, "KLR_ENTRY_FORMAT")) {
       if (!strcmp(ef, "u24")) fmt = FMT_U24; else if (!strcmp(ef, "u32")) fmt = FMT_U32; else if (!strcmp(ef, "r64")) fmt = FMT_R64;
     }
   }
@@ -423,7 +423,7 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
   std::vector<i64> n1(T, 0);
   // large inputs also get their narrow copy (u32 column, f32 value) in this pass: if they turn out to be count data,
   // the device builds CSC and tiles from it (KLR_HOST_INGEST=1 keeps everything on the host)
-  const bool maybe_device = n >= 2048 && nnz >= (1 << 20) && !getenv("KLR_HOST_INGEST");
+  const bool maybe_device = n >= 2048 && nnz >= (1 << 20) && !ctx_opt(ctx, "KLR_HOST_INGEST");
   std::vector<u32> n_col(maybe_device ? (size_t)nnz : 0);
   std::vector<float> n_val(maybe_device ? (size_t)nnz : 0);
   auto rows_of = [&](int t, i64& r0, i64& r1) { r0 = n * t / T; r1 = n * (t + 1) / T; };
@@ -1155,7 +1155,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
     } else {
       // row marks: bit masks (sorted rows for free) when they are small, else counters + cursor + in-row sort
       const int W = (int)ceil_div(c1, (i64)64);
-      const char* ss_env = getenv("KLR_SUBSELECT");         // bin | flat | sort (tests); default: the first that applies
+      const char* ss_env = ctx_opt(ctx, "KLR_SUBSELECT");         // bin | flat | sort (tests); default: the first that applies
       const bool use_bin = !any_zero && n > 0 && c1 <= RB_CMAX && n < ((i64)1 << 32) && (!ss_env || ss_env[0] == 'b');
       if (use_bin) {
         const i64 nblk = ceil_div(n, (i64)RB_ROWS);
@@ -1166,13 +1166,7 @@ int build_reduced(klr_ctx* ctx, const klr_mat* full, const i64* cols, i64 c1, co
         u32* blocktot = (u32*)(wsb + m_bytes);
         u32* seg = (u32*)(wsb + m_bytes + t_bytes);
         const size_t ldsb = (size_t)RB_ROWS * W * 8 + (size_t)RB_TCAP * 12 + (size_t)(RB_ROWS + 1) * 4;
-        static bool attr = false;
-        if (!attr) {
-          hipError_t ea = hipFuncSetAttribute((const void*)k_red_bin_b, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)((size_t)RB_ROWS * RB_WMAX * 8 + (size_t)RB_TCAP * 12 + (size_t)(RB_ROWS + 1) * 4));
-          if (ea != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "select_columns: %s", hipGetErrorString(ea)); break; }
-          attr = true;
-        }
+        if ((rc = ctx_func_lds(ctx, (const void*)k_red_bin_b, (int)((size_t)RB_ROWS * RB_WMAX * 8 + (size_t)RB_TCAP * 12 + (size_t)(RB_ROWS + 1) * 4)))) break;
         if (full->val_f64)
           hipLaunchKernelGGL(k_red_bin_a<double>, dim3((unsigned)nblk), dim3(1024), 0, st, full->colptr, full->crow, (const double*)full->cval,
                              d_sel, r->colptr, d_dstlen, (int)c1, scp, n, W, r->crow, (double*)r->cval, gmask, blocktot, seg);

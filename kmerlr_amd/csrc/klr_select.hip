@@ -585,16 +585,9 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
       const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
       hipLaunchKernelGGL(k_fast_keys_hist, dim3(grid), dim3(256), 0, st, g_dev, m, keys, hist);
     }
-    static bool attr = false;
-    if (!attr) {
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(2 * FAST_CAP * sizeof(Cand))));
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_direct, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(2 * FAST_CAP * sizeof(Cand))));
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_rank, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(FAST_CAP * sizeof(Cand))));
-      attr = true;
-    }
+    KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_finish, (int)(2 * FAST_CAP * sizeof(Cand))));
+    KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_direct, (int)(2 * FAST_CAP * sizeof(Cand))));
+    KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_rank, (int)(FAST_CAP * sizeof(Cand))));
     bool direct_ok = false;
     if (hint_tau != 0 && keys_hist_ready) {
       // the candidates are already in `cand` (SelHint): one sort kernel, no pass over the keys
@@ -730,11 +723,7 @@ static int sweep_select_scatter(klr_ctx* ctx, const klr_mat* full, double scale_
     FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
     hipLaunchKernelGGL(k_slice_keys, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 1024), 256))), dim3(256), 0, st, rbuf, lo, feat0,
                        m_s, 1.0 / scale_fx, keys, hist);
-    static bool attr = false;
-    if (!attr) {
-      KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_fast_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * FAST_CAP * sizeof(Cand))));
-      attr = true;
-    }
+    KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_finish, (int)(2 * FAST_CAP * sizeof(Cand))));
     const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 4096), 256));
     hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m_s, (u32)K_s, cand);
     hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), 2 * FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K_s, (u32)std::min<i64>(N, K_s),
@@ -861,10 +850,11 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     const bool tr = scale != nullptr || offset != nullptr;
     // reduce-scatter form of the collective: wide matrices on several ranks with both hooks installed, nothing that
     // needs the whole vector on every rank (g_out, a transform), a selection the one-workgroup sort can hold
-    static const i64 rs_min_dim = getenv("KLR_RS_MIN_DIM") ? atoll(getenv("KLR_RS_MIN_DIM")) : 131072;
-    static const bool rs_force = getenv("KLR_RS_FORCE") != nullptr;      // plumbing check: take the path with one rank too
+    const i64 rs_min_dim = ctx->sw.rs_min_dim;
+    const bool rs_force = ctx->sw.rs_force;                                // plumbing check: take the path with one rank too
+    // ... on a context whose hooks passed klr_ctx_comm_selfcheck (KLR_RS=0 keeps the all-reduce, KLR_RS=1 skips that test)
     const bool scatter = ctx->rs_fn && ctx->ag_fn && ctx->ar_fn && (ctx->nranks > 1 || rs_force) && !tr && !g_out && dim >= rs_min_dim &&
-                         2 * N <= FAST_CAP && N >= 1;
+                         2 * N <= FAST_CAP && N >= 1 && ctx->sw.rs != 0 && (ctx->comm_checked || ctx->sw.rs == 1);
     if (scatter) {
       const i64 slice = ceil_div(dim + IB_EXTRA, (i64)ctx->nranks);
       i64* ibuf = nullptr;
@@ -873,16 +863,39 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
       double loss_sum_s = NAN;
       restore_b(); restored = true;
       KLR_TRY(sweep_select_scatter(ctx, full, scale_fx, ibuf, slice, N, b, c_prev, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, &loss_sum_s, &done));
-      if (done) {
+      ctx->n_rs_sweeps++;
+      if (done && full->rs_verified) {
         if (loss_out) *loss_out = full->n_total ? loss_sum_s / (double)full->n_total : 0.0;
         return KLR_OK;
       }
+      if (!done) ctx->n_rs_fallbacks++;
       ctx->sel_hist_zeroed = nullptr;                                // the slice selection used the same buffers: start clean
       KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
       KLR_TRY(sweep_fix_tail(ctx, full, scale_fx, ibuf, gbuf, keys, hist, nullptr));
       hint_tau = 0;
-    } else
+      if (done) {
+        // the FIRST reduce-scatter sweep on a matrix is repeated as an all-reduce on the intact local sums: the two forms
+        // must give the same mask, count, lambda and loss bit for bit (the sums are integers), or the run ends here
+        std::vector<uint8_t> b2((size_t)dim, 0);
+        b2[0] = 1;
+        if (reduced) for (i64 p = 1; p < c_plus_1; p++) if (theta_red[p] != 0.0) b2[(size_t)red_cols[p]] = 1;
+        double lam2 = 0.0, loss2 = NAN; i64 c2 = 0; int ok2 = 0;
+        const u64 keep_hint = ctx->sel_hint; const i64 keep_K = ctx->sel_hint_K, keep_m = ctx->sel_hint_m;
+        KLR_TRY(select_from_device(ctx, gbuf, m, b2.data(), c_prev, N, lambda_prev, eps_lambda, &lam2, &c2, &ok2, nullptr, true, gbuf + dim, &loss2, 0));
+        ctx->sel_hint = keep_hint; ctx->sel_hint_K = keep_K; ctx->sel_hint_m = keep_m;
+        const bool same = lam2 == *lambda_out && c2 == *c_out && ok2 == *ok_out && memcmp(b2.data(), b, (size_t)dim) == 0 &&
+                          (loss2 == loss_sum_s || (loss2 != loss2 && loss_sum_s != loss_sum_s));
+        if (!same)
+          return klr_fail(ctx, KLR_ECOMM, "reduce-scatter and all-reduce forms of the sweep's collective disagree (lambda %.17g / %.17g, c %lld / %lld): "
+                          "the installed collectives do not sum the same data", *lambda_out, lam2, (long long)*c_out, (long long)c2);
+        const_cast<klr_mat*>(full)->rs_verified = 1;
+        if (loss_out) *loss_out = full->n_total ? loss_sum_s / (double)full->n_total : 0.0;
+        return KLR_OK;
+      }
+    } else {
+      if (ctx->ar_fn) ctx->n_ar_sweeps++;
       KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk, hint.tau ? &hint : nullptr));
+    }
     keys_ready = m > 0 && !tr;
   } else {
     // the row pass leaves the local loss partial in gbuf[dim]; [g | loss] in ONE f64 all-reduce

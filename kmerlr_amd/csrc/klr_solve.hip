@@ -1450,13 +1450,9 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const size_t lds_bytes = g_in_lds ? lds_big : lds_small;
   // wave variant: packed per-coordinate operands (4 per coordinate), theta (+ G) in LDS
   const size_t lds_wave = (size_t)5 * d * sizeof(double) + (g_in_lds ? (size_t)d * d * sizeof(double) : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_sweeps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_cd_lds2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr_set = true;
-  }
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_cd_sweeps, (int)LDS_MAX));
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_cd_lds2, (int)LDS_MAX));
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_gram_offdiag<true>, 128 * 1024));
 
   hipStream_t st = ctx->stream;
   double *w, *z, *G, *vec, *lossb;
@@ -1469,27 +1465,30 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // re-weighting at configs[2]) and plain global integer atomics are the cheaper build
   const double est_pairs = (double)n * std::max(0.0, red->avg_row - 1.0) * std::max(0.0, red->avg_row - 2.0) * 0.5 + (double)n;
   // KLR_GRAM_PATH=lds|global forces the privatised (LDS / tiled) or the global-atomics build (tests)
-  const char* gram_env = getenv("KLR_GRAM_PATH");
+  const char* gram_env = ctx_opt(ctx, "KLR_GRAM_PATH");
   const bool gram_many = gram_env ? (gram_env[0] == 'l') : est_pairs > 4e6;
   // one Gram row per workgroup once there are enough columns to fill the chip with workgroups (KLR_GRAM_ROWS_MIN)
-  const int gram_rows_min = getenv("KLR_GRAM_ROWS_MIN") ? atoi(getenv("KLR_GRAM_ROWS_MIN")) : 384;
+  const int gram_rows_min = ctx_opt(ctx, "KLR_GRAM_ROWS_MIN") ? atoi(ctx_opt(ctx, "KLR_GRAM_ROWS_MIN")) : 384;
   const bool gram_rows = d >= gram_rows_min && gram_many && (size_t)d * 8 <= 128 * 1024 && red->d_collen != nullptr;
   const bool gram_lds = !gram_rows && (size_t)d * d * 8 <= 128 * 1024 && gram_many;
   const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
   // 128 < d <= 1024 with many pairs: tile pairs privatised in LDS (k_gram_offdiag_tiled)
   const int gram_nt = (d + GT - 1) / GT, gram_npairs = gram_nt * (gram_nt + 1) / 2;
   // every row stores all d columns (dense score tables): the value array is the n x d panel -> Gram on the matrix cores
-  const bool gram_dense_ok = red->nnz == n * (i64)d && d >= 2 && d <= GD_MAXD && n >= 256 && !getenv("KLR_GRAM_NO_MFMA");
-  const bool gram_dense = gram_dense_ok && (!gram_env || gram_env[0] == 'm');
-  const unsigned gram_dense_blocks = gram_dense ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n, (i64)GD_ROWS))) : 0u;
+  const bool gram_dense_ok = red->nnz == n * (i64)d && d >= 2 && d <= GD_MAXD && n >= 256 && !ctx_opt(ctx, "KLR_GRAM_NO_MFMA");
+  // ... decided TOGETHER by all ranks (below, with the first re-linearisation's all-reduce): a shard that lacks one entry
+  // of a selected column, or has fewer than 256 rows, would post the int64 Gram all-reduce against its neighbours' f64 one
+  const bool gram_dense_local = gram_dense_ok && (!gram_env || gram_env[0] == 'm');
+  bool gram_dense = gram_dense_local;
+  const bool gram_dense_vote = ctx->ar_fn != nullptr && ctx->nranks > 1 && d <= GD_MAXD;   // every rank knows d: all vote or none
+  const unsigned gram_dense_blocks = gram_dense_local ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n, (i64)GD_ROWS))) : 0u;
   const bool gram_tiled = !gram_lds && !gram_rows && (size_t)d * d * 8 > 128 * 1024 && d <= 1024 && gram_many;
   const unsigned gram_groups = gram_tiled ? (unsigned)std::max<i64>(1, std::min<i64>(std::max(1, ctx->n_cu / gram_npairs), ceil_div(n, 2 * 1024))) : 0u;
   if (gram_tiled) {
-    static bool attr = false;
-    if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_offdiag_tiled, hipFuncAttributeMaxDynamicSharedMemorySize, GT * GT * 8)); attr = true; }
+    KLR_TRY(ctx_func_lds(ctx, (const void*)k_gram_offdiag_tiled, GT * GT * 8));
   }
   const int gd_T = (d + 15) / 16;
-  const size_t gram_dense_bytes = gram_dense ? (size_t)gram_dense_blocks * (gd_T * (gd_T + 1) / 2) * 256 * 8 : 0;
+  const size_t gram_dense_bytes = gram_dense_local ? (size_t)gram_dense_blocks * (gd_T * (gd_T + 1) / 2) * 256 * 8 : 0;
   const size_t gram_part_bytes = std::max(gram_dense_bytes, gram_tiled ? (size_t)gram_npairs * gram_groups * GT * GT * 8 : (size_t)gram_blocks * d * d * 8);
   const size_t gram_toff_bytes = gram_tiled ? (size_t)n * (gram_nt + 1) * sizeof(unsigned short) : 0;
   KLR_TRY(ws_get(ctx, WS_CD_G, (size_t)2 * d * d * 8 + gram_part_bytes + gram_toff_bytes, (void**)&G));
@@ -1500,10 +1499,11 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   Gi = (i64*)(G + (size_t)d * d);
   // vec: a0[d] nm[d] xy[d] theta[d] | hist[K*d] delta[K] losses[K] gsc[2] | ints: stopf[K] ndone
   // everything a batch of sweeps reports (hist .. ndone) is contiguous: ONE device-to-host copy per batch
-  const size_t vec_bytes = ((size_t)4 * d + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16 + (size_t)d * 8
+  const size_t vec_bytes = ((size_t)4 * d + 2 + (size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 8) * sizeof(int) + 16 + (size_t)d * 8
                            + (size_t)d * 8 + SBW * 64 * 8 + 8;
   KLR_TRY(ws_get(ctx, WS_CD_VEC, vec_bytes, (void**)&vec));
-  double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d; double* hist = thd + d;
+  // xy[d]: this rank's vote on the dense-panel Gram (1 = not dense here), summed with [a0 | nm | xy]
+  double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d + 2; double* hist = thd + d;
   double* delta = hist + (size_t)KSPEC * d; double* losses = delta + KSPEC; double* gsc = losses + KSPEC;
   int* stopf = (int*)(gsc + 2); int* ndone = stopf + KSPEC;
   unsigned long long* fin_ctl = (unsigned long long*)(stopf + KSPEC + 8);     // {ticket, max bits} of k_irls_finish
@@ -1539,12 +1539,12 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   };
 
   int relin = 0;                   // re-linearisations so far
-  const int first_k = getenv("KLR_CD_FIRST_BATCH") ? std::max(1, std::min(KSPEC, atoi(getenv("KLR_CD_FIRST_BATCH")))) : 1;
+  const int first_k = ctx_opt(ctx, "KLR_CD_FIRST_BATCH") ? std::max(1, std::min(KSPEC, atoi(ctx_opt(ctx, "KLR_CD_FIRST_BATCH")))) : 1;
   // sweeps per speculative batch: a batch costs ~45 us beside its sweeps (launches, loss pass, report, host turn) and
   // wastes (K-1)/2 sweeps on average when the loss rule stops it; a sweep is ~8 us at d = 101 and ~67 us at d = 501:
   // small problems want full batches, large ones shorter ones (measured at d = 501: 8 -> 190 ms, 4 -> 180, 2 -> 187)
-  const int batch_k = getenv("KLR_CD_BATCH") ? std::max(1, std::min(KSPEC, atoi(getenv("KLR_CD_BATCH")))) : (d <= 128 ? KSPEC : KSPEC / 2);
-  const bool dbg_sync = getenv("KLR_CD_DEBUG") && atoi(getenv("KLR_CD_DEBUG")) >= 2;
+  const int batch_k = ctx_opt(ctx, "KLR_CD_BATCH") ? std::max(1, std::min(KSPEC, atoi(ctx_opt(ctx, "KLR_CD_BATCH")))) : (d <= 128 ? KSPEC : KSPEC / 2);
+  const bool dbg_sync = ctx_opt(ctx, "KLR_CD_DEBUG") && atoi(ctx_opt(ctx, "KLR_CD_DEBUG")) >= 2;
 #define DBG_STEP(name) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[cd] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
   for (i64 iter = 0; iter < max_iter; iter++, relin++) {
     // ---- IRLS linearisation + Gram --------------------------------------------------------------
@@ -1558,6 +1558,14 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     if (single) hipLaunchKernelGGL(k_irls_finish<true>, dim3(fin_blocks), dim3(256), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc, fin_ctl);
     else {
       hipLaunchKernelGGL(k_irls_finish<false>, dim3(fin_blocks), dim3(256), 0, st, red->colchunk, d, red->nchunks, part3, a0, gsc, fin_ctl);
+      if (gram_dense_vote && relin == 0) {
+        const double vote = gram_dense_local ? 0.0 : 1.0;
+        KLR_TRY(h2d(ctx, xy + d, &vote, sizeof(double)));
+        KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d + 1, KLR_F64));              // [a0 | nm | xy | vote] contiguous
+        double votes = 1.0;
+        KLR_TRY(d2h_sync(ctx, &votes, xy + d, sizeof(double)));
+        gram_dense = votes == 0.0;                                             // the matrix cores only if EVERY shard is a dense panel
+      } else
       KLR_TRY(klr_allreduce(ctx, a0, 3 * (i64)d, KLR_F64));                    // [a0 | nm | xy] contiguous
       hipLaunchKernelGGL(k_gram_scale, dim3(1), dim3(256), 0, st, nm, d, gsc);
     }
@@ -1566,8 +1574,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
     if ((!gram_lds && !gram_tiled && !gram_rows && !gram_dense) || !n) KLR_HIP(ctx, hipMemsetAsync(Gi, 0, (size_t)d * d * 8, st));
     bool assembled = false;
     if (n && gram_dense) {
-      static bool attr = false;
-      if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_dense_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; }
+      KLR_TRY(ctx_func_lds(ctx, (const void*)k_gram_dense_mfma, 96 * 1024));
       double* gpart = (double*)(Gi + (size_t)d * d);
       const size_t lds = ((size_t)GD_ROWS * (gd_T * 16 + 2) + GD_ROWS) * 8;
       hipLaunchKernelGGL(k_gram_dense_mfma, dim3(gram_dense_blocks), dim3(1024), lds, st, (const double*)red->val, w, n, d, gpart);
@@ -1594,8 +1601,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
           hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ceil_div((i64)d * d, 64)), dim3(256), 0, st, (unsigned long long*)Gi,
                              d, (int)gram_blocks);
       } else if (gram_rows) {
-        static bool attr = false;
-        if (!attr) { KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr = true; }
+        KLR_TRY(ctx_func_lds(ctx, (const void*)k_gram_rows, 128 * 1024));
         hipLaunchKernelGGL(k_gram_rows, dim3((unsigned)d), dim3(1024), (size_t)d * 8, st, red->rowptr, red->col, (const double*)red->val,
                            red->colptr, red->d_collen, red->crow, (const double*)red->cval, w, d, gsc, Gi);
       } else if (gram_tiled) {
@@ -1653,9 +1659,9 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       }
       else if (d <= 256) hipLaunchKernelGGL((k_cd_wave<4, false, true>), dim3(1), dim3(256), lds_wave, st, a);
       else if (d <= 512) hipLaunchKernelGGL((k_cd_wave<8, false, true>), dim3(1), dim3(256), lds_wave, st, a);
-      else if (d <= 1024 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<1>, dim3(1), dim3(1024), 0, st, a);
-      else if (d <= 2048 && !getenv("KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<2>, dim3(1), dim3(1024), 0, st, a);
-      else if (!getenv("KLR_CD_SWEEPS") || lds_small > LDS_MAX) {
+      else if (d <= 1024 && !ctx_opt(ctx, "KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<1>, dim3(1), dim3(1024), 0, st, a);
+      else if (d <= 2048 && !ctx_opt(ctx, "KLR_CD_SWEEPS")) hipLaunchKernelGGL(k_cd_blocked<2>, dim3(1), dim3(1024), 0, st, a);
+      else if (!ctx_opt(ctx, "KLR_CD_SWEEPS") || lds_small > LDS_MAX) {
         // super-blocks: two launches per 512 coordinates, one per sweep for the stop rule; a halted batch's later
         // launches return at once
         const int S = (d + 63) / 64, NSB = (S + SBW - 1) / SBW;
@@ -1724,7 +1730,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (cut) { thd_stale = true; q_stale = true; if (!inline_theta) KLR_TRY(sync_thd()); }
       if (nd == 0) inner_done = true;
     }
-    if (getenv("KLR_CD_DEBUG")) fprintf(stderr, "[cd] d=%d inner sweeps=%lld stopf=%d\n", d, (long long)(iter - dbg_iter0), dbg_stopk);
+    if (ctx_opt(ctx, "KLR_CD_DEBUG")) fprintf(stderr, "[cd] d=%d inner sweeps=%lld stopf=%d\n", d, (long long)(iter - dbg_iter0), dbg_stopk);
     // ---- outer checks -----------------------------------------------------------------------------
     double dl;
     if (host_eval_stopping(tp.data(), th.data(), d, eps, &dl)) break;                   // coordinate.go:119-120

@@ -836,15 +836,8 @@ static int launch_sweep_q64(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
   // workgroups on one CU while another CU stays empty (it does: with 256 workgroups of 32 - 64 KiB on 256 CUs part of
   // them ran in pairs and finished 15 % later than the rest, tools/q64_phases.py)
   size_t lds_bytes = (size_t)R * ((size_t)8 << CB) + (SLDS ? (size_t)mat->q64_slds_rows * 8 : 0);
-  if ((int)mat->nwg <= ctx->n_cu) {
-    const char* e = getenv("KLR_Q64_LDS_KIB");
-    lds_bytes = std::max(lds_bytes, (size_t)(e ? atoi(e) : 96) << 10);
-  }
-  static bool attr_done = false;
-  if (!attr_done) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-    attr_done = true;
-  }
+  if ((int)mat->nwg <= ctx->n_cu) lds_bytes = std::max(lds_bytes, (size_t)ctx->sw.q64_lds_kib << 10);
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>, 160 << 10));
   hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
                         (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)mat->t_piece,
                         (const uint4*)mat->t_wgpiece, S, part);
@@ -856,7 +849,7 @@ template <int CB, bool NT, int ABL = 0>
 static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
 #ifdef KLR_ABLATIONS
   if (ABL == 0) {
-    const char* e = getenv("KLR_Q64_DEPTH");                // A/B: pipeline depths
+    const char* e = ctx_opt(ctx, "KLR_Q64_DEPTH");                // A/B: pipeline depths
     const int dsel = e ? atoi(e) : 0;
     if (dsel == 10) return launch_sweep_q64<CB, NT, 1, 0, 2, 0>(ctx, mat, S, part, e0, e1);
     if (dsel == 20) return launch_sweep_q64<CB, NT, 2, 0, 2, 0>(ctx, mat, S, part, e0, e1);
@@ -874,10 +867,10 @@ static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64*
 #endif
   if ((int)mat->nwg <= ctx->n_cu) {
 #ifdef KLR_ABLATIONS
-    if (getenv("KLR_Q64_REGIONS") && atoi(getenv("KLR_Q64_REGIONS")) == 1) return launch_sweep_q64<CB, NT, 2, 1, 1, ABL>(ctx, mat, S, part, e0, e1);
+    if (ctx_opt(ctx, "KLR_Q64_REGIONS") && atoi(ctx_opt(ctx, "KLR_Q64_REGIONS")) == 1) return launch_sweep_q64<CB, NT, 2, 1, 1, ABL>(ctx, mat, S, part, e0, e1);
 #endif
     if (mat->q64_slds_rows && ABL == 0) {                    // dense strips: the workgroup's S values in LDS
-      if (getenv("KLR_Q64_SLDS_A") && atoi(getenv("KLR_Q64_SLDS_A")) == 2) return launch_sweep_q64<CB, NT, 2, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
+      if (ctx->sw.q64_slds_a == 2) return launch_sweep_q64<CB, NT, 2, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
       return launch_sweep_q64<CB, NT, 3, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
     }
     return launch_sweep_q64<CB, NT, 2, 1, 2, ABL>(ctx, mat, S, part, e0, e1);   // one workgroup per CU: two accumulator regions
@@ -888,11 +881,7 @@ static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64*
 template <int THREADS, int UNROLL, bool NT, int ABL = 0, int FMT = FMT_U32>
 static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds_bytes = (size_t)TILE_DIM * 16;
-  static bool attr_done = false;
-  if (!attr_done) {
-    KLR_HIP(ctx, hipFuncSetAttribute((const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL, FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done = true;
-  }
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_sweep_coo<THREADS, UNROLL, NT, ABL, FMT>, (int)lds_bytes));
   // start / stop events ride on the dispatch packet itself (hipExtLaunchKernelGGL): recording them with
   // hipEventRecord puts two barrier packets around the kernel and costs ~15 us per step
   hipExtLaunchKernelGGL((k_sweep_coo<THREADS, UNROLL, NT, ABL, FMT>), dim3(mat->nwg), dim3(THREADS), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
@@ -907,10 +896,10 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
 static int g_coo_variant = -1;
 extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
 static int dispatch_ablation(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1, bool* done) {
-  if (g_coo_variant < 0) { const char* e = getenv("KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
+  if (g_coo_variant < 0) { const char* e = ctx_opt(ctx, "KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
   *done = true;
   if (mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13) {
-    const char* e = getenv("KLR_Q64_ABL");
+    const char* e = ctx_opt(ctx, "KLR_Q64_ABL");
     const int abl = e ? atoi(e) : 0;
     const bool c13 = mat->fmt == FMT_Q64C13;
     switch (abl) {
@@ -973,7 +962,7 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
   // averaged 48.9 us: no better than non-temporal, with a 35 % cliff behind it (profiles/README.md, round 2).
   // KLR_STREAM_NT=0 reads it with plain loads (A/B tooling).
   bool fits_mall = false;
-  if (const char* e = getenv("KLR_STREAM_NT")) fits_mall = atoi(e) == 0 && (size_t)mat->total4 * 16 <= ((size_t)220 << 20);
+  if (ctx->sw.stream_nt == 0) fits_mall = (size_t)mat->total4 * 16 <= ((size_t)220 << 20);
   switch (mat->fmt) {
     case FMT_Q64C12: return fits_mall ? launch_sweep_q64_by_grid<12, false>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true>(ctx, mat, S, part, e0, e1);
     case FMT_Q64C13: return fits_mall ? launch_sweep_q64_by_grid<13, false>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<13, true>(ctx, mat, S, part, e0, e1);
@@ -1287,9 +1276,9 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
   // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
   u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
-  if (const char* e = getenv("KLR_FINISH_ITER")) fiter = (u32)std::max(1, std::min(8, atoi(e)));          // A/B tooling
+  if (ctx->sw.finish_iter > 0) fiter = (u32)std::max(1, std::min(8, ctx->sw.finish_iter));          // A/B tooling
   // (one pass of 1024 columns per workgroup, 8x the workgroups, measured 3x slower on the 1M-column step: keep ITER)
-  const bool flat = mat->max_ct_pieces >= 1 && mat->max_ct_pieces <= 8 && fiter % 4 == 0 && !getenv("KLR_FINISH_NO_FLAT");
+  const bool flat = mat->max_ct_pieces >= 1 && mat->max_ct_pieces <= 8 && fiter % 4 == 0 && !ctx->sw.finish_no_flat;
   const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
   if (!ctx->ar_fn) {
     // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel

@@ -180,6 +180,7 @@ void klo_backend_table(klr_backend* out) {
   out->set_active_rows = ob_set_active_rows;
   out->log_pdf = ob_log_pdf;
   out->expand_cooccurrence = ob_expand_cooccurrence;
+  out->transform_fit = 0;                                /* the driver then keeps the caller's transform for every fold */
 }
 
 void klo_backend_mat_destroy(klr_mat* m) { ob_mat_destroy(m); }

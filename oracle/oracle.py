@@ -15,12 +15,16 @@ _lib = None
 
 
 def build(force=False):
-    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("klr_oracle.c", "klr_synth.c", "klr_oracle.h", "Makefile")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
-        return _LIB_PATH
-    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    """Compile the oracle with gcc (recipe: oracle/Makefile; make decides what is stale -- the driver library also
+    depends on the product's klr_driver.cpp and headers).  Serialised by a file lock: several test ranks may start at once."""
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []) + ["all"])
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return _LIB_PATH
 
 

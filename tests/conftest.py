@@ -30,3 +30,25 @@ def scores_data():
     x = np.concatenate([fg, bg], axis=0)
     labels = np.array([1] * len(fg) + [0] * len(bg), dtype=np.uint8)
     return O.Csr.from_dense(x), labels, x
+
+
+@pytest.fixture()
+def setopt(monkeypatch):
+    """setopt("KLR_X", value | None): a KLR_* switch for the rest of this test.  Contexts read the environment only when
+    they are created (klr_ctx_create), so the switch is put into the environment (for contexts and processes created
+    later) AND set on every live Context (klr_ctx_set_option); both are undone when the test ends."""
+    import kmerlr_amd as K
+    touched = []
+
+    def _set(name, value):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(value))
+        touched.append(name)
+        for c in K.Context.live():
+            c.set_option(name, value)
+    yield _set
+    monkeypatch.undo()
+    for c in K.Context.live():
+        c.reload_env()

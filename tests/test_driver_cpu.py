@@ -149,8 +149,10 @@ def test_crossvalidation_matches_explicit_subsets(tmp_path):
             theta_full = np.zeros(x.dim); theta_full[c["cols"]] = c["theta"]
             pred = np.array([O.class_log_pdf(x, i, theta_full, 1) for i in te])
             np.testing.assert_allclose(r["predictions"][j, te], pred, rtol=1e-12)
-            lt = -np.mean([O.class_log_pdf(x, i, theta_full, labels[i]) for i in tr])
-            ls = -np.mean([O.class_log_pdf(x, i, theta_full, labels[i]) for i in te])
+            # classifier.Loss with config.Balance: class weights of the row set itself (kmerLr_classifier_ensemble.go:108-116)
+            cwt, cws = O.class_weights(labels[tr]), O.class_weights(labels[te])
+            lt = -np.mean([cwt[labels[i]] * O.class_log_pdf(x, i, theta_full, labels[i]) for i in tr])
+            ls = -np.mean([cws[labels[i]] * O.class_log_pdf(x, i, theta_full, labels[i]) for i in te])
             assert abs(r["loss_train"][j, f] - lt) < 1e-12 and abs(r["loss_test"][j, f] - ls) < 1e-12
     OD.free_matrix(h)
     L = OD.lib()
@@ -176,6 +178,92 @@ def _co_data(golden_dir):
     dense = np.concatenate([fg, bg], axis=0)
     labels = np.array([1] * len(fg) + [0] * len(bg), dtype=np.uint8)
     return O.Csr.from_dense(dense), labels, dense, len(fg)
+
+
+def go_cv_groups(n, fold, val_ratio):
+    """getCvGroups before its shuffle, restated from kmerLr_crossvalidation.go:56-90."""
+    groups, validation = [0] * n, [0] * n
+    if fold <= 1:
+        for i in range(n):
+            groups[i] = -1
+            validation[i] = 1 if (float(i) < val_ratio * float(n) and i + fold < n) else 0
+    else:
+        for i in range(0, n, fold):
+            for j in range(fold):
+                if i + j < n:
+                    groups[i + j] = j
+                    validation[i + j] = 1 if (float(i) < val_ratio * float(n) and i + fold < n) else 0
+    return groups, validation
+
+
+def test_cv_groups_with_validation_follow_getCvGroups():
+    L = OD.lib()
+    for n, fold, ratio in ((16, 1, 0.3), (16, 4, 0.25), (23, 5, 0.5), (10, 3, 0.0), (7, 1, 1.0), (40, 2, 0.1)):
+        g = np.zeros(n, dtype=np.int32); v = np.zeros(n, dtype=np.uint8)
+        L.klr_cv_groups_val(n, fold, ratio, -1, 0, n, g.ctypes.data, v.ctypes.data)          # seed -1: no shuffle
+        eg, ev = go_cv_groups(n, fold, ratio)
+        assert list(g) == eg and list(v) == ev, (n, fold, ratio)
+        g2 = np.zeros(n, dtype=np.int32); v2 = np.zeros(n, dtype=np.uint8)
+        L.klr_cv_groups_val(n, fold, ratio, 3, 0, n, g2.ctypes.data, v2.ctypes.data)
+        # shuffleInts moves both arrays alike: the (group, flag) pairs are a permutation of the unshuffled ones
+        assert sorted(zip(g2.tolist(), v2.tolist())) == sorted(zip(eg, ev))
+        # a shard sees its block of the same assignment
+        g3 = np.zeros(n - 3, dtype=np.int32); v3 = np.zeros(n - 3, dtype=np.uint8)
+        L.klr_cv_groups_val(n, fold, ratio, 3, 3, n - 3, g3.ctypes.data, v3.ctypes.data)
+        assert list(g3) == list(g2[3:]) and list(v3) == list(v2[3:])
+        # without a validation set the groups are klr_cv_groups'
+        g4 = np.zeros(n, dtype=np.int32)
+        L.klr_cv_groups(n, fold, 3, 0, n, g4.ctypes.data)
+        g5 = np.zeros(n, dtype=np.int32)
+        L.klr_cv_groups_val(n, fold, 0.0, 3, 0, n, g5.ctypes.data, None)
+        assert list(g4) == list(g5)
+
+
+def subset(x, rows):
+    rp = [0]; col = []; val = []
+    for i in rows:
+        s, e = x.rowptr[i], x.rowptr[i + 1]
+        col += list(x.col[s:e]); val += list(x.val[s:e]); rp.append(len(col))
+    return O.Csr(len(rows), x.dim, rp, col, val)
+
+
+@pytest.mark.parametrize("k_fold", [1, 3])
+def test_validation_set_selects_the_best_classifier(k_fold):
+    """--validation-size: every lambda_auto is trained on the training rows; per fold only the classifier with the
+    lowest loss on the fold's validation rows is kept (kmerLr_estimator_ensemble.go:119-135); k_fold = 1 is the plain
+    `learn` run with a validation set."""
+    x, labels = O.synth_csr(5, 0, 300, 300, 128, 60, 8)
+    h = OD.matrix(x, labels)
+    L = OD.lib()
+    est = OD.estimator(validation_size=0.2)
+    r = est.crossvalidate(h, x.n, k_fold, [2, 5, 9], seed=11)
+    g = np.zeros(x.n, dtype=np.int32); v = np.zeros(x.n, dtype=np.uint8)
+    L.klr_cv_groups_val(x.n, k_fold, 0.2, 11, 0, x.n, g.ctypes.data, v.ctypes.data)
+    nf = max(k_fold, 1)
+    assert len(r["classifiers"]) == nf
+    for f in range(nf):
+        ff = f                                                 # groups are -1 without folds: no test rows
+        te = np.nonzero(g == ff)[0]
+        va = np.nonzero((g != ff) & (v == 1))[0]
+        tr = np.nonzero((g != ff) & (v == 0))[0]
+        assert len(va) > 0 and len(tr) > 0 and len(te) + len(va) + len(tr) == x.n
+        hs = OD.matrix(subset(x, tr), labels[tr])
+        cs = OD.estimator().estimate(hs, [2, 5, 9])
+        OD.free_matrix(hs)
+        xv = subset(x, va)
+        lv = [O.loss(O.select_columns(xv, c["cols"]), labels[va], c["theta"]) for c in cs]
+        best = cs[int(np.argmin(lv))]
+        c = r["classifiers"][f]
+        np.testing.assert_array_equal(c["cols"], best["cols"])
+        np.testing.assert_allclose(c["theta"], best["theta"], rtol=1e-9, atol=1e-13)
+        lt = O.loss(O.select_columns(subset(x, tr), c["cols"]), labels[tr], c["theta"])
+        assert abs(r["loss_train"][0, f] - lt) < 1e-10
+        if k_fold > 1:
+            ls = O.loss(O.select_columns(subset(x, te), c["cols"]), labels[te], c["theta"])
+            assert abs(r["loss_test"][0, f] - ls) < 1e-10
+        else:
+            assert r["loss_test"][0, f] == 0.0
+    OD.free_matrix(h)
 
 
 def test_scores2_cooccurrence_lambda_auto_1(golden_dir, tmp_path):
@@ -279,3 +367,34 @@ def test_ensemble_members_train_on_the_other_groups(tmp_path):
         want = [c["theta"][0]] + [th.get(u, 0.0) for u in uni]
         np.testing.assert_allclose(lr[k]["Parameters"], want)
     OD.free_matrix(h)
+
+
+def test_two_estimators_in_two_threads():
+    """The host driver keeps no state outside its estimator: two threads run whole leapfrog estimates at the same time
+    (ctypes releases the GIL) and reproduce the sequential runs bit for bit (one estimator per fold / ensemble member in
+    the reference: kmerLr_crossvalidation.go:176, kmerLr_estimator_ensemble.go:81)."""
+    import threading
+    data = [O.synth_csr(41 + i, 0, 400 + 100 * i, 400 + 100 * i, 256, 80, 10) for i in range(2)]
+    hs = [OD.matrix(x, labels) for x, labels in data]
+
+    def job(i, out):
+        est = OD.estimator(balance=1, save_trace=1)
+        cls = est.estimate(hs[i], [3, 7])
+        out[i] = (cls, est.epochs(), len(est.trace()))
+
+    seq, par = {}, {}
+    for i in range(2):
+        job(i, seq)
+    ths = [threading.Thread(target=job, args=(i, par)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert len(par) == 2
+    for i in range(2):
+        (ca, ea, ta), (cb, eb, tb) = seq[i], par[i]
+        assert ea == eb and ta == tb
+        for a, b in zip(ca, cb):
+            np.testing.assert_array_equal(a["cols"], b["cols"]); np.testing.assert_array_equal(a["theta"], b["theta"])
+    for h in hs:
+        OD.free_matrix(h)

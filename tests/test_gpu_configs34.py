@@ -86,13 +86,13 @@ def test_c3_shard_sweep_exact_and_selection(ctx, shard_c3):
     assert abs(ra["g"][0] - (2.0 * (N_ROWS - rows_fg) - 0.5 * rows_fg) / (2.0 * N_ROWS)) < 1e-12
 
 
-def test_c3_shard_entry_formats_agree(ctx, monkeypatch):
+def test_c3_shard_entry_formats_agree(ctx, setopt):
     """Every entry format of the packed stream gives the same integer sums on the 1M-column shape (bitwise equal g)."""
     n = 20000                                            # 20k rows keep the three extra ingests short; same column geometry
     rowptr, col, val, labels = K.synth_csr(SEED, 0, n, n, M_COLS, DRAWS, 1000)
     gs = {}
     for fmt in FORMATS:
-        monkeypatch.setenv("KLR_ENTRY_FORMAT", fmt)
+        setopt("KLR_ENTRY_FORMAT", fmt)
         mat = K.Matrix.from_csr(ctx, n, M_COLS + 1, rowptr, col, val, labels)
         assert mat.layout()["tiled"]
         theta_cols = np.array([0, 17, 4242, 1000003])
@@ -145,7 +145,7 @@ def shard_c4(ctx):
     mat.close()
 
 
-def test_c4_leapfrog_path_50_200_1000_5000(ctx, shard_c4, monkeypatch):
+def test_c4_leapfrog_path_50_200_1000_5000(ctx, shard_c4, setopt):
     from kmerlr_amd import _driver
     mat, labels = shard_c4
     path = [50, 200, 1000, 5000]
@@ -169,8 +169,8 @@ def test_c4_leapfrog_path_50_200_1000_5000(ctx, shard_c4, monkeypatch):
     for a, b in zip(cls, cls2):
         np.testing.assert_array_equal(a["cols"], b["cols"]); np.testing.assert_array_equal(a["theta"], b["theta"])
     assert ep2 == ep
-    monkeypatch.setenv("KLR_CD_BATCH", "3")
-    monkeypatch.setenv("KLR_CD_FIRST_BATCH", "8")
+    setopt("KLR_CD_BATCH", "3")
+    setopt("KLR_CD_FIRST_BATCH", "8")
     cls3, ep3 = run()
     for a, b in zip(cls, cls3):
         np.testing.assert_array_equal(a["cols"], b["cols"]); np.testing.assert_array_equal(a["theta"], b["theta"])

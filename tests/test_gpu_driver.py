@@ -124,7 +124,7 @@ def test_allreduce_hook_f64_and_int64(ctx):
 
 
 @pytest.mark.parametrize("N", [150, 600])
-def test_allreduce_hook_large_selection(ctx, N, monkeypatch):
+def test_allreduce_hook_large_selection(ctx, N, setopt):
     """The same emulated second rank for the solver paths of larger selections: tiled Gram partials reduced to the
     integer Gram, all-reduced and assembled around the hook (128 < d <= 1024), q = G theta carried between batches,
     the wave (d <= 512) and blocked (d > 512) sweeps."""
@@ -137,7 +137,7 @@ def test_allreduce_hook_large_selection(ctx, N, monkeypatch):
         host *= 2
         assert hip.hipMemcpy(C.c_void_p(buf), host.ctypes.data_as(C.c_void_p), C.c_size_t(count * 8), 1) == 0
 
-    monkeypatch.setenv("KLR_GRAM_PATH", "lds")
+    setopt("KLR_GRAM_PATH", "lds")
     x, labels = O.synth_csr(13, 0, 3000, 3000, 8192, 400, 2 * N)
     cw = O.class_weights(labels)
     base = K.Context(0)
@@ -204,7 +204,7 @@ def test_crossvalidation_on_gpu_matches_oracle_driver(ctx):
     np.testing.assert_allclose(rg["loss_test"], ro["loss_test"], rtol=1e-8)
 
 
-def test_full_size_estimate_kkt_and_reproducibility(ctx, monkeypatch):
+def test_full_size_estimate_kkt_and_reproducibility(ctx, setopt):
     """The whole leapfrog run at BASELINE configs[2] size (100k x 65,536, --lambda-auto=100), without the oracle (it would
     take minutes): the classifier has exactly N nonzero coefficients, satisfies the KKT conditions of the L1 problem at
     its lambda (|g_j| = lambda with the opposite sign on the support, bias gradient 0) to the accuracy the loss rule stops
@@ -237,8 +237,8 @@ def test_full_size_estimate_kkt_and_reproducibility(ctx, monkeypatch):
     np.testing.assert_array_equal(cl2["cols"], cols)
     np.testing.assert_array_equal(cl2["theta"], theta)
     assert ep2 == ep
-    monkeypatch.setenv("KLR_CD_BATCH", "3")
-    monkeypatch.setenv("KLR_CD_FIRST_BATCH", "8")
+    setopt("KLR_CD_BATCH", "3")
+    setopt("KLR_CD_FIRST_BATCH", "8")
     cl3, ep3 = run()
     np.testing.assert_array_equal(cl3["cols"], cols)
     np.testing.assert_array_equal(cl3["theta"], theta)

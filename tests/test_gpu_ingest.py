@@ -103,19 +103,19 @@ def test_ambiguous_characters_and_short_sequences(ctx):
 
 
 @pytest.fixture()
-def host_ingest(monkeypatch):
+def host_ingest(setopt):
     # klr_mat_from_csr builds large count matrices on the device too; KLR_HOST_INGEST=1 selects the host builder
-    monkeypatch.setenv("KLR_HOST_INGEST", "1")
+    setopt("KLR_HOST_INGEST", "1")
 
 
-def test_from_csr_device_route_equals_host_route(ctx, monkeypatch):
+def test_from_csr_device_route_equals_host_route(ctx, setopt):
     from oracle import oracle as O
     x, labels = O.synth_csr(77, 0, 9000, 9000, 5000, 200, 8)
     v = x.val.copy(); v[5::31] = 300.0; v[x.rowptr[:-1]] = 1.0          # some counts above 255
     md = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, v, labels)
-    monkeypatch.setenv("KLR_HOST_INGEST", "1")
+    setopt("KLR_HOST_INGEST", "1")
     mh = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, v, labels)
-    monkeypatch.delenv("KLR_HOST_INGEST")
+    setopt("KLR_HOST_INGEST", None)
     # the device route builds the row-streamed q64 stream, the host route the tiled formats: different packings of the
     # same integers -- the sweep must agree bit for bit
     assert md.layout()["tiled"] and mh.layout()["tiled"] and md.layout()["format"].startswith("q64")

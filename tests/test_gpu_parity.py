@@ -78,7 +78,7 @@ def test_roundtrip_and_select_columns(ctx, synth_small):
 
 @pytest.mark.parametrize("ncols,mode", [(1, None), (40, "sort"), (40, "flat"), (40, None), (200, None), (256, None),
                                         (700, None), (700, "flat"), (1024, None), (1500, None)])
-def test_select_columns_paths_and_block_reuse(ctx, synth_small, monkeypatch, ncols, mode):
+def test_select_columns_paths_and_block_reuse(ctx, synth_small, setopt, ncols, mode):
     """Row-block binning in LDS (<= 1024 columns, the default), flat kernels with bit-mask ranks (KLR_SUBSELECT=flat),
     counters + in-row sort (more columns, or KLR_SUBSELECT=sort), and the pooled block of a
     released reduced matrix handed to the next sub-select: same CSR as featureSelection.Data + Transform (oracle),
@@ -86,7 +86,7 @@ def test_select_columns_paths_and_block_reuse(ctx, synth_small, monkeypatch, nco
     x, labels = synth_small
     m = upload(ctx, x, labels)
     if mode:
-        monkeypatch.setenv("KLR_SUBSELECT", mode)
+        setopt("KLR_SUBSELECT", mode)
     rng = np.random.default_rng(ncols)
     for rep in range(3):                                   # released blocks are reused by the next call
         k = max(0, ncols - 1 - 7 * rep)
@@ -344,9 +344,9 @@ def synth_tiled():
 
 
 @pytest.fixture(params=["q64c12", "q64c13", "r64", "u24", "u32"])
-def entry_format(request, monkeypatch):
+def entry_format(request, setopt):
     # the packings of the tiled stream: 8-byte quads (row | 4 columns) / 3-byte unit entries / 4-byte entries with a count
-    monkeypatch.setenv("KLR_ENTRY_FORMAT", request.param)
+    setopt("KLR_ENTRY_FORMAT", request.param)
     return request.param
 
 
@@ -375,11 +375,11 @@ def test_tiled_sweep_matches_oracle(ctx, synth_tiled, entry_format):
 
 
 @pytest.mark.parametrize("fmt,dim", [("q64c12", 4_200_000), ("q64c13", 8_300_000)])
-def test_q64_many_strips_per_workgroup(ctx, monkeypatch, fmt, dim):
+def test_q64_many_strips_per_workgroup(ctx, setopt, fmt, dim):
     # > 1000 column strips on 256 workgroups: every workgroup streams four or five pieces, so the second accumulator
     # region is written out and reused in mid-stream (a piece boundary with and without a barrier), and most strips hold
     # only a block or two.  g at theta = 0 is an exact function of the integer column sums: bitwise against numpy.
-    monkeypatch.setenv("KLR_ENTRY_FORMAT", fmt)
+    setopt("KLR_ENTRY_FORMAT", fmt)
     rng = np.random.default_rng(11)
     n, per_row = 6000, 400
     cols = np.sort(rng.integers(1, dim, size=(n, per_row)), axis=1)
@@ -403,7 +403,7 @@ def test_q64_many_strips_per_workgroup(ctx, monkeypatch, fmt, dim):
     assert np.max(np.abs(out["g"] - g_ref)) <= 1e-11 * np.max(np.abs(g_ref))
     out2 = K.sweep_select(ctx, m, None, None, np.zeros(1), cw, 50, want_g=True)
     np.testing.assert_array_equal(out["g"], out2["g"])
-    monkeypatch.setenv("KLR_ENTRY_FORMAT", "u32")
+    setopt("KLR_ENTRY_FORMAT", "u32")
     m2 = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
     out3 = K.sweep_select(ctx, m2, None, None, np.zeros(1), cw, 50, want_g=True)
     np.testing.assert_array_equal(out["g"], out3["g"])
@@ -477,13 +477,13 @@ def test_full_size_properties(ctx):
 
 @pytest.mark.parametrize("gram_path", [None, "lds", "global"])
 @pytest.mark.parametrize("N", [40, 150, 300, 560, 1100, 2100])
-def test_cd_solve_solver_variants(ctx, N, gram_path, monkeypatch):
+def test_cd_solve_solver_variants(ctx, N, gram_path, setopt):
     """d = N+1 selects the solver kernel: one wavefront (Gram in LDS, or 4/8 q values per lane with rows from L2),
     blocked Gauss-Seidel over 16 wavefronts (d > 512), super-blocks with a multi-workgroup update (d > 2048);
     all must follow the oracle's iterate sequence.  gram_path forces the Gram build: privatised in LDS
     (d <= 128: whole, d <= 1024: tile pairs) or global integer atomics -- the default picks by the number of pairs."""
     if gram_path:
-        monkeypatch.setenv("KLR_GRAM_PATH", gram_path)
+        setopt("KLR_GRAM_PATH", gram_path)
     x, labels = O.synth_csr(77, 0, 3000, 3000, 8192, 400, 2 * N)
     m = upload(ctx, x, labels)
     cw = O.class_weights(labels)
@@ -644,7 +644,7 @@ def test_tiled_ragged_rows_and_empty_tiles(ctx, entry_format):
 
 
 @pytest.mark.parametrize("n,m", [(4000, 60), (3000, 255), (700, 17)])
-def test_dense_panel_mfma_gram(ctx, n, m, monkeypatch):
+def test_dense_panel_mfma_gram(ctx, n, m, setopt):
     """Dense score tables (every column stored, scoresLr_data.go:108-117): the reduced matrix is a dense n x d panel and
     the Gram matrix of a re-weighting is built on the matrix cores (k_gram_dense_mfma, v_mfma_f64_16x16x4_f64).  The
     solve must follow the oracle's iterate sequence (theta within 1e-6) and agree with the sparse Gram builds."""
@@ -667,7 +667,7 @@ def test_dense_panel_mfma_gram(ctx, n, m, monkeypatch):
     assert [a["iteration"] for a in recs] == [a["iteration"] for a in reco]
     assert [a["nonzero"] for a in recs] == [a["nonzero"] for a in reco]
     np.testing.assert_allclose(th, tho, rtol=THETA_RTOL, atol=1e-10)
-    monkeypatch.setenv("KLR_GRAM_NO_MFMA", "1")
+    setopt("KLR_GRAM_NO_MFMA", "1")
     th2, recs2 = K.cd_solve(ctx, red, np.zeros(m + 1), cw=cw, l1reg=l1, eps_loss=1e-10, max_iter=80)
     assert len(recs2) == len(recs)
     np.testing.assert_allclose(th, th2, rtol=1e-8, atol=1e-12)
@@ -681,7 +681,7 @@ def test_dense_panel_mfma_gram(ctx, n, m, monkeypatch):
     (2100, 600000, 520, "q64c12"),      # 149 sparse strips of ~16 blocks: more strips than half the workgroups, short pieces
     (9000, 4033, 500, "q64c12"),        # the second strip holds a single column
 ])
-def test_q64_shapes_bitwise_against_u32(ctx, monkeypatch, n, dim, per_row, fmt):
+def test_q64_shapes_bitwise_against_u32(ctx, setopt, n, dim, per_row, fmt):
     """The row-streamed kernel in its variants (S from global memory or copied to LDS, one or two pieces per workgroup,
     strips of a few blocks) against the tiled u32 format: the same integers, bit for bit, and the f64 column sums."""
     rng = np.random.default_rng(n + dim)
@@ -696,11 +696,11 @@ def test_q64_shapes_bitwise_against_u32(ctx, monkeypatch, n, dim, per_row, fmt):
     labels = (rng.uniform(size=n) < 0.5).astype(np.uint8)
     if rowptr[-1] < (1 << 20):
         pytest.skip("below the packed stream's size threshold")
-    monkeypatch.setenv("KLR_ENTRY_FORMAT", fmt)
+    setopt("KLR_ENTRY_FORMAT", fmt)
     m = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
     assert m.layout()["format"] == fmt
     cw = m.class_weights()
-    monkeypatch.setenv("KLR_ENTRY_FORMAT", "u32")
+    setopt("KLR_ENTRY_FORMAT", "u32")
     m2 = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
     assert m2.layout()["format"] == "u32"
     theta = np.zeros(dim); theta[0] = 0.3
@@ -718,11 +718,11 @@ def test_q64_shapes_bitwise_against_u32(ctx, monkeypatch, n, dim, per_row, fmt):
 
 @pytest.mark.parametrize("switch", ["KLR_Q64_SLDS=0", "KLR_Q64_WGS=2", "KLR_Q64_BANK=0", "KLR_FINISH_NO_FLAT=1", "KLR_Q64_CUT=snap",
                                     "KLR_Q64_PIECE_COST=0", "KLR_Q64_SNAP_TOL=0", "KLR_Q64_LDS_KIB=0"])
-def test_q64_switches_leave_the_sums_alone(ctx, synth_tiled, monkeypatch, switch):
+def test_q64_switches_leave_the_sums_alone(ctx, synth_tiled, setopt, switch):
     """Every ingest / launch switch of the row-streamed sweep (column order, cuts, S in LDS, regions per workgroup,
     finish form) changes the schedule only: the gradient is the same, bit for bit."""
     x, labels = synth_tiled
-    monkeypatch.setenv("KLR_ENTRY_FORMAT", "q64c12")
+    setopt("KLR_ENTRY_FORMAT", "q64c12")
     m0 = upload(ctx, x, labels)
     cw = O.class_weights(labels)
     rng = np.random.default_rng(4)
@@ -730,7 +730,7 @@ def test_q64_switches_leave_the_sums_alone(ctx, synth_tiled, monkeypatch, switch
     theta[1 + rng.choice(x.dim - 1, size=30, replace=False)] = rng.normal(size=30) * 0.1
     g0 = K.gradient_dense(ctx, m0, theta, cw=cw)
     name, value = switch.split("=")
-    monkeypatch.setenv(name, value)
+    setopt(name, value)
     m1 = upload(ctx, x, labels)
     assert m1.layout()["format"] == "q64c12"
     np.testing.assert_array_equal(K.gradient_dense(ctx, m1, theta, cw=cw), g0)

@@ -119,12 +119,20 @@ def scatter_collective(K, dist, ctx, hip, rank, world, calls):
     est = _driver.hip_estimator(ctx)
     ca = est.estimate(shard._h, [10, N]); ea = est.epochs(); est.close()
     at = K.sweep_select(ctx, shard, None, None, np.zeros(1), (1.0, 1.0), 400)     # tied count data, wide selection
-    i64_before = calls["i64"]
-    # reduce-scatter form
+    # reduce-scatter form: used only once the hooks passed the collective self-check
     ctx.set_collectives(rs_hook, ag_hook)
+    u0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
+    assert cnt["rs"] == 0 and not ctx.comm_stats()["checked"], "unchecked hooks must not carry the sweep"
+    ctx.comm_selfcheck()
+    assert ctx.comm_stats()["checked"] and cnt == {"rs": 1, "ag": 1}, cnt
+    i64_before = calls["i64"]
     s0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
+    # the first reduce-scatter sweep on a matrix is repeated as an all-reduce and compared (one int64 all-reduce) ...
+    assert cnt == {"rs": 2, "ag": 2} and calls["i64"] == i64_before + 1, (cnt, calls)
     s1 = K.sweep_select(ctx, shard, red, cols, theta, cw, N)
-    assert cnt["rs"] == 2 and cnt["ag"] == 2 and calls["i64"] == i64_before, (cnt, calls)     # no int64 all-reduce was posted
+    # ... later ones post no all-reduce at all
+    assert cnt == {"rs": 3, "ag": 3} and calls["i64"] == i64_before + 1, (cnt, calls)
+    assert u0["lam"] == s0["lam"]
     for a, s in ((a0, s0), (a1, s1)):
         np.testing.assert_array_equal(a["b"], s["b"])
         assert a["lam"] == s["lam"] and a["loss"] == s["loss"] and a["c"] == s["c"] and a["ok"] == s["ok"]
@@ -138,8 +146,10 @@ def scatter_collective(K, dist, ctx, hip, rank, world, calls):
     st = K.sweep_select(ctx, shard, None, None, np.zeros(1), (1.0, 1.0), 400)
     np.testing.assert_array_equal(at["b"], st["b"])
     assert at["lam"] == st["lam"] and at["loss"] == st["loss"] and at["c"] == st["c"]
+    st_ = ctx.comm_stats()
+    assert st_["sweeps_scatter"] >= 3 and st_["sweeps_allreduce"] >= 3, st_
     if rank == 0:
-        print("two ranks ok (scatter): lambda=%e rs=%d ag=%d" % (s0["lam"], cnt["rs"], cnt["ag"]))
+        print("two ranks ok (scatter): lambda=%e rs=%d ag=%d fallbacks=%d" % (s0["lam"], cnt["rs"], cnt["ag"], st_["scatter_fallbacks"]))
     dist.barrier()
     dist.destroy_process_group()
     return 0
