@@ -328,7 +328,7 @@ def main(argv=None):
             "cpu_baseline": cpu_baseline,
             "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
                      "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N),
-                     "selfcheck": "passed" if R.comm else "no communicator", "stats": stats_c2},
+                     "selfcheck": "passed" if R.comm else "no communicator", "stats": stats_c2, "probe": ctx.comm_probe()},
             "cd_sweeps_per_s": cd["sweeps_per_s"], "cd_sweeps": cd,
             "cd_solve": {"sweeps_to_converge": n_sweeps_solve, "seconds": round(t_solve, 4), "nonzero": int(np.count_nonzero(theta[1:]))},
             "estimate_lambda_auto": estimate,
@@ -410,7 +410,7 @@ def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, w
             "roofline": roofline,
             "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
                      "allreduce_elements": m + 6 if R.comm else 0,
-                     "sweep_collective": sweep_collective(world, m, N), "stats": stats},
+                     "sweep_collective": sweep_collective(world, m, N), "stats": stats, "probe": ctx.comm_probe()},
             "estimate_lambda_auto": est,
             "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]}}
 

@@ -105,6 +105,11 @@ int         klr_ctx_comm_selfcheck(klr_ctx* ctx);
 int         klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce, int64_t* sweeps_scatter,
                                int64_t* scatter_fallbacks, int* checked);
 
+/* what the context measured before its first reduce-scatter sweep: the installed reduce-scatter hook on a vector of
+ * `elements` int64 (averaged over the ranks) and the number of strip ranges the overlapped sweep then uses (1 = the
+ * sweep stays one launch).  Zeros before the first such sweep. */
+int         klr_ctx_comm_probe(const klr_ctx* ctx, int64_t* elements, double* reduce_scatter_ms, int* ranges);
+
 /* KLR_* switches.  A context reads the process environment ONCE, in klr_ctx_create; later changes
  * go through these calls (value NULL unsets).  klr_ctx_reload_env re-reads the environment. */
 int         klr_ctx_set_option(klr_ctx* ctx, const char* name, const char* value);

@@ -338,6 +338,14 @@ extern "C" int klr_ctx_comm_selfcheck(klr_ctx* ctx) {
   return KLR_OK;
 }
 
+extern "C" int klr_ctx_comm_probe(const klr_ctx* ctx, int64_t* elements, double* reduce_scatter_ms, int* ranges) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  if (elements) *elements = ctx->probe_dim ? ctx->probe_dim + IB_EXTRA : 0;
+  if (reduce_scatter_ms) *reduce_scatter_ms = ctx->probe_ms;
+  if (ranges) *ranges = ctx->probe_G;
+  return KLR_OK;
+}
+
 extern "C" int klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce, int64_t* sweeps_scatter, int64_t* scatter_fallbacks, int* checked) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   if (sweeps_allreduce) *sweeps_allreduce = ctx->n_ar_sweeps;
@@ -351,7 +359,7 @@ extern "C" int klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, k
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, (rs == nullptr) == (ag == nullptr));
   ctx->rs_fn = rs; ctx->ag_fn = ag; ctx->coll_user = user;
-  ctx->comm_checked = false;
+  ctx->comm_checked = false; ctx->probe_dim = 0;
   return KLR_OK;
 }
 
@@ -433,6 +441,8 @@ extern "C" void klr_ctx_destroy(klr_ctx* ctx) {
   for (int i = 0; i < WS_COUNT; i++) if (ctx->ws[i].p) (void)hipFree(ctx->ws[i].p);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
   shm_release(ctx);
+  for (hipEvent_t ev : ctx->range_ev) (void)hipEventDestroy(ev);
+  if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
   if (ctx->rccl) {
     RcclState* st = (RcclState*)ctx->rccl;
     if (st->comm) st->CommDestroy(st->comm);

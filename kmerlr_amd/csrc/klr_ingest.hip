@@ -504,23 +504,21 @@ static int exscan64(klr_ctx* ctx, const u32* in, i64 n, i64* out) { return launc
 
 int build_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<u64>& toff4, i64 nrt, i64 nct, bool rt_major);
 
-// pieces of a q64 stream: the 64-unit blocks are dealt to nwg workgroups in equal shares, a share snapped to a strip
-// boundary when one lies within a few percent of it; a share is cut into pieces where the strip changes
-static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64>& strip_unit, i64 nct) {
-  // first row of a block, read back from the device table (one entry per workgroup; rows + 1024 must stay inside S)
-  std::vector<u32> h_blkrow((size_t)(strip_unit[(size_t)nct] / 64));
-  KLR_HIP(ctx, hipMemcpy(h_blkrow.data(), m->t_blkrow, h_blkrow.size() * 4, hipMemcpyDeviceToHost));
+// pieces of a q64 stream: the 64-unit blocks of strips [t0, t1) are dealt to nwg workgroups in equal shares, a share
+// snapped to a strip boundary when one lies within a few percent of it; a share is cut into pieces where the strip
+// changes.  Host work only.  piece: 4 u32 per piece {strip, first unit, end unit, 0}, ids local to the call; wgp: first
+// piece of every workgroup (nwg + 1); rec: the 48-byte workgroup records of the kernel (piece ids local: the caller adds
+// its offset); slds_rows > 0: every workgroup's rows fit LDS beside its accumulators (SLDS), the most rows of one.
+struct Q64Cuts { std::vector<u32> piece, wgp, rec; u32 npiece = 0, slds_rows = 0; };
+static void q64_cuts(klr_ctx* ctx, const klr_mat* m, const std::vector<u64>& sb, i64 t0, i64 t1, u32 nwg, int per_cu, Q64Cuts* out) {
+  const std::vector<u32>& h_blkrow = m->h_q64_blkrow;
   const i64 n_rows = m->n;
   auto h_blkrow_at = [&](u32 b) -> u32 {
     const i64 r = b < h_blkrow.size() ? (i64)h_blkrow[b] : 0;
     return (u32)std::max<i64>(0, std::min<i64>(r, n_rows - 1024));       // the warming load reads S[r .. r + 1024)
   };
-  const u64 total_blk = (u64)strip_unit[(size_t)nct] / 64;
-  // one workgroup per CU (a piece vector written per (strip, workgroup): half as many as with two), KLR_Q64_WGS=2 for two
-  const int per_cu = ctx_opt(ctx, "KLR_Q64_WGS") ? std::max(1, std::min(2, atoi(ctx_opt(ctx, "KLR_Q64_WGS")))) : 1;
-  const u32 nwg = (u32)std::max(2, per_cu * ctx->n_cu);
-  std::vector<u64> sb((size_t)nct + 1);
-  for (i64 t = 0; t <= nct; t++) sb[(size_t)t] = (u64)strip_unit[(size_t)t] / 64;
+  const u64 blk0 = sb[(size_t)t0], blk1 = sb[(size_t)t1];
+  const u64 total_blk = blk1 - blk0;
   // The kernel ends when its slowest workgroup does.  Equal shares of the blocks, with two corrections: a cut within
   // 4 % of a share of a strip boundary is snapped to it (a piece is 2^CB x 8 bytes written and read back: not worth a
   // sliver of a strip), and a share that still crosses a boundary pays for its second piece -- a second vector zeroed
@@ -538,17 +536,17 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     u32 crossings = 0;
     for (int pass = plain ? 1 : 0; pass < 2; pass++) {
       const double extra = pass && !plain ? (double)piece_cost * (double)crossings / (double)std::max<u64>(total_blk, 1) : 0.0;
-      i64 t = 0;
-      cut[0] = 0;
+      i64 t = t0;
+      cut[0] = blk0;
       u32 crossed = 0;
       for (u32 w = 1; w <= nwg; w++) {
         const u64 prev = cut[w - 1];
-        const u64 share = (u64)((double)(total_blk - prev) * (1.0 + extra) / (double)(nwg - w + 1));
-        const u64 ideal = std::min<u64>(prev + share, total_blk);
+        const u64 share = (u64)((double)(blk1 - prev) * (1.0 + extra) / (double)(nwg - w + 1));
+        const u64 ideal = std::min<u64>(prev + share, blk1);
         const double tol = tolf * (double)share;
-        while (t < nct && sb[(size_t)t + 1] <= ideal) t++;
+        while (t < t1 && sb[(size_t)t + 1] <= ideal) t++;
         u64 c = ideal;
-        const u64 lo = sb[(size_t)t], hi = t < nct ? sb[(size_t)t + 1] : total_blk;
+        const u64 lo = sb[(size_t)std::min(t, t1)], hi = t < t1 ? sb[(size_t)t + 1] : blk1;
         if (lo > prev && (double)(ideal - lo) <= tol && (ideal - lo) <= (hi - ideal)) c = lo;
         else if ((double)(hi - ideal) <= tol) c = hi;
         if (lo > prev && c > lo) {
@@ -559,11 +557,13 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
       }
       crossings = crossed;
     }
-    cut[nwg] = total_blk;
+    cut[nwg] = blk1;
   }
-  std::vector<u32> piece, wgp((size_t)nwg + 1);
+  std::vector<u32>& piece = out->piece;
+  std::vector<u32>& wgp = out->wgp;
+  piece.clear(); wgp.assign((size_t)nwg + 1, 0u);
   {
-    i64 t = 0;
+    i64 t = t0;
     for (u32 w = 0; w < nwg; w++) {
       wgp[w] = (u32)(piece.size() / 4);
       u64 q = cut[w];
@@ -577,9 +577,9 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
     }
     wgp[nwg] = (u32)(piece.size() / 4);
   }
-  const u32 npiece = (u32)(piece.size() / 4);
+  out->npiece = (u32)(piece.size() / 4);
   if (ctx_opt(ctx, "KLR_Q64_DEBUG")) {
-    fprintf(stderr, "q64 cuts: %llu blocks, %lld strips, %u workgroups, %u pieces\n", (unsigned long long)total_blk, (long long)nct, nwg, npiece);
+    fprintf(stderr, "q64 cuts: strips %lld..%lld, %llu blocks, %u workgroups, %u pieces\n", (long long)t0, (long long)t1, (unsigned long long)total_blk, nwg, out->npiece);
     for (u32 w = 0; w < std::min<u32>(nwg, 10u); w++) {
       fprintf(stderr, "  wg %u:", w);
       for (u32 q = wgp[w]; q < wgp[w + 1]; q++) fprintf(stderr, " [strip %u: blocks %u..%u of %llu..%llu]", piece[(size_t)q * 4], piece[(size_t)q * 4 + 1] / 64,
@@ -587,58 +587,141 @@ static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64
       fprintf(stderr, "\n");
     }
   }
-  std::vector<u32> ctptr((size_t)nct + 1, 0u), ctlist(std::max<u32>(npiece, 1));
-  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
-  m->max_ct_pieces = 0;
-  for (i64 c = 0; c < nct; c++) m->max_ct_pieces = std::max(m->max_ct_pieces, ctptr[(size_t)c + 1]);
-  for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
-  {
-    std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
-    for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
+  // per workgroup (48 bytes): {first piece, end piece, first unit, end unit of the first piece} {first row of its first
+  // block, -, -, -} {first row, rows of its first piece; first row, rows of its second piece}.  The last four let the
+  // sweep keep the S values of the workgroup's rows in LDS (SLDS) when EVERY workgroup has at most two pieces and its
+  // rows fit beside the two accumulator regions: dense strips (configs[2]: ~6.7k rows per workgroup).
+  std::vector<u32>& rec = out->rec;
+  rec.assign((size_t)nwg * 12, 0u);
+  const int CBm = m->fmt == FMT_Q64C13 ? 13 : 12;
+  const size_t lds_rows_cap = (((size_t)159 << 10) - 2 * ((size_t)8 << CBm)) / 8;
+  bool slds = per_cu == 1 && !(ctx_opt(ctx, "KLR_Q64_SLDS") && atoi(ctx_opt(ctx, "KLR_Q64_SLDS")) == 0);
+  u32 most_rows = 0;
+  for (u32 w = 0; w < nwg; w++) {
+    rec[(size_t)w * 12] = wgp[w]; rec[(size_t)w * 12 + 1] = wgp[w + 1];
+    if (wgp[w] < wgp[w + 1]) {
+      rec[(size_t)w * 12 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 12 + 3] = piece[(size_t)wgp[w] * 4 + 2];
+      rec[(size_t)w * 12 + 4] = h_blkrow_at(piece[(size_t)wgp[w] * 4 + 1] / 64);
+    }
+    if (wgp[w + 1] - wgp[w] > 2) slds = false;
+    u32 rows = 0;
+    for (u32 q = wgp[w]; q < wgp[w + 1] && q < wgp[w] + 2; q++) {
+      const u32 t = piece[(size_t)q * 4], b_first = piece[(size_t)q * 4 + 1] / 64, b_end = piece[(size_t)q * 4 + 2] / 64;
+      const i64 lo = (i64)h_blkrow[b_first];
+      // rows ascend inside a strip: the piece's last row is at most the first row of the block after it
+      const i64 hi = (u64)b_end >= sb[(size_t)t + 1] ? n_rows : std::min<i64>(n_rows, (i64)h_blkrow[b_end] + 1);
+      const i64 nr = std::max<i64>(hi - lo, 0);
+      if (nr > (i64)lds_rows_cap) { slds = false; break; }
+      rec[(size_t)w * 12 + 8 + 2 * (q - wgp[w])] = (u32)lo; rec[(size_t)w * 12 + 9 + 2 * (q - wgp[w])] = (u32)nr;
+      rows += (u32)nr;
+    }
+    if (rows > lds_rows_cap) slds = false;
+    most_rows = std::max(most_rows, rows);
   }
+  out->slds_rows = slds ? std::max<u32>(most_rows, 1u) : 0u;
+}
+
+// pieces grouped by strip for the finishing kernel: ctptr (nct + 1), ctlist (npiece), most pieces of one strip
+static u32 q64_group_pieces(const std::vector<u32>& piece, u32 npiece, i64 nct, std::vector<u32>& ctptr, std::vector<u32>& ctlist) {
+  ctptr.assign((size_t)nct + 1, 0u); ctlist.assign(std::max<u32>(npiece, 1), 0u);
+  for (u32 p = 0; p < npiece; p++) ctptr[(size_t)piece[(size_t)p * 4] + 1]++;
+  u32 most = 0;
+  for (i64 c = 0; c < nct; c++) most = std::max(most, ctptr[(size_t)c + 1]);
+  for (i64 c = 0; c < nct; c++) ctptr[(size_t)c + 1] += ctptr[(size_t)c];
+  std::vector<u32> cur(ctptr.begin(), ctptr.end() - 1);
+  for (u32 p = 0; p < npiece; p++) ctlist[cur[(size_t)piece[(size_t)p * 4]]++] = p;
+  return most;
+}
+
+static int q64_pieces_and_upload(klr_ctx* ctx, klr_mat* m, const std::vector<i64>& strip_unit, i64 nct) {
+  // first row of a block, read back from the device table (one entry per workgroup; rows + 1024 must stay inside S)
+  m->h_q64_blkrow.resize((size_t)(strip_unit[(size_t)nct] / 64));
+  KLR_HIP(ctx, hipMemcpy(m->h_q64_blkrow.data(), m->t_blkrow, m->h_q64_blkrow.size() * 4, hipMemcpyDeviceToHost));
+  // one workgroup per CU (a piece vector written per (strip, workgroup): half as many as with two), KLR_Q64_WGS=2 for two
+  const int per_cu = ctx_opt(ctx, "KLR_Q64_WGS") ? std::max(1, std::min(2, atoi(ctx_opt(ctx, "KLR_Q64_WGS")))) : 1;
+  const u32 nwg = (u32)std::max(2, per_cu * ctx->n_cu);
+  m->h_q64_sb.resize((size_t)nct + 1);
+  for (i64 t = 0; t <= nct; t++) m->h_q64_sb[(size_t)t] = (u64)strip_unit[(size_t)t] / 64;
+  Q64Cuts c;
+  q64_cuts(ctx, m, m->h_q64_sb, 0, nct, nwg, per_cu, &c);
+  const u32 npiece = c.npiece;
+  std::vector<u32> ctptr, ctlist;
+  m->max_ct_pieces = q64_group_pieces(c.piece, npiece, nct, ctptr, ctlist);
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_piece, (size_t)std::max<u32>(npiece, 1) * 16));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_wgpiece, (size_t)nwg * 48));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctptr, ((size_t)nct + 1) * 4));
   KLR_TRY(dev_alloc(ctx, (void**)&m->t_ctlist, (size_t)std::max<u32>(npiece, 1) * 4));
-  KLR_HIP(ctx, hipMemcpy(m->t_piece, piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
-  {
-    // per workgroup (48 bytes): {first piece, end piece, first unit, end unit of the first piece} {first row of its first
-    // block, -, -, -} {first row, rows of its first piece; first row, rows of its second piece}.  The last four let the
-    // sweep keep the S values of the workgroup's rows in LDS (SLDS) when EVERY workgroup has at most two pieces and its
-    // rows fit beside the two accumulator regions: dense strips (configs[2]: ~6.7k rows per workgroup).
-    std::vector<u32> rec((size_t)nwg * 12, 0u);
-    const int CBm = m->fmt == FMT_Q64C13 ? 13 : 12;
-    const size_t lds_rows_cap = (((size_t)159 << 10) - 2 * ((size_t)8 << CBm)) / 8;
-    bool slds = per_cu == 1 && !(ctx_opt(ctx, "KLR_Q64_SLDS") && atoi(ctx_opt(ctx, "KLR_Q64_SLDS")) == 0);
-    u32 most_rows = 0;
-    for (u32 w = 0; w < nwg; w++) {
-      rec[(size_t)w * 12] = wgp[w]; rec[(size_t)w * 12 + 1] = wgp[w + 1];
-      if (wgp[w] < wgp[w + 1]) {
-        rec[(size_t)w * 12 + 2] = piece[(size_t)wgp[w] * 4 + 1]; rec[(size_t)w * 12 + 3] = piece[(size_t)wgp[w] * 4 + 2];
-        rec[(size_t)w * 12 + 4] = h_blkrow_at(piece[(size_t)wgp[w] * 4 + 1] / 64);
-      }
-      if (wgp[w + 1] - wgp[w] > 2) slds = false;
-      u32 rows = 0;
-      for (u32 q = wgp[w]; q < wgp[w + 1] && q < wgp[w] + 2; q++) {
-        const u32 t = piece[(size_t)q * 4], b_first = piece[(size_t)q * 4 + 1] / 64, b_end = piece[(size_t)q * 4 + 2] / 64;
-        const i64 lo = (i64)h_blkrow[b_first];
-        // rows ascend inside a strip: the piece's last row is at most the first row of the block after it
-        const i64 hi = (u64)b_end >= sb[(size_t)t + 1] ? n_rows : std::min<i64>(n_rows, (i64)h_blkrow[b_end] + 1);
-        const i64 nr = std::max<i64>(hi - lo, 0);
-        if (nr > (i64)lds_rows_cap) { slds = false; break; }
-        rec[(size_t)w * 12 + 8 + 2 * (q - wgp[w])] = (u32)lo; rec[(size_t)w * 12 + 9 + 2 * (q - wgp[w])] = (u32)nr;
-        rows += (u32)nr;
-      }
-      if (rows > lds_rows_cap) slds = false;
-      most_rows = std::max(most_rows, rows);
-    }
-    m->q64_slds_rows = slds ? std::max<u32>(most_rows, 1u) : 0u;
-    KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, rec.data(), (size_t)nwg * 48, hipMemcpyHostToDevice));
-  }
+  KLR_HIP(ctx, hipMemcpy(m->t_piece, c.piece.data(), (size_t)npiece * 16, hipMemcpyHostToDevice));
+  m->q64_slds_rows = c.slds_rows;
+  KLR_HIP(ctx, hipMemcpy(m->t_wgpiece, c.rec.data(), (size_t)nwg * 48, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice));
   KLR_HIP(ctx, hipMemcpy(m->t_ctlist, ctlist.data(), (size_t)npiece * 4, hipMemcpyHostToDevice));
   m->rt_major = false; m->tiled = true; m->nrt = 1; m->nct = (u32)nct; m->nwg = nwg; m->npiece = npiece;
   m->total4 = strip_unit[(size_t)nct];
+  return KLR_OK;
+}
+
+void q64_free_ranges(klr_mat* m) {
+  if (!m->qr) return;
+  for (Q64Range& r : m->qr->r) if (r.t_wgpiece) (void)hipFree(r.t_wgpiece);
+  if (m->qr->t_piece) (void)hipFree(m->qr->t_piece);
+  if (m->qr->t_ctptr) (void)hipFree(m->qr->t_ctptr);
+  if (m->qr->t_ctlist) (void)hipFree(m->qr->t_ctlist);
+  delete m->qr;
+  m->qr = nullptr;
+}
+
+// The strip-range layout: G contiguous ranges of strips with about equal stream length (a range boundary is a strip
+// boundary), every range cut for all workgroups by the same rule as the whole stream.  Piece ids run through the ranges.
+int q64_build_ranges(klr_ctx* ctx, klr_mat* m, int G) {
+  if (m->qr && m->qr->G == G) return KLR_OK;
+  q64_free_ranges(m);
+  const i64 nct = m->nct;
+  if (!(m->fmt == FMT_Q64C12 || m->fmt == FMT_Q64C13) || m->h_q64_sb.size() != (size_t)nct + 1 || G < 2 || nct < 2 * G) return KLR_OK;
+  const std::vector<u64>& sb = m->h_q64_sb;
+  const int per_cu = (int)std::max<u32>(1, m->nwg / (u32)std::max(1, ctx->n_cu));
+  Q64Ranges* qr = new Q64Ranges();
+  qr->G = G;
+  std::vector<u32> piece_all;
+  i64 t_prev = 0;
+  int rc = KLR_OK;
+  for (int g = 0; g < G && rc == KLR_OK; g++) {
+    // the strip boundary nearest to (g + 1) / G of the stream (at least one strip per range)
+    i64 t_end = nct;
+    if (g + 1 < G) {
+      const u64 want = sb[(size_t)nct] * (u64)(g + 1) / (u64)G;
+      t_end = t_prev + 1;
+      while (t_end < nct - (G - 1 - g) && sb[(size_t)t_end] < want) t_end++;
+      if (t_end > t_prev + 1 && want - sb[(size_t)t_end - 1] < sb[(size_t)t_end] - want) t_end--;
+    }
+    Q64Cuts c;
+    q64_cuts(ctx, m, sb, t_prev, t_end, m->nwg, per_cu, &c);
+    Q64Range r;
+    r.strip0 = (u32)t_prev; r.strip1 = (u32)t_end;
+    r.col0 = (i64)t_prev * m->tile_c; r.col1 = std::min<i64>(m->dim, (i64)t_end * m->tile_c);
+    r.piece0 = (u32)(piece_all.size() / 4); r.npiece = c.npiece; r.nwg = m->nwg; r.slds_rows = c.slds_rows;
+    for (u32 w = 0; w < m->nwg; w++) { c.rec[(size_t)w * 12] += r.piece0; c.rec[(size_t)w * 12 + 1] += r.piece0; }
+    piece_all.insert(piece_all.end(), c.piece.begin(), c.piece.end());
+    if ((rc = dev_alloc(ctx, (void**)&r.t_wgpiece, (size_t)m->nwg * 48)) == KLR_OK &&
+        hipMemcpy(r.t_wgpiece, c.rec.data(), (size_t)m->nwg * 48, hipMemcpyHostToDevice) != hipSuccess)
+      rc = klr_fail(ctx, KLR_EHIP, "q64_build_ranges: upload failed");
+    qr->r.push_back(r);
+    t_prev = t_end;
+  }
+  m->qr = qr;
+  if (rc != KLR_OK) { q64_free_ranges(m); return rc; }
+  qr->npiece = (u32)(piece_all.size() / 4);
+  std::vector<u32> ctptr, ctlist;
+  qr->max_ct_pieces = q64_group_pieces(piece_all, qr->npiece, nct, ctptr, ctlist);
+  if ((rc = dev_alloc(ctx, (void**)&qr->t_piece, (size_t)std::max<u32>(qr->npiece, 1) * 16)) != KLR_OK ||
+      (rc = dev_alloc(ctx, (void**)&qr->t_ctptr, ((size_t)nct + 1) * 4)) != KLR_OK ||
+      (rc = dev_alloc(ctx, (void**)&qr->t_ctlist, (size_t)std::max<u32>(qr->npiece, 1) * 4)) != KLR_OK) { q64_free_ranges(m); return rc; }
+  if (hipMemcpy(qr->t_piece, piece_all.data(), (size_t)qr->npiece * 16, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(qr->t_ctptr, ctptr.data(), ((size_t)nct + 1) * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(qr->t_ctlist, ctlist.data(), (size_t)qr->npiece * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    q64_free_ranges(m);
+    return klr_fail(ctx, KLR_EHIP, "q64_build_ranges: upload failed");
+  }
   return KLR_OK;
 }
 
@@ -677,6 +760,12 @@ static int build_q64(klr_ctx* ctx, klr_mat* m, TmpPool& tmp, bool* built) {
   const u64 quads = CB == 13 ? h_tot[1] : h_tot[0];
   if (quads == 0 || quads / 2 + (u64)nct * 64 >= 0x0FFFFF00ull) return KLR_OK;       // the sweep addresses the stream with 32-bit byte offsets
   if ((u64)nct * (u64)n >= ((u64)1 << 32)) return KLR_OK;                              // the (strip, row) table is scanned with 32-bit counts
+  {
+    // the (strip, row) count table and its prefix are 12 bytes x strips x rows of scratch: when that does not fit beside
+    // the stream itself the tiled formats are built instead (not an error)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ((size_t)nct * (size_t)n * 12 + quads * 8) > free_b / 2) return KLR_OK;
+  }
   u32 *rq, *sunits; i64 *rq_prefix, *strip_unit;
   KLR_TRY(tmp.get(ctx, &rq, (size_t)nct * n + 1)); KLR_TRY(tmp.get(ctx, &rq_prefix, (size_t)nct * n + 2));
   KLR_TRY(tmp.get(ctx, &sunits, (size_t)nct + 1)); KLR_TRY(tmp.get(ctx, &strip_unit, (size_t)nct + 2));

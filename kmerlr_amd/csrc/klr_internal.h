@@ -59,6 +59,8 @@ struct klr_ctx {
   void*        coll_user = nullptr;
   void*        rccl = nullptr;       // struct RcclState*
   void*        shm = nullptr;        // struct ShmState* (klr_shm.hip)
+  hipStream_t  stream2 = nullptr;    // second stream: finish + collective of strip range g while range g + 1 streams
+  std::vector<hipEvent_t> range_ev;  // "range g's sweep kernel is done", recorded on `stream`, awaited by `stream2`
   DevBuf       ws[WS_COUNT];
   // pinned host staging
   void*        pin = nullptr;
@@ -103,6 +105,9 @@ struct klr_ctx {
   // sweep collectives that fell back from the reduce-scatter form to the all-reduce (klr_ctx_comm_stats)
   i64 n_rs_sweeps = 0, n_rs_fallbacks = 0, n_ar_sweeps = 0;
   bool comm_checked = false;     // the installed collectives passed klr_ctx_comm_selfcheck
+  // strip ranges of the overlapped sweep, chosen once per vector length from the MEASURED reduce-scatter time of the
+  // installed hook (sweep_ranges_auto, klr_select.hip): probe_dim = that length, probe_G = the choice, probe_ms = the time
+  i64 probe_dim = 0; int probe_G = 1; double probe_ms = 0.0;
 };
 
 void shm_release(klr_ctx* ctx);                                  // klr_shm.hip
@@ -116,6 +121,21 @@ bool ctx_alive(const klr_ctx* ctx);                              // false once k
 int  pool_get(klr_ctx* ctx, size_t bytes, void** p, size_t* cap);
 void pool_put(klr_ctx* ctx, void* p, size_t cap);
 int  stage_get(klr_ctx* ctx, size_t bytes, void** out);          // waits for the previous copy out of the buffer
+
+// what a launch of k_sweep_q64 needs beside the stream itself: the whole matrix (the tables the ingest made) or one
+// strip range of the overlapped form (q64_build_ranges)
+struct Q64View { u32 nwg = 0; const u32* t_piece = nullptr; const u32* t_wgpiece = nullptr; u32 slds_rows = 0; };
+// Strip ranges of a q64 stream (klr_ingest.hip q64_build_ranges): the strips are dealt into G contiguous ranges of about
+// equal stream length, each cut for ALL workgroups like the whole stream is -- one launch per range; while range g + 1
+// streams, range g's column sums are final and can be summed, reduce-scattered and searched on a second stream
+// (klr_select.hip).  Piece ids run through all ranges (one `part` buffer), ctptr / ctlist group them by strip.
+struct Q64Range { u32 strip0 = 0, strip1 = 0; i64 col0 = 0, col1 = 0; u32 piece0 = 0, npiece = 0; u32* t_wgpiece = nullptr; u32 nwg = 0; u32 slds_rows = 0; };
+struct Q64Ranges {
+  int G = 0;
+  std::vector<Q64Range> r;
+  u32* t_piece = nullptr; u32* t_ctptr = nullptr; u32* t_ctlist = nullptr;
+  u32 npiece = 0, max_ct_pieces = 0;
+};
 
 struct klr_mat {
   klr_ctx* ctx = nullptr;
@@ -172,6 +192,9 @@ struct klr_mat {
   u32* t_blkrow = nullptr;       // q64: first row of every 64-unit block of the stream (row fields are relative to it)
   u32  max_ct_pieces = 0;        // most pieces of one column tile / strip (0: not recorded): k_finish_coo's FLAT form up to 8
   u32  q64_slds_rows = 0;        // q64: > 0 = every workgroup's rows fit LDS beside its accumulators (k_sweep_q64 SLDS): the most rows of one
+  std::vector<u64> h_q64_sb;     // q64: block offset of every strip (nct + 1) and ...
+  std::vector<u32> h_q64_blkrow; // ... the first row of every block, host copies for cuts made later (q64_build_ranges)
+  Q64Ranges* qr = nullptr;       // strip-range layout of the overlapped sweep, built on first use
   u32* t_ctptr = nullptr;        // nct+1: pieces per column tile (for the finish kernel)
   u32* t_ctlist = nullptr;       // npiece piece ids grouped by column tile
   // ---- host metadata
@@ -264,6 +287,12 @@ int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* g
 int   sweep_fix_tail(klr_ctx* ctx, const klr_mat* mat, double scale, i64* ibuf, double* gbuf, u64* keys, u32* hist,
                      const SelHint* hint);
 #define IB_EXTRA 5
+// strip-range form of the integer sweep (klr_sweep.hip): layout + shared piece buffer; one launch per range on the ctx
+// stream; piece sums of a column range into a vector of its own on any stream
+int   sweep_ranges_prepare(klr_ctx* ctx, const klr_mat* mat, int G_want, const Q64Ranges** qr_out, i64** part_out);
+int   sweep_range_launch(klr_ctx* ctx, const klr_mat* mat, int g, i64* part);
+int   sweep_range_finish(klr_ctx* ctx, const klr_mat* mat, i64 col0, i64 col1, const i64* part, i64* vec, const unsigned long long* rowblk,
+                         i64 nrowblk, hipStream_t st);
 int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                           const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
                           const double* theta_host = nullptr, i64 theta_len = 0);
@@ -312,3 +341,6 @@ static const u32 TILE_DIM = 1u << TILE_BITS;   // at most 4096 rows x 4096 colum
 void tile_geometry(i64 n, i64 dim, u32 nwg, u32* tile_r, u32* tile_c, i64* nrt, i64* nct);
 // klr_ingest.hip: CSC + tiles + host metadata from a narrow count CSR already on the device
 int device_finish_csr(klr_ctx* ctx, klr_mat* m);
+// strip-range layout with G ranges (G >= 2) of a q64 matrix; *qr_out = nullptr when the matrix has too few strips
+int q64_build_ranges(klr_ctx* ctx, klr_mat* m, int G);
+void q64_free_ranges(klr_mat* m);

@@ -31,6 +31,7 @@ void mat_free(klr_mat* m) {
     return;
   }
   (void)hipDeviceSynchronize();
+  q64_free_ranges(m);
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
                 m->chunk_begin, m->chunk_len, m->colchunk, m->labels, m->active, m->t_ent, m->t_piece, m->t_wgpiece,
                 m->t_ctptr, m->t_ctlist, m->t_tileq, m->t_blkrow};

@@ -676,110 +676,316 @@ extern "C" int klr_select_fixed(klr_ctx* ctx, const double* g_full, int64_t m, u
 // numbers whichever collective adds them: selection and lambda are bitwise those of the all-reduce path.
 // =================================================================================================
 #define SCAT_HDR 128
+// keys of a rank's slice of one range.  tau != 0 (hinted, SelHint): nothing but the candidate list is produced -- every
+// key at or above tau goes into `cand` with its position in the rank's key list (pos0 + t), claimed per workgroup with
+// one atomic on the global cursor; tau == 0: keys + coarse histogram for the regular selection.
 __global__ __launch_bounds__(256) void k_slice_keys(const i64* __restrict__ rbuf, i64 lo, i64 feat0, i64 m_s, double inv_scale,
-                                                    u64* __restrict__ keys, u32* __restrict__ hist) {
+                                                    u64* __restrict__ keys, u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand,
+                                                    u32* __restrict__ cursor, u32 pos0) {
   __shared__ u32 sh[FAST_BINS];
-  for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
+  __shared__ Cand wcand[256];
+  __shared__ u32 wcnt, wbase;
+  if (threadIdx.x == 0) wcnt = 0u;
+  if (tau == 0ull) for (int i = threadIdx.x; i < FAST_BINS; i += 256) sh[i] = 0;
   __syncthreads();
   for (i64 t = (i64)blockIdx.x * 256 + threadIdx.x; t < m_s; t += (i64)gridDim.x * 256) {
     const double v = (double)rbuf[feat0 + t - lo] * inv_scale;        // inv_scale is a power of two: exact
     const u64 k = abs_key(v);
-    keys[t] = k;
-    atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+    if (tau == 0ull) {
+      keys[t] = k;
+      atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
+    } else if (k >= tau) {
+      const u32 wp = atomicAdd(&wcnt, 1u);
+      if (wp < 256u) { wcand[wp].key = k; wcand[wp].idx = pos0 + (u32)t; wcand[wp].pad = 0; }
+      else {
+        const u32 pos = atomicAdd(cursor, 1u);
+        if (pos < GCAND_CAP) { cand[pos].key = k; cand[pos].idx = pos0 + (u32)t; cand[pos].pad = 0; }
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+  if (tau != 0ull) {
+    if (threadIdx.x == 0) { const u32 nw = min(wcnt, 256u); wbase = nw ? atomicAdd(cursor, nw) : 0u; }
+    __syncthreads();
+    const u32 nw = min(wcnt, 256u);
+    if (threadIdx.x < nw && wbase + threadIdx.x < GCAND_CAP) cand[wbase + threadIdx.x] = wcand[threadIdx.x];
+  } else
+    for (int i = threadIdx.x; i < FAST_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], sh[i]);
 }
 
-// the five scalars behind the column sums (global elements dim .. dim+4): the rank that owns one writes it, the others 0
+// the five scalars behind the column sums (elements dim .. dim+4 of the vector whose slice this is): the rank that owns
+// one writes it, the others 0
 __global__ void k_slice_extras(const i64* __restrict__ rbuf, i64 lo, i64 slice, i64 dim, i64* __restrict__ dst, u32 m_s, u32 K_s) {
   const int q = threadIdx.x;
   if (q < IB_EXTRA) { const i64 j = dim + q; dst[q] = (j >= lo && j < lo + slice) ? rbuf[j - lo] : 0; }
   if (q == 5) dst[5] = ((i64)m_s << 32) | (i64)K_s;
+  if (q == 6) dst[6] = 0;                                  // the list is a top-K_s list, not "every key at or above lowkey"
 }
 
-static int sweep_select_scatter(klr_ctx* ctx, const klr_mat* full, double scale_fx, i64* ibuf, i64 slice, i64 N, uint8_t* b, i64 c_prev,
+// Hinted slice selection, last launch (one workgroup): the rank's block of the all-gather in one go --
+// [FastState | five scalars it owns, (m_s, listed), complete | the candidates sorted by k_fast_rank, at most kmax of them] --
+// and the control block re-armed.  complete = 1: the list holds EVERY key of the slice at or above lowkey = tau.
+__global__ __launch_bounds__(1024) void k_slice_report(FastCtl* __restrict__ ctl, u64 tau, u32 kmax, const Cand* __restrict__ sorted_dev,
+                                                       const i64* __restrict__ rbuf, i64 lo, i64 slice, i64 dim, u32 m_s, char* __restrict__ blk) {
+  const u32 t = threadIdx.x;
+  const u32 n = ctl->cursor;
+  __syncthreads();                                         // every lane has read the cursor
+  if (t == 0) ctl->cursor = 0u;
+  const bool over = n > FAST_CAP;                          // k_fast_rank left the list alone: the caller falls back
+  const u32 listed = over ? 0u : min(n, kmax);
+  FastState* st = (FastState*)blk;
+  i64* ex = (i64*)(blk + 64);
+  Cand* out = (Cand*)(blk + SCAT_HDR);
+  if (t == 0) {
+    st->lowkey = tau; st->ncand = n; st->cursor = listed; st->fallback = over ? 2u : 0u; st->wfound = 0; st->vkey = 0; st->wkey = 0;
+    ex[5] = ((i64)m_s << 32) | (i64)listed;
+    ex[6] = (!over && n <= kmax) ? 1 : 0;
+  }
+  if (t < IB_EXTRA) { const i64 j = dim + t; ex[t] = (j >= lo && j < lo + slice) ? rbuf[j - lo] : 0; }
+  for (u32 i = t; i < listed; i += 1024) out[i] = sorted_dev[i];
+}
+
+// How the dim + 5 sums travel: G strip ranges (G = 1: the whole vector), range g a vector of its columns [col0, col1)
+// -- the last one with the five scalars behind them -- cut into `nranks` slices of slice[g] elements.  Rank q owns the
+// local elements [q slice, (q + 1) slice) of every range; its features are those that are columns >= 1.  A rank's keys are
+// the concatenation of its ranges' features in range order, i.e. in ascending column order.
+struct ScatterPlan {
+  int G = 1, R = 1;
+  std::vector<i64> col0, col1, len, slice, ioff, roff;
+  i64 send_total = 0, recv_total = 0;
+  i64 feat_lo(int q, int g) const { return (g == 0 && q == 0) ? 1 : (i64)q * slice[(size_t)g]; }                 // local element of the rank's first feature
+  i64 feat_hi(int q, int g) const { return std::min<i64>((i64)(q + 1) * slice[(size_t)g], col1[(size_t)g] - col0[(size_t)g]); }
+  i64 feat_cnt(int q, int g) const { return std::max<i64>(0, feat_hi(q, g) - feat_lo(q, g)); }
+  i64 feat_total(int q) const { i64 t = 0; for (int g = 0; g < G; g++) t += feat_cnt(q, g); return t; }
+  // 0-based feature (column - 1) of position `pos` of rank q's key list
+  i64 feature_of(int q, i64 pos) const {
+    for (int g = 0; g < G; g++) { const i64 c = feat_cnt(q, g); if (pos < c) return col0[(size_t)g] + feat_lo(q, g) + pos - 1; pos -= c; }
+    return -1;
+  }
+};
+
+static ScatterPlan scatter_plan(i64 dim, int R, const Q64Ranges* qr) {
+  ScatterPlan P;
+  P.R = R; P.G = qr ? qr->G : 1;
+  for (int g = 0; g < P.G; g++) {
+    const i64 c0 = qr ? qr->r[(size_t)g].col0 : 0, c1 = qr ? qr->r[(size_t)g].col1 : dim;
+    const i64 len = c1 - c0 + (g == P.G - 1 ? IB_EXTRA : 0);
+    const i64 sl = ceil_div(len, (i64)R);
+    P.col0.push_back(c0); P.col1.push_back(c1); P.len.push_back(len); P.slice.push_back(sl);
+    P.ioff.push_back(P.send_total); P.roff.push_back(P.recv_total);
+    P.send_total += sl * R; P.recv_total += sl;
+  }
+  return P;
+}
+
+// How many strip ranges the overlapped form should use for vectors of `dim` sums on THIS communicator.  Splitting the
+// sweep into G launches costs ~15 us per extra launch (start, tail, a second set of piece vectors) and ~13 us per
+// cross-stream event (measured on MI355X: 142.7 -> 171.9 us for G = 2 on the configs[3] shard with a collective that
+// costs nothing); it hides all but the last range's finish + reduce-scatter + key pass.  So it pays only when the
+// reduce-scatter is slow enough -- which depends on the links, the ranks and RCCL, not on this code: the hook is TIMED
+// once per vector length (3 calls after a warm-up, HIP events on the ctx stream), the times are averaged over the ranks
+// (one f64 all-reduce: every rank takes the same decision) and G = 2 is chosen when half of it exceeds that overhead.
+// KLR_SWEEP_RANGES=g overrides (1 = never split).
+static int sweep_ranges_auto(klr_ctx* ctx, i64 dim, int* G_out) {
+  if (ctx->sw.overlap >= 0) { *G_out = ctx->sw.overlap; return KLR_OK; }
+  if (ctx->probe_dim == dim) { *G_out = ctx->probe_G; return KLR_OK; }
+  const i64 R = ctx->nranks, slice = ceil_div(dim + IB_EXTRA, R);
+  i64* buf;
+  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)(slice * R + slice) * 8, (void**)&buf));
+  KLR_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)(slice * R + slice) * 8, ctx->stream));
+  hipEvent_t e0, e1;
+  KLR_HIP(ctx, hipEventCreate(&e0));
+  KLR_HIP(ctx, hipEventCreate(&e1));
+  int rc = 0;
+  const int iters = 3;
+  for (int i = 0; i <= iters && rc == 0; i++) {
+    if (i == 1) (void)hipEventRecord(e0, ctx->stream);
+    rc = ctx->rs_fn(ctx->coll_user, buf, buf + slice * R, slice, KLR_I64, (void*)ctx->stream);
+  }
+  (void)hipEventRecord(e1, ctx->stream);
+  hipError_t he = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "reduce-scatter hook failed while it was timed");
+  if (he != hipSuccess) return klr_fail(ctx, KLR_EHIP, "timing the reduce-scatter failed: %s", hipGetErrorString(he));
+  double t[1] = {(double)ms / iters};
+  KLR_TRY(klr_allreduce_host(ctx, t, 1, KLR_F64));
+  ctx->probe_ms = t[0] / (double)R;
+  const double overhead_ms = 0.030;                  // one extra launch + one event, measured
+  ctx->probe_G = ctx->probe_ms * 0.5 > overhead_ms ? 2 : 1;
+  ctx->probe_dim = dim;
+  *G_out = ctx->probe_G;
+  return KLR_OK;
+}
+
+// ibuf: the send vectors of all ranges (P.ioff); ranged = the sweep has NOT run yet: launch it range by range on the ctx
+// stream and let a second stream finish, reduce-scatter and key each range as soon as its launch is done.
+static int sweep_select_scatter(klr_ctx* ctx, const klr_mat* full, double scale_fx, const ScatterPlan& P, i64* ibuf, bool ranged, i64* part,
+                                const unsigned long long* rowblk, i64 nrowblk, i64 N, uint8_t* b, i64 c_prev,
                                 double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out, int* ok_out, double* loss_sum,
                                 bool* done) {
   *done = false;
-  hipStream_t st = ctx->stream;
   const i64 dim = full->dim, m = dim - 1;
-  const int R = ctx->nranks, r = ctx->rank;
-  const i64 lo = (i64)r * slice, hi = std::min<i64>(lo + slice, dim);
-  const i64 feat0 = std::max<i64>(lo, 1);                              // global column of this rank's first feature
-  const i64 m_s = std::max<i64>(0, hi - feat0);
+  const int R = ctx->nranks, r = ctx->rank, G = P.G;
+  hipStream_t stA = ctx->stream, st = stA;
+  if (ranged) {
+    if (!ctx->stream2) KLR_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    while ((int)ctx->range_ev.size() < G) { hipEvent_t ev; KLR_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence)); ctx->range_ev.push_back(ev); }   // device-side ordering only: no system-scope flush
+    st = ctx->stream2;
+  }
+  const i64 m_s = P.feat_total(r);
   const i64 Kmax = std::min<i64>(m, 2 * N);                            // candidates per rank at most
   const i64 K_s = std::min<i64>(m_s, 2 * N);
   const size_t blk = SCAT_HDR + (size_t)std::max<i64>(Kmax, 1) * sizeof(Cand);
   i64* rbuf; char *sendb, *recvb;
-  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)slice * 8 + blk * (size_t)(R + 1), (void**)&rbuf));
-  sendb = (char*)(rbuf + slice); recvb = sendb + blk;
-  if (ctx->rs_fn(ctx->coll_user, ibuf, rbuf, slice, KLR_I64, (void*)st) != 0) return klr_fail(ctx, KLR_ECOMM, "reduce-scatter hook failed");
-  KLR_HIP(ctx, hipMemsetAsync(sendb, 0, blk, st));
-  if (K_s > 0) {
-    u64* keys; u32* hist; Cand* cand;
-    KLR_TRY(sel_prepare(ctx, m_s, &keys, &hist));
-    KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&cand));
-    FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
-    hipLaunchKernelGGL(k_slice_keys, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 1024), 256))), dim3(256), 0, st, rbuf, lo, feat0,
-                       m_s, 1.0 / scale_fx, keys, hist);
-    KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_finish, (int)(2 * FAST_CAP * sizeof(Cand))));
-    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 4096), 256));
-    hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m_s, (u32)K_s, cand);
-    hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), 2 * FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K_s, (u32)std::min<i64>(N, K_s),
-                       cand, (FastState*)sendb, (Cand*)(sendb + SCAT_HDR), (const double*)nullptr, (double*)nullptr);
+  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)P.recv_total * 8 + blk * (size_t)(R + 1), (void**)&rbuf));
+  sendb = (char*)(rbuf + P.recv_total); recvb = sendb + blk;
+  u64* keys = nullptr; u32* hist = nullptr; Cand* cand = nullptr;
+  KLR_TRY(sel_prepare(ctx, std::max<i64>(m_s, 1), &keys, &hist));
+  KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&cand));
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_finish, (int)(2 * FAST_CAP * sizeof(Cand))));
+  if (ranged) {
+    // every range's launch is queued first; `range g is done` is an event the second stream waits for
+    for (int g = 0; g < G; g++) {
+      KLR_TRY(sweep_range_launch(ctx, full, g, part));
+      KLR_HIP(ctx, hipEventRecord(ctx->range_ev[(size_t)g], stA));
+    }
   }
-  hipLaunchKernelGGL(k_slice_extras, dim3(1), dim3(64), 0, st, rbuf, lo, slice, dim, (i64*)(sendb + 64), (u32)m_s, (u32)K_s);
-  KLR_HIP(ctx, hipGetLastError());
-  if (ctx->ag_fn(ctx->coll_user, sendb, recvb, (int64_t)blk, (void*)st) != 0) return klr_fail(ctx, KLR_ECOMM, "all-gather hook failed");
-  char* pin;
-  KLR_TRY(pin_get(ctx, blk * (size_t)R, (void**)&pin));
-  KLR_HIP(ctx, hipMemcpyAsync(pin, recvb, blk * (size_t)R, hipMemcpyDeviceToHost, st));
-  KLR_HIP(ctx, hipStreamSynchronize(st));
-  // ---- merge on the host (identical on every rank)
-  std::vector<Cand> all;
-  i64 tot[IB_EXTRA] = {0, 0, 0, 0, 0};
-  bool fallback = false;
-  for (int q = 0; q < R; q++) {
-    const char* bq = pin + blk * (size_t)q;
-    FastState fs; memcpy(&fs, bq, sizeof(fs));
-    i64 ex[6]; memcpy(ex, bq + 64, sizeof(ex));
-    for (int u = 0; u < IB_EXTRA; u++) tot[u] += ex[u];
-    const i64 mq = (i64)((u64)ex[5] >> 32), Kq = (i64)((u64)ex[5] & 0xFFFFFFFFull);
-    if (Kq == 0) continue;
-    if (fs.fallback) { fallback = true; break; }
-    const i64 base = std::max<i64>((i64)q * slice, 1) - 1;             // global feature index of the rank's local feature 0
-    const Cand* cq = (const Cand*)(bq + SCAT_HDR);
-    for (i64 k = 0; k < Kq; k++) { Cand c = cq[k]; c.idx = (u32)(c.idx + base); c.pad = (u32)q; all.push_back(c); }
-    (void)mq;
+  // hinted (every rank holds the same hint: it comes from the merged result of the previous sweep): candidates are
+  // gathered while the keys are formed and ranked by many workgroups; else the regular bracket + trim + sort.  A hint that
+  // turns out too high (fewer than K keys at or above it over all ranks, or none below the N-th) costs one more round of
+  // the LOCAL selection without it -- the reduced slices are still there -- and one more all-gather; only the tie case in
+  // which a top-K list cannot prove lambda goes back to the all-reduce.
+  u64 tau = (ctx->sel_hint != 0 && ctx->sel_hint_K == Kmax && ctx->sel_hint_m == m) ? ctx->sel_hint : 0ull;
+  FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+  Cand* sorted_dev = cand + GCAND_CAP;
+  KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_rank, (int)(FAST_CAP * sizeof(Cand))));
+  auto slice_keys = [&](int g, i64 koff) {
+    const i64 cnt = P.feat_cnt(r, g);
+    if (cnt > 0 && K_s > 0)
+      hipLaunchKernelGGL(k_slice_keys, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(cnt, 1024), 256))), dim3(256), 0, st,
+                         (const i64*)(rbuf + P.roff[(size_t)g]), (i64)r * P.slice[(size_t)g], P.feat_lo(r, g), cnt, 1.0 / scale_fx, keys + koff, hist, tau,
+                         cand, &ctl->cursor, (u32)koff);
+    return cnt;
+  };
+  i64 koff = 0;
+  for (int g = 0; g < G; g++) {
+    i64* send = ibuf + P.ioff[(size_t)g];
+    i64* recv = rbuf + P.roff[(size_t)g];
+    const i64 len = P.len[(size_t)g], sl = P.slice[(size_t)g];
+    if (ranged) {
+      KLR_HIP(ctx, hipStreamWaitEvent(st, ctx->range_ev[(size_t)g], 0));
+      KLR_TRY(sweep_range_finish(ctx, full, P.col0[(size_t)g], P.col1[(size_t)g], part, send, g == G - 1 ? rowblk : nullptr, nrowblk, st));
+    }
+    if (sl * R > len) KLR_HIP(ctx, hipMemsetAsync(send + len, 0, (size_t)(sl * R - len) * 8, st));
+    if (ctx->rs_fn(ctx->coll_user, send, recv, sl, KLR_I64, (void*)st) != 0) return klr_fail(ctx, KLR_ECOMM, "reduce-scatter hook failed");
+    koff += slice_keys(g, koff);
   }
   const i64 K = Kmax;
+  const bool need_w = !(N > K) && N >= 1;
   u64 vkey = 0, wkey = 0;
-  if (!fallback) {
-    std::sort(all.begin(), all.end(), [](const Cand& a, const Cand& c) { return a.key != c.key ? a.key > c.key : a.idx < c.idx; });
-    if ((i64)all.size() < K) fallback = true;                          // cannot happen (every feature is in some slice); be safe
-  }
-  if (!fallback && !(N > K) && N >= 1) {
-    vkey = all[(size_t)N - 1].key;
-    bool found = false;
-    for (const Cand& c : all) if (c.key < vkey) { wkey = c.key; found = true; break; }     // sorted: the first below v is the largest
-    // a rank whose list holds nothing below v may hide larger keys below v than the one found, unless its list is its whole slice
-    for (int q = 0; q < R && !fallback; q++) {
-      const char* bq = pin + blk * (size_t)q;
-      i64 ex[6]; memcpy(ex, bq + 64, sizeof(ex));
-      const i64 mq = (i64)((u64)ex[5] >> 32), Kq = (i64)((u64)ex[5] & 0xFFFFFFFFull);
-      if (Kq == 0 || Kq == mq) continue;
-      const Cand* cq = (const Cand*)(bq + SCAT_HDR);
-      if (cq[Kq - 1].key >= vkey) fallback = true;                     // its smallest candidate is not below v
+  std::vector<Cand> hc;
+  i64 tot[IB_EXTRA] = {0, 0, 0, 0, 0};
+  bool fallback = false;
+  char* pin;
+  KLR_TRY(pin_get(ctx, blk * (size_t)R, (void**)&pin));
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const int gl = G - 1;                                              // the five scalars ride behind the last range's columns
+    if (tau) {
+      hipLaunchKernelGGL(k_fast_rank, dim3(FAST_RANK_WGS), dim3(1024), FAST_CAP * sizeof(Cand), st, (const FastCtl*)ctl, 0u, (const Cand*)cand, sorted_dev);
+      hipLaunchKernelGGL(k_slice_report, dim3(1), dim3(1024), 0, st, ctl, tau, (u32)Kmax, (const Cand*)sorted_dev, (const i64*)(rbuf + P.roff[(size_t)gl]),
+                         (i64)r * P.slice[(size_t)gl], P.slice[(size_t)gl], P.col1[(size_t)gl] - P.col0[(size_t)gl], (u32)m_s, sendb);
+    } else {
+      KLR_HIP(ctx, hipMemsetAsync(sendb, 0, blk, st));
+      if (K_s > 0) {
+        const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m_s, 4096), 256));
+        hipLaunchKernelGGL(k_fast_compact, dim3(grid), dim3(1024), 0, st, hist, hist + FAST_BINS, ctl, keys, m_s, (u32)K_s, cand);
+        hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), 2 * FAST_CAP * sizeof(Cand), st, hist, hist + FAST_BINS, ctl, (u32)K_s, (u32)std::min<i64>(N, K_s),
+                           cand, (FastState*)sendb, (Cand*)(sendb + SCAT_HDR), (const double*)nullptr, (double*)nullptr);
+      }
+      hipLaunchKernelGGL(k_slice_extras, dim3(1), dim3(64), 0, st, rbuf + P.roff[(size_t)gl], (i64)r * P.slice[(size_t)gl], P.slice[(size_t)gl],
+                         P.col1[(size_t)gl] - P.col0[(size_t)gl], (i64*)(sendb + 64), (u32)m_s, (u32)K_s);
     }
-    if (!found) fallback = true;
+    KLR_HIP(ctx, hipGetLastError());
+    if (ctx->ag_fn(ctx->coll_user, sendb, recvb, (int64_t)blk, (void*)st) != 0) return klr_fail(ctx, KLR_ECOMM, "all-gather hook failed");
+    KLR_HIP(ctx, hipMemcpyAsync(pin, recvb, blk * (size_t)R, hipMemcpyDeviceToHost, st));
+    KLR_HIP(ctx, hipStreamSynchronize(st));
+    if (ranged && attempt == 0) KLR_HIP(ctx, hipStreamSynchronize(stA));   // (already complete: the second stream waited for its last event)
+    // ---- merge on the host (identical on every rank): the R lists are sorted by (|g| desc, column asc); the global order
+    // is a K-way merge of them -- the heads are compared, R - 1 comparisons per output, K + a few outputs
+    bool retry = false;
+    fallback = false;
+    for (int u = 0; u < IB_EXTRA; u++) tot[u] = 0;
+    std::vector<const Cand*> lst((size_t)R, nullptr);
+    std::vector<i64> len_q((size_t)R, 0), mq_q((size_t)R, 0), head((size_t)R, 0);
+    std::vector<u64> low_q((size_t)R, 0);          // != 0: the rank's list holds EVERY key of its slice at or above this one
+    for (int q = 0; q < R; q++) {
+      const char* bq = pin + blk * (size_t)q;
+      FastState fs; memcpy(&fs, bq, sizeof(fs));
+      i64 ex[7]; memcpy(ex, bq + 64, sizeof(ex));
+      for (int u = 0; u < IB_EXTRA; u++) tot[u] += ex[u];
+      mq_q[(size_t)q] = (i64)((u64)ex[5] >> 32); len_q[(size_t)q] = (i64)((u64)ex[5] & 0xFFFFFFFFull);
+      if (fs.fallback) { if (tau) retry = true; else fallback = true; break; }
+      if (ex[6] == 1) low_q[(size_t)q] = fs.lowkey;
+      if (len_q[(size_t)q] == 0) continue;
+      lst[(size_t)q] = (const Cand*)(bq + SCAT_HDR);
+    }
+    hc.clear();
+    hc.reserve((size_t)K + 8);
+    bool found_w = false;
+    vkey = 0; wkey = 0;
+    if (!fallback && !retry) {
+      // global feature index of every list head (positions map piecewise onto columns: P.feature_of)
+      auto cand_at = [&](int q, i64 pos) { Cand c = lst[(size_t)q][pos]; c.idx = (u32)P.feature_of(q, (i64)c.idx); c.pad = (u32)q; return c; };
+      std::vector<Cand> hd((size_t)R);
+      for (int q = 0; q < R; q++) if (len_q[(size_t)q] > 0) hd[(size_t)q] = cand_at(q, 0);
+      for (;;) {
+        int best = -1;
+        for (int q = 0; q < R; q++) {
+          if (head[(size_t)q] >= len_q[(size_t)q]) continue;
+          const Cand& c = hd[(size_t)q];
+          if (best < 0 || c.key > hd[(size_t)best].key || (c.key == hd[(size_t)best].key && c.idx < hd[(size_t)best].idx)) best = q;
+        }
+        if (best < 0) break;
+        const Cand bc = hd[(size_t)best];
+        if (++head[(size_t)best] < len_q[(size_t)best]) hd[(size_t)best] = cand_at(best, head[(size_t)best]);
+        if ((i64)hc.size() < K) hc.push_back(bc);
+        if ((i64)hc.size() >= std::max<i64>(N, 1) && need_w && !found_w) {
+          vkey = hc[(size_t)N - 1].key;
+          if (bc.key < vkey) { wkey = bc.key; found_w = true; }        // merged order: the first key below v is the largest one
+        }
+        if ((i64)hc.size() >= K && (!need_w || found_w)) break;
+      }
+      // what a rank did NOT list must rank behind everything that is used: a list complete down to its lowkey hides only
+      // keys below that (the K-th merged key, and w, must be at or above it); a top-K list hides keys up to its last one
+      // (which must then lie below v: w is at least as large); a list that is the whole slice hides nothing
+      bool short_of = (i64)hc.size() < K || (need_w && !found_w);
+      const u64 kth = (i64)hc.size() >= K && K > 0 ? hc[(size_t)K - 1].key : 0ull;
+      if (need_w && (i64)hc.size() >= N) vkey = hc[(size_t)N - 1].key;
+      for (int q = 0; q < R && !short_of; q++) {
+        const i64 mq = mq_q[(size_t)q], Kq = len_q[(size_t)q];
+        if (Kq == mq) continue;
+        if (low_q[(size_t)q]) { if (kth < low_q[(size_t)q] || (need_w && wkey < low_q[(size_t)q])) short_of = true; }
+        else if (Kq == 0) { if (mq > 0) short_of = true; }
+        else if (need_w && lst[(size_t)q][Kq - 1].key >= vkey) short_of = true;
+      }
+      if (short_of) { if (tau) retry = true; else fallback = true; }
+    }
+    if (!retry) break;
+    // once more without the hint: keys + histogram of every range's slice, then the regular selection
+    tau = 0ull;
+    ctx->sel_hint = 0;
+    KLR_HIP(ctx, hipMemsetAsync(ctl, 0, sizeof(FastCtl), st));         // candidates of the failed attempt
+    i64 ko = 0;
+    for (int g = 0; g < G; g++) ko += slice_keys(g, ko);
   }
   if (fallback) return KLR_OK;                                         // *done stays false: the caller takes the all-reduce path
-  std::vector<Cand> hc(all.begin(), all.begin() + (size_t)K);
   if (K > 0 && hc[(size_t)K - 1].key != 0ull) {
     ctx->sel_hint = abs_key_host(0.9 * key_to_double(hc[(size_t)K - 1].key));
     ctx->sel_hint_K = K; ctx->sel_hint_m = m;
   } else ctx->sel_hint = 0;
+  hc.resize((size_t)std::max<i64>(K, 1));
   select_finish_host(hc, K, vkey, wkey, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr);
   *loss_sum = tot[4] ? NAN : ((double)tot[2] + (double)tot[3] * (1.0 / 4398046511104.0)) * (1.0 / 1048576.0);
   *done = true;
@@ -856,22 +1062,38 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     const bool scatter = ctx->rs_fn && ctx->ag_fn && ctx->ar_fn && (ctx->nranks > 1 || rs_force) && !tr && !g_out && dim >= rs_min_dim &&
                          2 * N <= FAST_CAP && N >= 1 && ctx->sw.rs != 0 && (ctx->comm_checked || ctx->sw.rs == 1);
     if (scatter) {
-      const i64 slice = ceil_div(dim + IB_EXTRA, (i64)ctx->nranks);
+      // Strip ranges (sweep_ranges_auto: from the measured reduce-scatter time; KLR_SWEEP_RANGES overrides): the sweep runs as
+      // one launch per range and range g's sums are finished, reduce-scattered and keyed on a second stream while range
+      // g + 1 streams.
+      int G_want = 1;
+      if (full->fmt == FMT_Q64C12 || full->fmt == FMT_Q64C13) KLR_TRY(sweep_ranges_auto(ctx, dim, &G_want));
+      const Q64Ranges* qr = nullptr;
+      i64* part_r = nullptr;
+      KLR_TRY(sweep_ranges_prepare(ctx, full, G_want, &qr, &part_r));
+      const ScatterPlan P = scatter_plan(dim, ctx->nranks, qr);
       i64* ibuf = nullptr;
-      KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, nullptr, nullptr, rowblk, nrowblk, nullptr, &ibuf, slice * ctx->nranks));
+      if (qr) KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(P.send_total + dim + IB_EXTRA) * 8, (void**)&ibuf));
+      else KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, nullptr, nullptr, rowblk, nrowblk, nullptr, &ibuf, P.send_total));
       bool done = false;
       double loss_sum_s = NAN;
       restore_b(); restored = true;
-      KLR_TRY(sweep_select_scatter(ctx, full, scale_fx, ibuf, slice, N, b, c_prev, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, &loss_sum_s, &done));
+      KLR_TRY(sweep_select_scatter(ctx, full, scale_fx, P, ibuf, qr != nullptr, part_r, rowblk, nrowblk, N, b, c_prev, lambda_prev, eps_lambda,
+                                   lambda_out, c_out, ok_out, &loss_sum_s, &done));
       ctx->n_rs_sweeps++;
       if (done && full->rs_verified) {
         if (loss_out) *loss_out = full->n_total ? loss_sum_s / (double)full->n_total : 0.0;
         return KLR_OK;
       }
       if (!done) ctx->n_rs_fallbacks++;
+      // the all-reduce form on this rank's intact local sums: as ONE vector (the ranged form sums its pieces once more)
+      i64* ibc = ibuf;
+      if (qr) {
+        ibc = ibuf + P.send_total;
+        KLR_TRY(sweep_range_finish(ctx, full, 0, dim, part_r, ibc, rowblk, nrowblk, ctx->stream));
+      }
       ctx->sel_hist_zeroed = nullptr;                                // the slice selection used the same buffers: start clean
       KLR_TRY(sel_prepare(ctx, m, &keys, &hist));
-      KLR_TRY(sweep_fix_tail(ctx, full, scale_fx, ibuf, gbuf, keys, hist, nullptr));
+      KLR_TRY(sweep_fix_tail(ctx, full, scale_fx, ibc, gbuf, keys, hist, nullptr));
       hint_tau = 0;
       if (done) {
         // the FIRST reduce-scatter sweep on a matrix is repeated as an all-reduce on the intact local sums: the two forms

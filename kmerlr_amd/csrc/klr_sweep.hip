@@ -35,6 +35,7 @@ __device__ __forceinline__ double group_sum(double v) {
 // row pass: G lanes per row
 // ---------------------------------------------------------------------------------------------
 #define THETA_INLINE_MAX 128
+#define THETA_LDS_MAX 2048        // a reduced problem's theta up to this length is staged in LDS by every block (16 KiB)
 struct RowPassArgs {
   const i64* rowptr; const u32* col; const void* val; const uint8_t* labels; const uint8_t* active;
   const double* theta; i64 n; double inv_n; double cw0, cw1;
@@ -42,6 +43,7 @@ struct RowPassArgs {
   double theta0_only; int const_mode;
   double fix_scale; i64* S; unsigned long long* acc;     // ROW_SWEEP_FIX
   int theta_inline_n;                                    // > 0: theta travels in the kernel arguments (no upload)
+  int theta_lds_n;                                       // > 0: theta (device) is copied to LDS first: a.theta[col] becomes an LDS read
   double theta_inline[THETA_INLINE_MAX];
 };
 
@@ -78,13 +80,16 @@ __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i
 template <typename VT, int G, int MODE>
 __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
   __shared__ double sh[256 / 64];
-  __shared__ double sth[THETA_INLINE_MAX];
+  __shared__ double sth[THETA_LDS_MAX];
   const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   double loss_term = 0.0;
-  const bool inl = a.theta_inline_n > 0;                 // theta of a small reduced problem: kernel arguments -> LDS
-  if (inl) {
+  const bool inl = a.theta_inline_n > 0 || a.theta_lds_n > 0;   // theta of a reduced problem: kernel arguments / device -> LDS
+  if (a.theta_inline_n > 0) {
     if ((int)threadIdx.x < a.theta_inline_n) sth[threadIdx.x] = a.theta_inline[threadIdx.x];
+    __syncthreads();
+  } else if (a.theta_lds_n > 0) {
+    for (int i = threadIdx.x; i < a.theta_lds_n; i += 256) sth[i] = a.theta[i];
     __syncthreads();
   }
   if (gid < a.n) {
@@ -195,15 +200,22 @@ static void row_pass_group(int g, int mode, i64 n, hipStream_t st, const RowPass
   }
 }
 
+// lanes per row by the average row length (KLR_ROW_G overrides: A/B tooling)
+static int row_group(klr_ctx* ctx, const klr_mat* mat, bool const_mode) {
+  int g = 64;
+  if (const_mode || mat->avg_row <= 4.0) g = 1;
+  else if (mat->avg_row <= 24.0) g = 4;
+  else if (mat->avg_row <= 160.0) g = 16;
+  if (!const_mode) if (const char* e = ctx_opt(ctx, "KLR_ROW_G")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16 || v == 64) g = v; }
+  return g;
+}
+
 static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                            int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev,
                            double fix_scale = 0.0, i64* S = nullptr, unsigned long long* acc = nullptr,
                            const double* theta_host = nullptr, i64 theta_len = 0) {
   const i64 n = mat->n;
-  int g = 64;
-  if (const_mode || mat->avg_row <= 4.0) g = 1;
-  else if (mat->avg_row <= 24.0) g = 4;
-  else if (mat->avg_row <= 160.0) g = 16;
+  const int g = row_group(ctx, mat, const_mode);
   const i64 nb = std::max<i64>(1, ceil_div(n * g, 256));
   double* blk;
   KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(double), (void**)&blk));
@@ -212,10 +224,12 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
   a.theta = theta_dev; a.n = n; a.inv_n = 1.0 / (double)mat->n_total; a.cw0 = cw[0]; a.cw1 = cw[1];
   a.out0 = out0; a.out1 = out1; a.blk = blk; a.theta0_only = theta0; a.const_mode = const_mode ? 1 : 0;
   a.fix_scale = fix_scale; a.S = S; a.acc = acc;
-  a.theta_inline_n = 0;
+  a.theta_inline_n = 0; a.theta_lds_n = 0;
   if (theta_host && !const_mode && theta_len > 0 && theta_len <= THETA_INLINE_MAX) {
     a.theta_inline_n = (int)theta_len;
     memcpy(a.theta_inline, theta_host, (size_t)theta_len * sizeof(double));
+  } else if (!const_mode && theta_dev && mat->dim <= THETA_LDS_MAX && (double)mat->dim <= 2.0 * (256 / g) * std::max(1.0, mat->avg_row)) {
+    a.theta_lds_n = (int)mat->dim;                       // worth it while a block's rows use more entries than the copy moves
   }
   if (n > 0) {
     if (mat->val_f64) row_pass_group<double>(g, mode, n, ctx->stream, a);
@@ -241,10 +255,7 @@ int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_de
                         const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
                         const double* theta_host, i64 theta_len) {
   // the kernel writes 5 integer partials per block into the WS_BLK block-partial buffer
-  int g = 64;
-  if (const_mode || mat->avg_row <= 4.0) g = 1;
-  else if (mat->avg_row <= 24.0) g = 4;
-  else if (mat->avg_row <= 160.0) g = 16;
+  const int g = row_group(ctx, mat, const_mode);
   const i64 nb = std::max<i64>(1, ceil_div(mat->n * g, 256));
   unsigned long long* blk;
   KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(unsigned long long), (void**)&blk));
@@ -830,52 +841,64 @@ __global__ __launch_bounds__(1024) void k_sweep_q64(const uint4* __restrict__ en
   asm volatile("" :: "v"((u32)s_warm), "v"((u32)(s_warm >> 32)));       // keeps the warming load alive
 }
 
+static inline Q64View q64_view_of(const klr_mat* mat) {
+  Q64View v; v.nwg = mat->nwg; v.t_piece = mat->t_piece; v.t_wgpiece = mat->t_wgpiece; v.slds_rows = mat->q64_slds_rows;
+  return v;
+}
+
 template <int CB, bool NT, int A, int B, int R, int ABL = 0, bool SLDS = false>
-static int launch_sweep_q64(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+static int launch_sweep_q64(klr_ctx* ctx, const klr_mat* mat, const Q64View& v, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
   // one workgroup per CU: the request is padded past half of the CU's 160 KiB, so the dispatcher cannot put two
   // workgroups on one CU while another CU stays empty (it does: with 256 workgroups of 32 - 64 KiB on 256 CUs part of
   // them ran in pairs and finished 15 % later than the rest, tools/q64_phases.py)
-  size_t lds_bytes = (size_t)R * ((size_t)8 << CB) + (SLDS ? (size_t)mat->q64_slds_rows * 8 : 0);
-  if ((int)mat->nwg <= ctx->n_cu) lds_bytes = std::max(lds_bytes, (size_t)ctx->sw.q64_lds_kib << 10);
+  size_t lds_bytes = (size_t)R * ((size_t)8 << CB) + (SLDS ? (size_t)v.slds_rows * 8 : 0);
+  if ((int)v.nwg <= ctx->n_cu) lds_bytes = std::max(lds_bytes, (size_t)ctx->sw.q64_lds_kib << 10);
   KLR_TRY(ctx_func_lds(ctx, (const void*)k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>, 160 << 10));
-  hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>), dim3(mat->nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
-                        (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)mat->t_piece,
-                        (const uint4*)mat->t_wgpiece, S, part);
+  // the extended launch (events riding on the dispatch packet) only while profiling: it costs a completion signal per
+  // kernel, which shows as idle time before and after the dispatch
+  if (e0 || e1)
+    hipExtLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>), dim3(v.nwg), dim3(1024), (u32)lds_bytes, ctx->stream, e0, e1, 0u,
+                          (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)v.t_piece,
+                          (const uint4*)v.t_wgpiece, S, part);
+  else
+    hipLaunchKernelGGL((k_sweep_q64<CB, NT, A, B, R, ABL, SLDS>), dim3(v.nwg), dim3(1024), (u32)lds_bytes, ctx->stream,
+                       (const uint4*)mat->t_ent, (u32)((size_t)mat->total4 * 16), (const u32*)mat->t_blkrow, (const uint4*)v.t_piece,
+                       (const uint4*)v.t_wgpiece, S, part);
   return KLR_OK;
 }
 
 // pipeline depth by the number of workgroups the ingest cut the stream for (one or two per CU)
 template <int CB, bool NT, int ABL = 0>
-static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+static int launch_sweep_q64_by_grid(klr_ctx* ctx, const klr_mat* mat, const Q64View& v, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
 #ifdef KLR_ABLATIONS
   if (ABL == 0) {
     const char* e = ctx_opt(ctx, "KLR_Q64_DEPTH");                // A/B: pipeline depths
     const int dsel = e ? atoi(e) : 0;
-    if (dsel == 10) return launch_sweep_q64<CB, NT, 1, 0, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 20) return launch_sweep_q64<CB, NT, 2, 0, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 21) return launch_sweep_q64<CB, NT, 2, 1, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 30) return launch_sweep_q64<CB, NT, 3, 0, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 32) return launch_sweep_q64<CB, NT, 3, 2, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 41) return launch_sweep_q64<CB, NT, 4, 1, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 42) return launch_sweep_q64<CB, NT, 4, 2, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 31) return launch_sweep_q64<CB, NT, 3, 1, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 52) return launch_sweep_q64<CB, NT, 5, 2, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 73) return launch_sweep_q64<CB, NT, 7, 3, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 115) return launch_sweep_q64<CB, NT, 11, 5, 2, 0>(ctx, mat, S, part, e0, e1);
-    if (dsel == 71) return launch_sweep_q64<CB, NT, 7, 1, 2, 0>(ctx, mat, S, part, e0, e1);
+    if (dsel == 10) return launch_sweep_q64<CB, NT, 1, 0, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 20) return launch_sweep_q64<CB, NT, 2, 0, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 21) return launch_sweep_q64<CB, NT, 2, 1, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 30) return launch_sweep_q64<CB, NT, 3, 0, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 32) return launch_sweep_q64<CB, NT, 3, 2, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 41) return launch_sweep_q64<CB, NT, 4, 1, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 42) return launch_sweep_q64<CB, NT, 4, 2, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 31) return launch_sweep_q64<CB, NT, 3, 1, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 52) return launch_sweep_q64<CB, NT, 5, 2, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 73) return launch_sweep_q64<CB, NT, 7, 3, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 115) return launch_sweep_q64<CB, NT, 11, 5, 2, 0>(ctx, mat, v, S, part, e0, e1);
+    if (dsel == 71) return launch_sweep_q64<CB, NT, 7, 1, 2, 0>(ctx, mat, v, S, part, e0, e1);
   }
 #endif
-  if ((int)mat->nwg <= ctx->n_cu) {
+  if ((int)v.nwg <= ctx->n_cu) {
 #ifdef KLR_ABLATIONS
-    if (ctx_opt(ctx, "KLR_Q64_REGIONS") && atoi(ctx_opt(ctx, "KLR_Q64_REGIONS")) == 1) return launch_sweep_q64<CB, NT, 2, 1, 1, ABL>(ctx, mat, S, part, e0, e1);
+    if (ctx_opt(ctx, "KLR_Q64_REGIONS") && atoi(ctx_opt(ctx, "KLR_Q64_REGIONS")) == 1) return launch_sweep_q64<CB, NT, 2, 1, 1, ABL>(ctx, mat, v, S, part, e0, e1);
 #endif
-    if (mat->q64_slds_rows && ABL == 0) {                    // dense strips: the workgroup's S values in LDS
-      if (ctx->sw.q64_slds_a == 2) return launch_sweep_q64<CB, NT, 2, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
-      return launch_sweep_q64<CB, NT, 3, 0, 2, 0, true>(ctx, mat, S, part, e0, e1);
+    if (v.slds_rows && ABL == 0) {                           // dense strips: the workgroup's S values in LDS
+      if (ctx->sw.q64_slds_a == 2) return launch_sweep_q64<CB, NT, 2, 0, 2, 0, true>(ctx, mat, v, S, part, e0, e1);
+      return launch_sweep_q64<CB, NT, 3, 0, 2, 0, true>(ctx, mat, v, S, part, e0, e1);
     }
-    return launch_sweep_q64<CB, NT, 2, 1, 2, ABL>(ctx, mat, S, part, e0, e1);   // one workgroup per CU: two accumulator regions
+    return launch_sweep_q64<CB, NT, 2, 1, 2, ABL>(ctx, mat, v, S, part, e0, e1);   // one workgroup per CU: two accumulator regions
   }
-  return launch_sweep_q64<CB, NT, 1, 0, 1, ABL>(ctx, mat, S, part, e0, e1);
+  return launch_sweep_q64<CB, NT, 1, 0, 1, ABL>(ctx, mat, v, S, part, e0, e1);
 }
 
 template <int THREADS, int UNROLL, bool NT, int ABL = 0, int FMT = FMT_U32>
@@ -895,7 +918,7 @@ static int launch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64*
 #ifdef KLR_ABLATIONS
 static int g_coo_variant = -1;
 extern "C" void klr_debug_set_coo_variant(int v) { g_coo_variant = v; }
-static int dispatch_ablation(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1, bool* done) {
+static int dispatch_ablation(klr_ctx* ctx, const klr_mat* mat, const Q64View& v, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1, bool* done) {
   if (g_coo_variant < 0) { const char* e = ctx_opt(ctx, "KLR_COO_VARIANT"); g_coo_variant = e ? atoi(e) : 0; }
   *done = true;
   if (mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13) {
@@ -903,10 +926,10 @@ static int dispatch_ablation(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64
     const int abl = e ? atoi(e) : 0;
     const bool c13 = mat->fmt == FMT_Q64C13;
     switch (abl) {
-      case 1: return c13 ? launch_sweep_q64_by_grid<13, true, 1>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 1>(ctx, mat, S, part, e0, e1);
-      case 2: return c13 ? launch_sweep_q64_by_grid<13, true, 2>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 2>(ctx, mat, S, part, e0, e1);
-      case 3: return c13 ? launch_sweep_q64_by_grid<13, true, 3>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 3>(ctx, mat, S, part, e0, e1);
-      case 4: return c13 ? launch_sweep_q64_by_grid<13, true, 4>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 4>(ctx, mat, S, part, e0, e1);
+      case 1: return c13 ? launch_sweep_q64_by_grid<13, true, 1>(ctx, mat, v, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 1>(ctx, mat, v, S, part, e0, e1);
+      case 2: return c13 ? launch_sweep_q64_by_grid<13, true, 2>(ctx, mat, v, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 2>(ctx, mat, v, S, part, e0, e1);
+      case 3: return c13 ? launch_sweep_q64_by_grid<13, true, 3>(ctx, mat, v, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 3>(ctx, mat, v, S, part, e0, e1);
+      case 4: return c13 ? launch_sweep_q64_by_grid<13, true, 4>(ctx, mat, v, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true, 4>(ctx, mat, v, S, part, e0, e1);
       default: break;
     }
     *done = false;
@@ -951,9 +974,10 @@ static int dispatch_ablation(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64
 }
 #endif
 
-static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1) {
+static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i64* part, hipEvent_t e0, hipEvent_t e1, const Q64View* view = nullptr) {
+  const Q64View v = view ? *view : q64_view_of(mat);
 #ifdef KLR_ABLATIONS
-  { bool done; const int rc = dispatch_ablation(ctx, mat, S, part, e0, e1, &done); if (done) return rc; }
+  { bool done; const int rc = dispatch_ablation(ctx, mat, v, S, part, e0, e1, &done); if (done) return rc; }
 #endif
   // The stream is read with non-temporal loads whatever its size.  A stream that fits the 256 MiB Infinity Cache would
   // stay resident from sweep to sweep under plain loads (configs[2]: 45.7 us back to back against 47.7), but a plain
@@ -964,8 +988,8 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
   bool fits_mall = false;
   if (ctx->sw.stream_nt == 0) fits_mall = (size_t)mat->total4 * 16 <= ((size_t)220 << 20);
   switch (mat->fmt) {
-    case FMT_Q64C12: return fits_mall ? launch_sweep_q64_by_grid<12, false>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true>(ctx, mat, S, part, e0, e1);
-    case FMT_Q64C13: return fits_mall ? launch_sweep_q64_by_grid<13, false>(ctx, mat, S, part, e0, e1) : launch_sweep_q64_by_grid<13, true>(ctx, mat, S, part, e0, e1);
+    case FMT_Q64C12: return fits_mall ? launch_sweep_q64_by_grid<12, false>(ctx, mat, v, S, part, e0, e1) : launch_sweep_q64_by_grid<12, true>(ctx, mat, v, S, part, e0, e1);
+    case FMT_Q64C13: return fits_mall ? launch_sweep_q64_by_grid<13, false>(ctx, mat, v, S, part, e0, e1) : launch_sweep_q64_by_grid<13, true>(ctx, mat, v, S, part, e0, e1);
     case FMT_R64:
       // 32 waves/CU, ping-pong prefetch.  The prefetch loop runs a uniform, even number of trips per tile with masked
       // lanes: only worth it for long tiles (a 1M-column shard has ~2.6 trips per tile: 116 us with it, 103 us without)
@@ -988,8 +1012,10 @@ static int dispatch_sweep_coo(klr_ctx* ctx, const klr_mat* mat, const i64* S, i6
 // go in ITER / 4 passes of 1024 with nothing between them; the four-lane form spends a barrier pair and three dependent
 // round trips per 256 columns, 17 us for the 1M columns of a configs[3] shard.
 template <bool FUSE, bool FLAT = false>
+// Columns [j0, dim) are summed (a strip range of the overlapped form: its first column .. its end; otherwise 0 .. dim) and
+// the five scalars go to ibuf[dim ..]: a ranged launch is handed ibuf shifted so that its own vector starts at j0.
 __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ part, const u32* __restrict__ ctptr,
-                                                     const u32* __restrict__ ctlist, i64 dim, i64* __restrict__ ibuf,
+                                                     const u32* __restrict__ ctlist, i64 j0, i64 dim, i64* __restrict__ ibuf,
                                                      const i64* __restrict__ rowblk, i64 nrowblk, u32 CT, u32 PSTRIDE,
                                                      double inv_scale, double* __restrict__ g, u64* __restrict__ keys,
                                                      u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor,
@@ -1059,7 +1085,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
     i64 jv[2], sums[2];
 #pragma unroll
     for (int ps = 0; ps < 2; ps++) {
-      const i64 j = (i64)blockIdx.x * ITER * 256 + (i64)ps * 1024 + threadIdx.x;
+      const i64 j = j0 + (i64)blockIdx.x * ITER * 256 + (i64)ps * 1024 + threadIdx.x;
       jv[ps] = j; sums[ps] = 0;
       if ((u32)ps * 4u < ITER && j < dim) {
         const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
@@ -1077,7 +1103,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
     __syncthreads();
   } else
   for (u32 it = 0; it < ITER; it++) {
-  const i64 j = ((i64)blockIdx.x * ITER + it) * 256 + cx;
+  const i64 j = j0 + ((i64)blockIdx.x * ITER + it) * 256 + cx;
   i64 v = 0;
   if (j < dim) {
     const u32 ct = (u32)j / CT, c = (u32)j - ct * CT;
@@ -1282,14 +1308,14 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
   if (!ctx->ar_fn) {
     // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
-    if (flat) hipLaunchKernelGGL((k_finish_coo<true, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+    if (flat) hipLaunchKernelGGL((k_finish_coo<true, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
                                  nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
-    else hipLaunchKernelGGL((k_finish_coo<true, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+    else hipLaunchKernelGGL((k_finish_coo<true, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
                             nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
   } else {
-    if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+    if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
                                  nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
-    else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, dim, ibuf, (const i64*)rowblk,
+    else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
                             nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
     KLR_HIP(ctx, hipGetLastError());
     if (ibuf_out) {                                // the caller runs the collective (reduce-scatter form, klr_select.hip)
@@ -1312,6 +1338,56 @@ int sweep_fix_tail(klr_ctx* ctx, const klr_mat* mat, double scale, i64* ibuf, do
   KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
   hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, ctx->stream, ibuf, dim,
                      1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
+// ---- strip-range form (the overlapped collective of klr_select.hip) -------------------------------------------------
+// The layout (built on first use) and the buffers every range shares; G = 0: this matrix has no range form.
+int sweep_ranges_prepare(klr_ctx* ctx, const klr_mat* mat, int G_want, const Q64Ranges** qr_out, i64** part_out) {
+  *qr_out = nullptr;
+  if (!(mat->fmt == FMT_Q64C12 || mat->fmt == FMT_Q64C13) || G_want < 2) return KLR_OK;
+  KLR_TRY(q64_build_ranges(ctx, const_cast<klr_mat*>(mat), G_want));
+  if (!mat->qr) return KLR_OK;
+  const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;
+  KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(std::max(mat->npiece, mat->qr->npiece), 1) * pstride * 8, (void**)part_out));
+  *qr_out = mat->qr;
+  return KLR_OK;
+}
+
+// range g's launch of the sweep kernel on the ctx stream (S = the fixed-point weights the row pass left in WS_Z)
+int sweep_range_launch(klr_ctx* ctx, const klr_mat* mat, int g, i64* part) {
+  const Q64Range& r = mat->qr->r[(size_t)g];
+  i64* S;
+  KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(mat->n, 1) * 8, (void**)&S));
+  Q64View v; v.nwg = r.nwg; v.t_piece = mat->qr->t_piece; v.t_wgpiece = r.t_wgpiece; v.slds_rows = r.slds_rows;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof_on) {
+    KLR_HIP(ctx, hipEventCreate(&e0));
+    KLR_HIP(ctx, hipEventCreate(&e1));
+  }
+  KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1, &v));
+  if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
+// piece sums of the columns [col0, col1) -> vec[0 .. col1 - col0) (+ the five scalars behind them when rowblk is given)
+// on `st`; whole = the piece tables of the ranges (true) or of the one-launch form (false: the fallback after a sweep
+// that ran as one launch never gets here)
+int sweep_range_finish(klr_ctx* ctx, const klr_mat* mat, i64 col0, i64 col1, const i64* part, i64* vec, const unsigned long long* rowblk,
+                       i64 nrowblk, hipStream_t st) {
+  const Q64Ranges* qr = mat->qr;
+  const i64 ncol = col1 - col0;
+  const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;
+  u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, ncol / (256 * 512)));
+  if (ctx->sw.finish_iter > 0) fiter = (u32)std::max(1, std::min(8, ctx->sw.finish_iter));
+  const bool flat = qr->max_ct_pieces >= 1 && qr->max_ct_pieces <= 8 && fiter % 4 == 0 && !ctx->sw.finish_no_flat;
+  const dim3 fgrid((unsigned)ceil_div(ncol, (i64)256 * fiter) + 1);
+  if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, qr->t_ctptr, qr->t_ctlist, col0, col1, vec - col0, (const i64*)rowblk,
+                               nrowblk, mat->tile_c, pstride, 1.0, (double*)nullptr, (u64*)nullptr, (u32*)nullptr, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
+  else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, qr->t_ctptr, qr->t_ctlist, col0, col1, vec - col0, (const i64*)rowblk,
+                          nrowblk, mat->tile_c, pstride, 1.0, (double*)nullptr, (u64*)nullptr, (u32*)nullptr, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }

@@ -40,6 +40,8 @@ def main():
     case = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     shm = shared_memory.SharedMemory(name=os.environ["KLR_SHM_NAME"])
+    from multiprocessing import resource_tracker
+    resource_tracker.unregister(shm._name, "shared_memory")          # the creating test unlinks it (Python 3.10 would do it here, too)
     addr = C.addressof(C.c_char.from_buffer(shm.buf))
     ctx = K.Context(0)
     ctx.init_shm(addr, shm.size, rank, world)

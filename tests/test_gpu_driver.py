@@ -268,6 +268,12 @@ assert info["rccl_ranks"] == 1 and info["nranks"] == 1, info
 mc = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
 r1 = K.sweep_select(ctx, mc, None, None, np.zeros(1), cw, N)           # KLR_RS_FORCE: reduce-scatter + all-gather
 assert r1["lam"] == r0["lam"] and r1["loss"] == r0["loss"] and r1["c"] == r0["c"] and np.array_equal(r1["b"], r0["b"])
+for G in (1, 2, 3, 4):                                                  # strip ranges of the overlapped form, RCCL on a second stream
+    ctx.set_option("KLR_SWEEP_RANGES", G)
+    rg = K.sweep_select(ctx, mc, None, None, np.zeros(1), cw, N)
+    assert rg["lam"] == r0["lam"] and rg["loss"] == r0["loss"] and rg["c"] == r0["c"] and np.array_equal(rg["b"], r0["b"]), G
+ctx.set_option("KLR_SWEEP_RANGES", None)
+assert ctx.comm_stats()["sweeps_scatter"] >= 5
 r2 = K.sweep_select(ctx, mc, None, None, np.zeros(1), cw, N, want_g=True)   # g_out: the all-reduce form
 assert r2["lam"] == r0["lam"] and np.array_equal(r2["b"], r0["b"])
 assert ctx.allreduce_time(m + 6, 1, 3) >= 0.0

@@ -38,7 +38,10 @@ def run_ranks(case, world=2):
     finally:
         del addr
         shm.close()
-        shm.unlink()
+        try:
+            shm.unlink()
+        except FileNotFoundError:
+            pass
 
 
 def test_shm_collectives_against_numpy():

@@ -125,13 +125,15 @@ def scatter_collective(K, dist, ctx, hip, rank, world, calls):
     assert cnt["rs"] == 0 and not ctx.comm_stats()["checked"], "unchecked hooks must not carry the sweep"
     ctx.comm_selfcheck()
     assert ctx.comm_stats()["checked"] and cnt == {"rs": 1, "ag": 1}, cnt
+    ctx.set_option("KLR_SWEEP_RANGES", 1)                              # one reduce-scatter per sweep: the counts below
     i64_before = calls["i64"]
     s0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
     # the first reduce-scatter sweep on a matrix is repeated as an all-reduce and compared (one int64 all-reduce) ...
     assert cnt == {"rs": 2, "ag": 2} and calls["i64"] == i64_before + 1, (cnt, calls)
     s1 = K.sweep_select(ctx, shard, red, cols, theta, cw, N)
-    # ... later ones post no all-reduce at all
-    assert cnt == {"rs": 3, "ag": 3} and calls["i64"] == i64_before + 1, (cnt, calls)
+    # ... later ones post no all-reduce at all (a hint from the previous sweep that proves too high after the model moved
+    # costs a second local selection and a second all-gather, not a second reduction)
+    assert cnt["rs"] == 3 and cnt["ag"] in (3, 4) and calls["i64"] == i64_before + 1, (cnt, calls)
     assert u0["lam"] == s0["lam"]
     for a, s in ((a0, s0), (a1, s1)):
         np.testing.assert_array_equal(a["b"], s["b"])
@@ -146,6 +148,17 @@ def scatter_collective(K, dist, ctx, hip, rank, world, calls):
     st = K.sweep_select(ctx, shard, None, None, np.zeros(1), (1.0, 1.0), 400)
     np.testing.assert_array_equal(at["b"], st["b"])
     assert at["lam"] == st["lam"] and at["loss"] == st["loss"] and at["c"] == st["c"]
+    # strip ranges of the overlapped form (one sweep launch per range, finish + reduce-scatter of range g on a second stream
+    # while range g + 1 streams): whatever the number of ranges, the same integers are summed -- bitwise the same result
+    for G in (1, 2, 3, 5):
+        ctx.set_option("KLR_SWEEP_RANGES", G)
+        g0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
+        g1 = K.sweep_select(ctx, shard, red, cols, theta, cw, N)
+        gt = K.sweep_select(ctx, shard, None, None, np.zeros(1), (1.0, 1.0), 400)
+        for a, s_ in ((a0, g0), (a1, g1), (at, gt)):
+            np.testing.assert_array_equal(a["b"], s_["b"])
+            assert a["lam"] == s_["lam"] and a["loss"] == s_["loss"] and a["c"] == s_["c"] and a["ok"] == s_["ok"], (G, a["lam"], s_["lam"])
+    ctx.set_option("KLR_SWEEP_RANGES", None)
     st_ = ctx.comm_stats()
     assert st_["sweeps_scatter"] >= 3 and st_["sweeps_allreduce"] >= 3, st_
     if rank == 0:
