@@ -208,18 +208,27 @@ def roofline_of(lay, alg_bytes, kern_avg_ms, launches, cold_avg_ms, n_local, nnz
 
 
 def load_traffic(lay, nnz, m):
-    """HBM traffic of the sweep kernel from the committed PMC passes (profiles/): valid for this exact workload only."""
-    for name in ("r02_pmc_traffic.json", "r02_pmc_traffic_c3.json"):
+    """HBM traffic of the sweep kernel from the committed PMC passes (profiles/): valid for this exact workload AND this
+    exact kernel build only -- the file records the hash of the sweep / ingest sources it was collected with (klr_version),
+    and numbers of another build are refused (traffic null, the reason in traffic_source)."""
+    import kmerlr_amd as K
+    have = K.kernel_hash()
+    stale = None
+    for name in ("r03_pmc_traffic.json", "r03_pmc_traffic_c3.json"):
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", name)))
             w = pj["workload"]
             if (lay["tiled"] and w["nnz"] == nnz and w["features"] == m and w.get("format") == lay.get("format", w.get("format"))
                     and w.get("entry_bytes") == 3 + lay["value_bytes"]):
+                if pj.get("kernel_hash") != have:
+                    stale = "profiles/%s was collected with kernels:%s, this library is kernels:%s: not used" % (name, pj.get("kernel_hash"), have)
+                    continue
                 k = pj["kernels"][pj.get("kernel", "k_sweep_coo")]
-                return k["hbm_traffic_bytes_per_launch"], "profiles/%s (%s)" % (name, pj.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"))
+                return k["hbm_traffic_bytes_per_launch"], "profiles/%s (%s; kernels:%s, collected at commit %s)" % (
+                    name, pj.get("how", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"), pj.get("kernel_hash"), pj.get("collected_at_commit", "?"))
         except Exception:
             continue
-    return None, None
+    return None, stale
 
 
 def main(argv=None):

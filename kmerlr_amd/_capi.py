@@ -258,6 +258,16 @@ class Context:
         self.check(lib().klr_prof_evict(self._h, int(nbytes)))
 
 
+def version():
+    return lib().klr_version().decode()
+
+
+def kernel_hash():
+    """Hash of the sweep / ingest sources the loaded library was built from (klr_version: "... kernels:<hash>")."""
+    v = version()
+    return v.split("kernels:")[1] if "kernels:" in v else ""
+
+
 def rccl_unique_id():
     buf = C.create_string_buffer(128)
     rc = lib().klr_rccl_unique_id(buf)

@@ -41,9 +41,28 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def kernel_hash():
+    """Hash of the sources that decide what the roofline kernel does and reads (the sweep, the ingest that lays the stream
+    out, the shared header): klr_version() reports it, profiles/ record it, bench.py refuses PMC numbers of another build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("klr_sweep.hip", "klr_ingest.hip", "klr_internal.h"):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def _write_hash_header():
+    path = os.path.join(CSRC, "klr_kernel_hash.inc")
+    text = '#define KLR_KERNEL_HASH "%s"\n' % kernel_hash()
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    HEADERS.append(_write_hash_header()) if os.path.join(CSRC, "klr_kernel_hash.inc") not in HEADERS else _write_hash_header()
     cc = hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []

@@ -21,7 +21,8 @@ int klr_fail(klr_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" const char* klr_version(void) { return "kmerlr-hip 0.3 (gfx950)"; }
+#include "klr_kernel_hash.inc"      // written by kmerlr_amd/build.py: hash of the sweep / ingest sources of this build
+extern "C" const char* klr_version(void) { return "kmerlr-hip 0.3 (gfx950) kernels:" KLR_KERNEL_HASH; }
 
 // ---- switches: read from the environment ONCE per context, changed through klr_ctx_set_option -------------------
 extern char** environ;

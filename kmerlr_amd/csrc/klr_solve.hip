@@ -1471,7 +1471,8 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   const int gram_rows_min = ctx_opt(ctx, "KLR_GRAM_ROWS_MIN") ? atoi(ctx_opt(ctx, "KLR_GRAM_ROWS_MIN")) : 384;
   const bool gram_rows = d >= gram_rows_min && gram_many && (size_t)d * 8 <= 128 * 1024 && red->d_collen != nullptr;
   const bool gram_lds = !gram_rows && (size_t)d * d * 8 <= 128 * 1024 && gram_many;
-  const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(ctx->n_cu, ceil_div(n * 16, 1024))) : 0u;
+  const i64 gram_blocks_cap = ctx_opt(ctx, "KLR_GRAM_BLOCKS") ? std::max(1, atoi(ctx_opt(ctx, "KLR_GRAM_BLOCKS"))) : ctx->n_cu;   // A/B tooling
+  const unsigned gram_blocks = gram_lds ? (unsigned)std::max<i64>(1, std::min<i64>(gram_blocks_cap, ceil_div(n * 16, 1024))) : 0u;
   // 128 < d <= 1024 with many pairs: tile pairs privatised in LDS (k_gram_offdiag_tiled)
   const int gram_nt = (d + GT - 1) / GT, gram_npairs = gram_nt * (gram_nt + 1) / 2;
   // every row stores all d columns (dense score tables): the value array is the n x d panel -> Gram on the matrix cores

@@ -27,12 +27,12 @@ for sh in shapes:
     mats = {}
     for f in formats:
         f0, _, cutmode = f.partition("%")                                      # q64c13%snap: the old cuts
-        os.environ["KLR_Q64_CUT"] = cutmode.split(":")[0] or "comp"
-        os.environ["KLR_Q64_SNAP_TOL"] = cutmode.split(":")[1] if ":" in cutmode else "0.04"
+        os.environ["KLR_Q64_CUT"] = cutmode.split(":")[0] or "comp"; ctx.reload_env()
+        os.environ["KLR_Q64_SNAP_TOL"] = cutmode.split(":")[1] if ":" in cutmode else "0.04"; ctx.reload_env()
         base, _, bank = f0.partition("#")                                      # q64c12#0: columns left in ascending order
-        os.environ["KLR_ENTRY_FORMAT"] = base.split("@")[0]
-        os.environ["KLR_Q64_WGS"] = base.split("@")[1] if "@" in base else "1"  # q64c13@2: two workgroups per CU
-        os.environ["KLR_Q64_BANK"] = bank or "16"
+        os.environ["KLR_ENTRY_FORMAT"] = base.split("@")[0]; ctx.reload_env()
+        os.environ["KLR_Q64_WGS"] = base.split("@")[1] if "@" in base else "1"; ctx.reload_env()  # q64c13@2: two workgroups per CU
+        os.environ["KLR_Q64_BANK"] = bank or "16"; ctx.reload_env()
         mats[f] = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     del rowptr, col, val
     cw = mats[formats[0]].class_weights()

@@ -12,17 +12,17 @@ SHAPES = {"c2": (100000, 65536, 100, "q64c12"), "c3": (125000, 1048576, 500, "q6
 ctx = K.Context(0)
 for sh in (sys.argv[1:] or ["c2", "c3"]):
     n, m, N, fmt = SHAPES[sh]
-    os.environ["KLR_ENTRY_FORMAT"] = os.environ.get("AB_FMT", fmt)
+    os.environ["KLR_ENTRY_FORMAT"] = os.environ.get("AB_FMT", fmt); ctx.reload_env()
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
     mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     del rowptr, col, val
     cw = mat.class_weights()
-    os.environ["KLR_STREAM_NT"] = "1"
+    os.environ["KLR_STREAM_NT"] = "1"; ctx.reload_env()
     names = {0: "full (nt)", 1: "no write-out", 2: "no atomics", 3: "no S loads", 4: "stream only"}
     res = {a: [] for a in names}
     for r in range(5):
         for a in names:
-            os.environ["KLR_Q64_ABL"] = str(a)
+            os.environ["KLR_Q64_ABL"] = str(a); ctx.reload_env()
             ctx.prof_enable(True); ctx.prof_read(reset=True)
             for _ in range(6):
                 ctx.evict(1 << 30)

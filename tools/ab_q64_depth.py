@@ -11,11 +11,11 @@ SHAPES = {"c2": (100000, 65536, 100, "q64c12"), "c3": (125000, 1048576, 500, "q6
 ctx = K.Context(0)
 for sh in (sys.argv[1:] or ["c2", "c3"]):
     n, m, N, fmt = SHAPES[sh]
-    os.environ["KLR_ENTRY_FORMAT"] = fmt
+    os.environ["KLR_ENTRY_FORMAT"] = fmt; ctx.reload_env()
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
     mats = {}
     for w in (int(v) for v in os.environ.get("AB_WGS", "1").split(",")):
-        os.environ["KLR_Q64_WGS"] = str(w)
+        os.environ["KLR_Q64_WGS"] = str(w); ctx.reload_env()
         mats[w] = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     del rowptr, col, val
     cw = mats[1].class_weights()
@@ -23,7 +23,7 @@ for sh in (sys.argv[1:] or ["c2", "c3"]):
     res = {(c, mode): [] for c in combos for mode in ("res", "cold")}
     for r in range(int(os.environ.get("AB_ROUNDS", "4")) + 1):
         for (w, d) in combos:
-            os.environ["KLR_Q64_DEPTH"] = str(d)
+            os.environ["KLR_Q64_DEPTH"] = str(d); ctx.reload_env()
             for mode in ("res", "cold"):
                 ctx.prof_enable(True); ctx.prof_read(reset=True)
                 for _ in range(6):

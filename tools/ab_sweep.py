@@ -16,7 +16,7 @@ ctx = K.Context(0)
 rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, draws, 2 * N)
 mats = {}
 for order in ("ct", "rt"):
-    os.environ["KLR_TILE_ORDER"] = order
+    os.environ["KLR_TILE_ORDER"] = order; ctx.reload_env()
     mats[order] = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     print(order, mats[order].layout())
 full = mats["ct"]

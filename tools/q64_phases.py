@@ -15,7 +15,7 @@ ctx = K.Context(0)
 lib = _capi.lib()
 for sh in (sys.argv[1:] or ["c2"]):
     n, m, N, fmt = SHAPES[sh]
-    os.environ["KLR_ENTRY_FORMAT"] = fmt
+    os.environ["KLR_ENTRY_FORMAT"] = fmt; ctx.reload_env()
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
     mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     cw = mat.class_weights()
@@ -42,7 +42,7 @@ for sh in (sys.argv[1:] or ["c2"]):
 # are the slow workgroups the same ones from launch to launch?  (systematic: by XCD = blockIdx % 8, or by position)
 for sh in (sys.argv[1:] or ["c2"]):
     n, m, N, fmt = SHAPES[sh]
-    os.environ["KLR_ENTRY_FORMAT"] = fmt
+    os.environ["KLR_ENTRY_FORMAT"] = fmt; ctx.reload_env()
     rowptr, col, val, labels = K.synth_csr(20261004, 0, n, n, m, 993, 2 * N)
     mat = K.Matrix.from_csr(ctx, n, m + 1, rowptr, col, val, labels)
     cw = mat.class_weights()

@@ -34,7 +34,7 @@ for it in range(int(os.environ.get("ITERS", "24"))):
     idx = 1 + rng.choice(dim - 1, size=20, replace=False); theta[idx] = rng.normal(size=20) * 0.05
     gs = {}
     for fmt in ("u32", "q64c12", "q64c13"):
-        os.environ["KLR_ENTRY_FORMAT"] = fmt
+        os.environ["KLR_ENTRY_FORMAT"] = fmt; ctx.reload_env()
         m = K.Matrix.from_csr(ctx, n, dim, rowptr, col, val, labels)
         lay = m.layout()
         cw = m.class_weights()
