@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 SEED = 20261004
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+PROF_STRIDE = 4            # launches of the sweep kernel per HIP-event pair inside the timed region
 EVICT_BYTES = 1 << 30      # written + copied between the steps of the cold-stream leg (Infinity Cache: 256 MiB)
 
 
@@ -51,6 +52,9 @@ def parse(argv=None):
     ap.add_argument("--configs3", action="store_true", help="(default since round 3) kept for old command lines")
     ap.add_argument("--no-configs3", action="store_true",
                     help="skip BASELINE configs[3]'s per-GPU shard (125,000 x 1,048,576, --lambda-auto=500), which every N runs by default")
+    ap.add_argument("--transport", choices=("rccl", "shm"), default="rccl",
+                    help="collectives of an N > 1 run: RCCL over xGMI (one GPU per rank), or the library's host-staged shared-memory "
+                         "hooks with every rank on the SAME card (rehearsal of the N > 1 code path on a one-GPU box; the line says so)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous rehearsal on the CPU (gloo): no GPU work, the line says dry_run")
     return ap.parse_args(argv)
@@ -108,17 +112,42 @@ class Rank:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.shm = args.transport == "shm" and self.world > 1
+        if self.shm:
+            self.local_rank = 0                    # rehearsal: every rank on the same card
         torch.cuda.set_device(self.local_rank)
         self.comm = self.world > 1 or args.force_comm
+        self.tdev = "cpu" if self.shm else "cuda"
         if self.comm:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             import datetime
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", self.local_rank),
-                                    timeout=datetime.timedelta(seconds=300))      # a rank that never arrives fails the run, not hangs it
+            if self.shm:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank),
+                                        timeout=datetime.timedelta(seconds=300))      # a rank that never arrives fails the run, not hangs it
         self.ctx = K.Context(self.local_rank)
-        if self.comm:
+        if self.shm:
+            # one shared region for all ranks: rank 0 creates and initialises it, the name travels through the process group
+            import ctypes
+            from multiprocessing import shared_memory, resource_tracker
+            nbytes = K.lib().klr_shm_region_bytes(self.world)
+            if self.rank == 0:
+                self._shm = shared_memory.SharedMemory(create=True, size=nbytes)
+                addr = ctypes.addressof(ctypes.c_char.from_buffer(self._shm.buf))
+                assert K.lib().klr_shm_region_init(ctypes.c_void_p(addr), self._shm.size, self.world) == 0
+            names = [self._shm.name if self.rank == 0 else None]
+            dist.broadcast_object_list(names, src=0)
+            if self.rank != 0:
+                self._shm = shared_memory.SharedMemory(name=names[0])
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+                addr = ctypes.addressof(ctypes.c_char.from_buffer(self._shm.buf))
+            self._shm_addr = addr
+            self.ctx.init_shm(addr, self._shm.size, self.rank, self.world)
+            assert self.ctx.comm_stats()["checked"]
+        elif self.comm:
             # RCCL communicator owned by the library: one collective per sweep on the library's stream.  klr_ctx_init_rccl
             # ends with the collective self-check ([1, rank] as int64 must come back as [N, N(N-1)/2]; f64, reduce-scatter
             # and all-gather alike) and raises if the communicator does not reduce over the ranks it claims
@@ -136,17 +165,20 @@ class Rank:
 
     def max_over_ranks(self, dt):
         if self.world > 1:
-            t = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.tdev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
     def timed_steps(self, step, warmup, steps):
         """W untimed steps, then exactly K steps between two fences; HIP-event time of the sweep kernel inside."""
+        self.ctx.prof_reserve(4 * steps + 16)      # the timed steps take their HIP events from the context's pool: none is created
         for _ in range(warmup):
             step()
         self.fence()
-        self.ctx.prof_enable(True)
+        # inside the timed region every PROF_STRIDE-th launch of the sweep kernel carries HIP events (a timed dispatch costs a
+        # completion signal, ~8 us of a 75 us step); the cold and in-estimate legs time every launch
+        self.ctx.prof_enable(PROF_STRIDE)
         self.ctx.prof_read(reset=True)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -173,6 +205,16 @@ class Rank:
     def close(self):
         self.ctx.close()
         if self.comm:
+            self.dist.barrier()
+        if self.shm:
+            del self._shm_addr
+            try:
+                self._shm.close()
+                if self.rank == 0:
+                    self._shm.unlink()
+            except Exception:
+                pass
+        if self.comm:
             self.dist.destroy_process_group()
 
 
@@ -194,6 +236,7 @@ def roofline_of(lay, alg_bytes, kern_avg_ms, launches, cold_avg_ms, n_local, nnz
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
          "kernel": lay["kernel"], "layout": lay, "kernel_avg_ms": round(kern_avg_ms, 4), "launches": launches,
+         "launches_note": "launches timed with HIP events inside the timed region: every %d-th of its steps" % PROF_STRIDE,
          "algorithmic_bytes_per_launch": alg_bytes,
          "resident": {"kernel_avg_ms": round(kern_avg_ms, 4), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                       "note": "the timed region: back-to-back steps, a stream that fits the 256 MiB Infinity Cache stays in it"},
@@ -332,10 +375,12 @@ def main(argv=None):
             "config": {"workload": "synthetic %d seqs/GPU x %d 8-mer columns, %d draws/row, --lambda-auto=%d "
                                    "(BASELINE configs[2])" % (n_local, m, draws, N),
                        "rows_per_gpu": n_local, "rows_total": n_total, "features": m, "nnz_per_gpu": nnz,
-                       "selected": int(len(cols) - 1), "parallelism": "row-shards x%d, 1 RCCL all-reduce of m+6 int64 per sweep" % world},
+                       "selected": int(len(cols) - 1), "parallelism": "row-shards x%d, 1 collective of m+6 int64 per sweep" % world,
+                       "transport": ("shm: all ranks on ONE card, host-staged collectives -- a rehearsal of the N > 1 code path, not a scaling figure"
+                                     if R.shm else "rccl" if R.comm else "none")},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
-            "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
+            "comm": {"n_ranks_seen": (info["nranks"] if R.shm else info["rccl_ranks"]) if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
                      "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N),
                      "selfcheck": "passed" if R.comm else "no communicator", "stats": stats_c2, "probe": ctx.comm_probe()},
             "cd_sweeps_per_s": cd["sweeps_per_s"], "cd_sweeps": cd,
@@ -417,7 +462,7 @@ def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, w
             "value": float(n_total) * float(m) / (dt / steps), "unit": "samples*features/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "scaling": "weak",
             "roofline": roofline,
-            "comm": {"n_ranks_seen": info["rccl_ranks"] if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
+            "comm": {"n_ranks_seen": (info["nranks"] if R.shm else info["rccl_ranks"]) if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
                      "allreduce_elements": m + 6 if R.comm else 0,
                      "sweep_collective": sweep_collective(world, m, N), "stats": stats, "probe": ctx.comm_probe()},
             "estimate_lambda_auto": est,

@@ -295,7 +295,11 @@ int  klr_synth_csr(uint64_t seed, int64_t row0, int64_t n_local, int64_t n_total
 /* ---- measurement -------------------------------------------------------------------------- */
 /* HIP-event timing of the dominant kernel (the full-width column sweep) on the ctx stream:
  * accumulated since the last reset.  Events are recorded only while enabled. */
+/* on = 0 off; 1 every launch of the sweep kernel is timed; k > 1: every k-th one (the events ride on the dispatch packet, but
+ * each timed launch still costs a completion signal: a sampled timed region stays close to an untimed one) */
 int  klr_prof_enable(klr_ctx* ctx, int on);
+/* creates timing events ahead of a timed region (they are pooled and reused: klr_prof_read with reset hands them back) */
+int  klr_prof_reserve(klr_ctx* ctx, int64_t events);
 int  klr_prof_read(klr_ctx* ctx, int64_t* launches, double* total_ms, int reset);
 /* while enabled, klr_cd_solve also records HIP events around the coordinate-descent sweep kernels of every batch
  * (soft-threshold sweeps only: no IRLS set-up, loss pass or host turnaround): sweeps executed, batches, their time. */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "klr_cd_solve": (_int, [_vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _int, _i64, _vp, _i64, C.POINTER(_i64)]),
     "klr_synth_csr": (_int, [C.c_uint64, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _int]),
     "klr_prof_enable": (_int, [_vp, _int]),
+    "klr_prof_reserve": (_int, [_vp, _i64]),
     "klr_prof_read": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl), _int]),
     "klr_prof_read_cd": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_dbl), _int]),
     "klr_prof_evict": (_int, [_vp, _i64]),
@@ -239,6 +240,9 @@ class Context:
         ms = C.c_double(0.0)
         self.check(lib().klr_allreduce_time(self._h, int(count), int(dtype), int(iters), C.byref(ms)))
         return ms.value
+
+    def prof_reserve(self, events):
+        self.check(lib().klr_prof_reserve(self._h, int(events)))
 
     def prof_enable(self, on=True):
         self.check(lib().klr_prof_enable(self._h, int(on)))

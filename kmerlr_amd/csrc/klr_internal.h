@@ -69,10 +69,12 @@ struct klr_ctx {
   size_t       pin_cap = 0;
   // profiling of the column sweep
   bool         prof_on = false;
+  int          prof_stride = 1, prof_count = 0;   // time every prof_stride-th launch of the sweep kernel (klr_prof_enable(ctx, stride))
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   // ... and of the reduced-problem CD sweep kernels: (start, stop, sweeps executed) per batch of klr_cd_solve
   struct CdProf { hipEvent_t e0, e1; int sweeps; };
   std::vector<CdProf> prof_cd;
+  std::vector<hipEvent_t> prof_free;         // timing events handed back by klr_prof_read(reset): a timed step creates none
   void*        evict_buf = nullptr;          // scratch of klr_prof_evict
   size_t       evict_cap = 0;
   int          n_cu = 256;
@@ -110,6 +112,8 @@ struct klr_ctx {
   i64 probe_dim = 0; int probe_G = 1; double probe_ms = 0.0;
 };
 
+bool prof_take(klr_ctx* ctx);                                   // profiling on and this launch of the sweep is one to be timed
+int  prof_event_get(klr_ctx* ctx, hipEvent_t* ev);              // a timing event from the context's pool
 void shm_release(klr_ctx* ctx);                                  // klr_shm.hip
 // value of switch `name` ("KLR_...") on this context, nullptr when unset
 const char* ctx_opt(const klr_ctx* ctx, const char* name);

@@ -1648,7 +1648,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       }
       hipEvent_t pe0 = nullptr, pe1 = nullptr;           // klr_prof_*: device time of the sweep kernels of this batch
       if (ctx->prof_on) {
-        KLR_HIP(ctx, hipEventCreate(&pe0)); KLR_HIP(ctx, hipEventCreate(&pe1));
+        KLR_TRY(prof_event_get(ctx, &pe0)); KLR_TRY(prof_event_get(ctx, &pe1));
         KLR_HIP(ctx, hipEventRecord(pe0, st));
       }
       if (d <= 128) {

@@ -1294,12 +1294,13 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;      // width of a piece vector
   KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * pstride * 8, (void**)&part));
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->prof_on) {
-    KLR_HIP(ctx, hipEventCreate(&e0));
-    KLR_HIP(ctx, hipEventCreate(&e1));
+  const bool timed = prof_take(ctx);
+  if (timed) {
+    KLR_TRY(prof_event_get(ctx, &e0));
+    KLR_TRY(prof_event_get(ctx, &e1));
   }
   KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1));
-  if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
+  if (timed) ctx->prof_ev.emplace_back(e0, e1);
   // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
   u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
   if (ctx->sw.finish_iter > 0) fiter = (u32)std::max(1, std::min(8, ctx->sw.finish_iter));          // A/B tooling
@@ -1362,12 +1363,13 @@ int sweep_range_launch(klr_ctx* ctx, const klr_mat* mat, int g, i64* part) {
   KLR_TRY(ws_get(ctx, WS_Z, (size_t)std::max<i64>(mat->n, 1) * 8, (void**)&S));
   Q64View v; v.nwg = r.nwg; v.t_piece = mat->qr->t_piece; v.t_wgpiece = r.t_wgpiece; v.slds_rows = r.slds_rows;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->prof_on) {
-    KLR_HIP(ctx, hipEventCreate(&e0));
-    KLR_HIP(ctx, hipEventCreate(&e1));
+  const bool timed = prof_take(ctx);
+  if (timed) {
+    KLR_TRY(prof_event_get(ctx, &e0));
+    KLR_TRY(prof_event_get(ctx, &e1));
   }
   KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1, &v));
-  if (ctx->prof_on) ctx->prof_ev.emplace_back(e0, e1);
+  if (timed) ctx->prof_ev.emplace_back(e0, e1);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }
@@ -1425,8 +1427,8 @@ int launch_xt_s(klr_ctx* ctx, const klr_mat* mat, const double* s_dev, double* g
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = ctx->prof_on && !square;
     if (prof) {
-      KLR_HIP(ctx, hipEventCreate(&e0));
-      KLR_HIP(ctx, hipEventCreate(&e1));
+      KLR_TRY(prof_event_get(ctx, &e0));
+      KLR_TRY(prof_event_get(ctx, &e1));
       KLR_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
     if (mat->val_f64) { if (square) xt_s_group<double, true>(g, grid, ctx->stream, mat, s_dev, part); else xt_s_group<double, false>(g, grid, ctx->stream, mat, s_dev, part); }
