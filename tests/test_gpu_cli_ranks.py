@@ -83,6 +83,23 @@ def test_two_ranks_scores_table_and_cv(tmp_path):
         assert os.path.exists(tmp_path / ("cv2_cv%d.trace" % f))      # learn_parameters: one _cv<f> file set per fold
 
 
+def test_two_ranks_ensemble_and_warm_start(tmp_path):
+    """--ensemble-size (members = row masks by global row id: every rank masks its own rows) and the warm start from a model
+    file on two ranks against one."""
+    ens = ["learn", "--lambda-auto=4", "--ensemble-size=3", "--ensemble-summary=mean", "4", "4", FG, BG]
+    run(ens + ["e1"], tmp_path)
+    run(["--ranks=2", "--transport=shm"] + ens + ["e2"], tmp_path)
+    m1, m2 = json.load(open(tmp_path / "e1.json")), json.load(open(tmp_path / "e2.json"))
+    assert m1["Name"] == m2["Name"] == "kmerLr [mean]" and m1["Parameters"] == m2["Parameters"]
+    assert len(m1["Distributions"]) == len(m2["Distributions"]) == 4                  # three members + the transform
+    for a, b in zip(m1["Distributions"][:3], m2["Distributions"][:3]):
+        np.testing.assert_allclose(a["Parameters"], b["Parameters"], rtol=1e-8, atol=1e-13)
+    run(["learn", "--lambda-auto=5", "--revcomp", "4", "4", FG, BG, "five"], tmp_path)
+    run(["learn", "--lambda-auto=9", "five.json", FG, BG, "w1"], tmp_path)
+    run(["--ranks=2", "--transport=shm", "learn", "--lambda-auto=9", "five.json", FG, BG, "w2"], tmp_path)
+    same_model(tmp_path / "w1.json", tmp_path / "w2.json", rtol=1e-8)
+
+
 def write_fasta(path, seqs):
     with open(path, "w") as f:
         for i, s in enumerate(seqs):
