@@ -69,10 +69,19 @@ typedef struct klr_config {
   int64_t copreselection;    /* --co-preselection, 0 = none                          */
   double  validation_size;   /* --validation-size: fraction of the rows set aside to choose among the lambda_auto
                               * classifiers (getCvGroups, kmerLr_crossvalidation.go:56-90); 0 = none        */
+  int     ensemble_size;     /* --ensemble-size inside klr_estimator_crossvalidate (0 / 1: none): every fold trains
+                              * ensemble_size members, member k on the fold's training rows whose group (getCvGroups over
+                              * the training rows, kmerLr_estimator_ensemble.go:75) is not k                */
+  int     ensemble_summary;  /* --ensemble-summary of their predictions and losses: KLR_SUMMARY_*          */
   int     data_transform;    /* --data-transform as KLR_TR_* (0 none): only read where the driver has to FIT the
                               * transform itself, i.e. per fold when a validation set is split off
                               * (kmerLr_estimator_ensemble.go:116-117 fits on train + test rows)            */
 } klr_config;
+
+#define KLR_SUMMARY_MEAN    0   /* {Kmer,Scores}LrEnsemble.Summarize, kmerLr_classifier_ensemble.go:64-104 */
+#define KLR_SUMMARY_PRODUCT 1
+#define KLR_SUMMARY_MIN     2
+#define KLR_SUMMARY_MAX     3
 
 void klr_config_default(klr_config* cfg);
 
@@ -131,6 +140,10 @@ void klr_cv_groups_val(int64_t n_all, int k_fold, double val_ratio, int64_t seed
  * kmerLr_learn.go:89-108 with --validation-size), estimates every lambda_auto on the training rows, keeps for each
  * fold ONLY the classifier with the lowest loss on the fold's validation rows (kmerLr_estimator_ensemble.go:119-135)
  * and fills row 0 of predictions / loss_train / loss_test alone; klr_estimator_n_classifiers is then k_fold (or 1).
+ * With cfg.ensemble_size = E > 1 every fold trains E members (estimate_ensemble inside the fold,
+ * kmerLr_estimator_ensemble.go:74-96,118); predictions and losses are the cfg.ensemble_summary of the members' values
+ * (KmerLrEnsemble.Predict / .Loss); the fold's estimator (klr_estimator_fold) then holds the members' classifiers
+ * member-major (member k, kept lambda_auto j at k * n_kept + j: klr_estimator_save_ensemble's layout).
  * Estimator of fold f after a cross-validation (its trace, path and classifiers: learn_parameters writes one
  * `_cv<f+1>` file set per fold, kmerLr_learn.go:45-66); owned by `est`, valid until its next call. */
 klr_estimator* klr_estimator_fold(const klr_estimator* est, int fold);

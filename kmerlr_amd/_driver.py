@@ -22,7 +22,7 @@ class Config(C.Structure):
                 ("epsilon_loss", C.c_double), ("eval_loss", C.c_int), ("balance", C.c_int), ("penalty_free", C.c_int),
                 ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double),
                 ("cooccurrence", C.c_int), ("copreselection", C.c_int64), ("validation_size", C.c_double),
-                ("data_transform", C.c_int)]
+                ("ensemble_size", C.c_int), ("ensemble_summary", C.c_int), ("data_transform", C.c_int)]
 
 
 def bind_driver(L):
@@ -141,6 +141,16 @@ class Estimator:
                                                   None if scale is None else scale.ctypes.data,
                                                   None if offset is None else offset.ctypes.data))
         return self.classifiers()
+
+    def fold(self, f):
+        """Estimator of fold f of the last cross-validation (owned by this one)."""
+        h = self.L.klr_estimator_fold(self._h, f)
+        if not h:
+            return None
+        fe = Estimator.__new__(Estimator)
+        fe.L, fe.backend, fe.cfg, fe._h = self.L, self.backend, self.cfg, C.c_void_p(h)
+        fe.close = lambda: None
+        return fe
 
     def crossvalidate(self, mat_handle, n_local, k_fold, lambda_auto, seed=1, row0=0, n_all=0, scale=None, offset=None):
         """Returns dict(predictions[nla, n_local], groups[n_local], loss_train[nla, k], loss_test[nla, k])."""

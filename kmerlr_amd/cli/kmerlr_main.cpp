@@ -661,8 +661,9 @@ int main(int argc, char** argv) {
     if (ensemble < 1) die("invalid --ensemble-size");
     if (summary != "mean" && summary != "product" && summary != "min" && summary != "max" && !summary.empty()) die("invalid --ensemble-summary");
     const bool cv_path = kfold > 1 || cfg.validation_size > 0.0;
-    if (ensemble > 1 && cv_path) die("--ensemble-size together with --k-fold-cv / --validation-size is not part of this build");
-    if (ensemble > 1 && !std::isnan(cfg.lambda)) die("--ensemble-size needs --lambda-auto in this build");
+    if (ensemble > 1 && !std::isnan(cfg.lambda) && !cv_path) die("--ensemble-size needs --lambda-auto in this build");
+    cfg.ensemble_size = ensemble;                                        // read by the cross-validation (members inside every fold)
+    cfg.ensemble_summary = summary == "product" ? KLR_SUMMARY_PRODUCT : summary == "min" ? KLR_SUMMARY_MIN : summary == "max" ? KLR_SUMMARY_MAX : KLR_SUMMARY_MEAN;
     cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;
     cfg.copreselection = opt_int(o, "co-preselection", "0");
     if (cfg.copreselection != 0 && !cfg.cooccurrence) die("--co-preselection needs --co-occurrence");
@@ -845,7 +846,12 @@ int main(int argc, char** argv) {
         for (int64_t j = 0; j < ncol && writer; j++) {
           const std::string mfn = ncol == 1 ? stem + ".json" : stem + "_" + std::to_string((long long)la[(size_t)j]) + ".json";
           say(1, "Exporting model to `%s'... ", mfn.c_str());
-          if (save_model(est, f * ncol + j, mfn.c_str(), names) != KLR_OK) die("failed");
+          if (ensemble > 1) {
+            // the fold's estimator holds its members' classifiers member-major ({Kmer,Scores}LrEnsemble of the fold)
+            if (cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
+            if (!fe || klr_estimator_save_ensemble(fe, j, ensemble, ncol, mfn.c_str(), scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
+                                                   summary.c_str()) != KLR_OK) die("failed");
+          } else if (save_model(est, f * ncol + j, mfn.c_str(), names) != KLR_OK) die("failed");
           say(1, "done\n");
         }
       }

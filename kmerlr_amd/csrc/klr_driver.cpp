@@ -429,6 +429,19 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
     if (e->be.loss(e->be.ctx, red, theta.data(), cwl, e->cfg.lambda, out) != KLR_OK) return be_fail(e, KLR_EHIP, "loss");
     return KLR_OK;
   };
+  const int E = std::max(1, e->cfg.ensemble_size);
+  // {Kmer,Scores}LrEnsemble.Summarize (kmerLr_classifier_ensemble.go:64-104)
+  auto summarize = [&](const std::vector<double>& x) -> double {
+    if (x.empty()) return NAN;
+    if (x.size() == 1 && E == 1) return x[0];
+    double r;
+    switch (e->cfg.ensemble_summary) {
+      case KLR_SUMMARY_PRODUCT: r = 1.0; for (double v : x) r *= v; return r;
+      case KLR_SUMMARY_MIN: r = x[0]; for (double v : x) if (r > v) r = v; return r;
+      case KLR_SUMMARY_MAX: r = x[0]; for (double v : x) if (r < v) r = v; return r;
+      default: r = 0.0; for (double v : x) r += v; return r / (double)x.size();
+    }
+  };
   for (int f = 0; f < nfold && rc == KLR_OK; f++) {
     const int32_t ff = f;             // without folds every group id is -1: no row is a test row (crossvalidation :183-186)
     // the three row sets of fold f over the WHOLE data set (filterCvGroup :96-120): test, validation, training
@@ -447,64 +460,118 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       if (e->be.transform_fit(e->be.ctx, data, e->cfg.data_transform, fsc.data(), fof.data(), &has_off) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "transform_fit"); break; }
       sc = fsc.data(); of = has_off ? fof.data() : nullptr;
     }
-    for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i);
-    if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_train) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
-    // a fresh estimator per fold (learn_parameters, kmerLr_learn.go:37-38)
+    // the fold's estimator (learn_parameters, kmerLr_learn.go:37-38): estimates itself without an ensemble, else holds
+    // the members (NewKmerLrEnsembleEstimator: ensemble_size estimators that start from the same model)
     klr_estimator* fe = fresh_like(e);
     if (!fe) { rc = fail(e, KLR_EINVAL, "cannot create fold estimator"); break; }
     e->folds.push_back(fe);
-    rc = klr_estimator_estimate(fe, data, lambda_auto, nla, sc, of);
-    if (rc != KLR_OK) { e->err = fe->err; break; }
-    for (auto& r : fe->trace) e->trace.push_back(r);
-    // reduced data of every classifier (SelectData); created under the training mask, which they inherit
-    std::vector<klr_mat*> reds((size_t)fe->out.size(), nullptr);
-    for (size_t j = 0; j < fe->out.size() && rc == KLR_OK; j++) {
-      const Classifier& c = fe->out[j];
-      if (e->be.select_columns(e->be.ctx, data, c.cols.data(), (int64_t)c.cols.size(), c.scale.empty() ? nullptr : c.scale.data(),
-                               c.offset.empty() ? nullptr : c.offset.data(), &reds[j]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "select_columns");
+    // member groups (estimate_ensemble :75): getCvGroups over the TRAINING rows in data order; member k trains on the
+    // training rows whose group is not k.  A local row's position among all training rows comes from the global arrays.
+    std::vector<int32_t> wgrp;
+    std::vector<int64_t> tpos;
+    if (E > 1) {
+      if (n_train < E) { rc = fail(e, KLR_EINVAL, "not enough training samples (%lld) for an ensemble of %d", (long long)n_train, E); break; }
+      wgrp.resize((size_t)n_train);
+      klr_cv_groups(n_train, E, seed, 0, n_train, wgrp.data());
+      tpos.assign((size_t)std::max<int64_t>(n, 1), -1);
+      int64_t cnt = 0;
+      for (int64_t gi = 0; gi < row0 + n; gi++) {
+        const bool tr = all[(size_t)gi] != ff && !(val && vall[(size_t)gi]);
+        if (gi >= row0 && tr) tpos[(size_t)(gi - row0)] = cnt;
+        if (tr) cnt++;
+      }
     }
-    size_t j_first = 0, j_end = fe->out.size();
+    std::vector<klr_estimator*> members;
+    for (int k = 0; k < E && rc == KLR_OK; k++) {
+      int64_t n_k = n_train;
+      if (E > 1) { n_k = 0; for (int32_t g : wgrp) if (g != k) n_k++; }
+      for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i) && (E == 1 || wgrp[(size_t)tpos[(size_t)i]] != k);
+      if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_k) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+      klr_estimator* me = fe;
+      if (E > 1) {
+        me = fresh_like(e);
+        if (!me) { rc = fail(e, KLR_EINVAL, "cannot create member estimator"); break; }
+        fe->folds.push_back(me);
+      }
+      members.push_back(me);
+      rc = klr_estimator_estimate(me, data, lambda_auto, nla, sc, of);
+      if (rc != KLR_OK) { e->err = me->err; break; }
+      for (auto& r : me->trace) { e->trace.push_back(r); if (E > 1) fe->trace.push_back(r); }
+    }
+    if (rc != KLR_OK) break;
+    const size_t ncls = members[0]->out.size();                        // lambda_auto values (1 with a fixed lambda)
+    // reduced data of member k's classifier j (SelectData)
+    std::vector<klr_mat*> reds((size_t)E * ncls, nullptr);
+    for (int k = 0; k < E && rc == KLR_OK; k++)
+      for (size_t j = 0; j < ncls && rc == KLR_OK; j++) {
+        const Classifier& c = members[(size_t)k]->out[j];
+        if (e->be.select_columns(e->be.ctx, data, c.cols.data(), (int64_t)c.cols.size(), c.scale.empty() ? nullptr : c.scale.data(),
+                                 c.offset.empty() ? nullptr : c.offset.data(), &reds[(size_t)k * ncls + j]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "select_columns");
+      }
+    // the ensemble's loss on a row set: the summary of its members' losses (KmerLrEnsemble.Loss :108-123)
+    auto ens_loss = [&](size_t j, const std::vector<uint8_t>& rows, int64_t n_rows, double* out) -> int {
+      std::vector<double> lv((size_t)E, 0.0);
+      for (int k = 0; k < E; k++) {
+        const int r_ = set_loss(reds[(size_t)k * ncls + j], rows, n_rows, members[(size_t)k]->out[j].theta, &lv[(size_t)k]);
+        if (r_ != KLR_OK) return r_;
+      }
+      *out = summarize(lv);
+      return KLR_OK;
+    };
+    size_t j_first = 0, j_end = ncls;
     if (rc == KLR_OK && val) {
       // "if validation data is available, select best classifier" (kmerLr_estimator_ensemble.go:119-135)
       size_t best = 0; double vbest = INFINITY;
       for (int64_t i = 0; i < n; i++) mask[(size_t)i] = is_val(i);
-      for (size_t j = 0; j < fe->out.size() && rc == KLR_OK; j++) {
+      for (size_t j = 0; j < ncls && rc == KLR_OK; j++) {
         double v = 0.0;
-        if (n_val > 0) rc = set_loss(reds[j], mask, n_val, fe->out[j].theta, &v);
+        if (n_val > 0) rc = ens_loss(j, mask, n_val, &v);
         if (rc != KLR_OK) break;
         if (v < vbest) { vbest = v; best = j; }
         say(e, 1, "> Classifier %zu has loss %g...\n", j, v);
       }
       say(e, 1, "> Selecting classifier %zu\n", best);
       j_first = best; j_end = best + 1;
-      if (rc == KLR_OK) { Classifier keep = fe->out[best]; fe->out.assign(1, keep); }
     }
+    std::vector<double> lpk((size_t)E * (size_t)std::max<int64_t>(n, 1));
     for (size_t j = j_first; j < j_end && rc == KLR_OK; j++) {
       const size_t jo = val ? 0 : j;                                   // output row
-      const Classifier& c = fe->out[jo];
-      klr_mat* red = reds[j];
       // loss_train on the training rows (classifier.Loss, kmerLr_estimator_ensemble.go:143-145)
       for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i);
-      rc = set_loss(red, mask, n_train, c.theta, &loss_train[jo * nfold + f]);
-      // predictions of the test rows
+      rc = ens_loss(j, mask, n_train, &loss_train[jo * nfold + f]);
+      // predictions of the test rows: the summary of the members' log pdf per row (KmerLrEnsemble.Predict :124-137)
       if (rc == KLR_OK && n_test > 0) {
-        if (e->be.log_pdf(e->be.ctx, red, c.theta.data(), lp.data()) != KLR_OK) rc = be_fail(e, KLR_EHIP, "log_pdf");
-        if (rc == KLR_OK) for (int64_t i = 0; i < n; i++) if (is_test(i)) predictions[jo * n + i] = lp[(size_t)i];
+        for (int k = 0; k < E && rc == KLR_OK; k++)
+          if (e->be.log_pdf(e->be.ctx, reds[(size_t)k * ncls + j], members[(size_t)k]->out[j].theta.data(), lpk.data() + (size_t)k * (size_t)n) != KLR_OK)
+            rc = be_fail(e, KLR_EHIP, "log_pdf");
+        std::vector<double> t((size_t)E);
+        if (rc == KLR_OK) for (int64_t i = 0; i < n; i++) if (is_test(i)) {
+          for (int k = 0; k < E; k++) t[(size_t)k] = lpk[(size_t)k * (size_t)n + (size_t)i];
+          predictions[jo * n + i] = summarize(t);
+        }
       }
       // loss_test on the test rows (no rows: 0, kmerLr_logistic_regression.go:251-253)
       if (rc == KLR_OK) {
         loss_test[jo * nfold + f] = 0.0;
         if (n_test > 0) {
           for (int64_t i = 0; i < n; i++) mask[(size_t)i] = is_test(i);
-          rc = set_loss(red, mask, n_test, c.theta, &loss_test[jo * nfold + f]);
+          rc = ens_loss(j, mask, n_test, &loss_test[jo * nfold + f]);
         }
       }
-      all_cls.push_back(c);
     }
     for (klr_mat* r : reds) if (r) e->be.mat_destroy(r);
+    if (rc != KLR_OK) break;
+    // what the fold keeps: member-major, kept classifier jo of member k at k * n_kept + jo
+    {
+      std::vector<Classifier> kept;
+      for (int k = 0; k < E; k++) for (size_t j = j_first; j < j_end; j++) kept.push_back(members[(size_t)k]->out[j]);
+      fe->out = kept;
+      for (const Classifier& c : kept) all_cls.push_back(c);
+    }
   }
   e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
-  if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j (f alone with a validation set)
+  if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j (f alone with a validation
+                                                 // set); with an ensemble the folds' member-major lists one after the other
   return rc;
 }
 

@@ -398,3 +398,47 @@ def test_two_estimators_in_two_threads():
             np.testing.assert_array_equal(a["cols"], b["cols"]); np.testing.assert_array_equal(a["theta"], b["theta"])
     for h in hs:
         OD.free_matrix(h)
+
+
+@pytest.mark.parametrize("summary", [0, 1])          # KLR_SUMMARY_MEAN, KLR_SUMMARY_PRODUCT
+def test_crossvalidation_with_ensembles(summary):
+    """estimate_ensemble inside every fold (kmerLr_estimator_ensemble.go:74-96,118): member k of a fold trains on the fold's
+    training rows whose group -- getCvGroups over the TRAINING rows, in data order -- is not k; the fold's predictions and
+    losses are the summary of its members' values (KmerLrEnsemble.Predict / .Loss)."""
+    x, labels = O.synth_csr(77, 0, 210, 210, 96, 50, 8)
+    h = OD.matrix(x, labels)
+    L = OD.lib()
+    k_fold, E, seed = 3, 2, 5
+    est = OD.estimator(ensemble_size=E, ensemble_summary=summary)
+    r = est.crossvalidate(h, x.n, k_fold, [3, 6], seed=seed)
+    g = r["groups"]
+    assert len(r["classifiers"]) == k_fold * E * 2
+    comb = (lambda v: float(np.mean(v))) if summary == 0 else (lambda v: float(np.prod(v)))
+    for f in range(k_fold):
+        tr = np.nonzero(g != f)[0]; te = np.nonzero(g == f)[0]
+        wg = np.zeros(len(tr), dtype=np.int32)
+        L.klr_cv_groups(len(tr), E, seed, 0, len(tr), wg.ctypes.data)
+        fe = est.fold(f)
+        fcls = fe.classifiers()
+        assert len(fcls) == E * 2                                   # member-major: member k, lambda_auto j at 2 k + j
+        members = []
+        for k in range(E):
+            rows = tr[wg != k]
+            hs = OD.matrix(subset(x, rows), labels[rows])
+            cs = OD.estimator().estimate(hs, [3, 6])
+            OD.free_matrix(hs)
+            members.append(cs)
+            for j in range(2):
+                np.testing.assert_array_equal(fcls[2 * k + j]["cols"], cs[j]["cols"])
+                np.testing.assert_allclose(fcls[2 * k + j]["theta"], cs[j]["theta"], rtol=1e-9, atol=1e-13)
+        for j in range(2):
+            full = []
+            for k in range(E):
+                t = np.zeros(x.dim); t[members[k][j]["cols"]] = members[k][j]["theta"]
+                full.append(t)
+            pred = [comb([O.class_log_pdf(x, i, t, 1) for t in full]) for i in te]
+            np.testing.assert_allclose(r["predictions"][j, te], pred, rtol=1e-9)
+            for key, rows in (("loss_train", tr), ("loss_test", te)):
+                lv = [-np.mean([O.class_log_pdf(x, i, t, labels[i]) for i in rows]) for t in full]
+                assert abs(r[key][j, f] - comb(lv)) < 1e-9
+    OD.free_matrix(h)

@@ -251,3 +251,22 @@ def test_rank_failure_ends_the_run(tmp_path):
     """A rank that cannot start (no such device) must end the whole command with an error, not hang it."""
     r = run(["--ranks=2", "--transport=shm", "--devices=0,63", "learn", "--lambda-auto=2", "4", "4", FG, BG, "x"], tmp_path, ok=False)
     assert r.returncode != 0 and "out of range" in r.stderr
+
+
+def test_ensembles_inside_cross_validation(tmp_path):
+    """--ensemble-size with --k-fold-cv (estimate_ensemble runs inside every fold, kmerLr_estimator_ensemble.go:118): one
+    ensemble model per fold, a prediction table of summarised member predictions; one rank and two."""
+    # (--max-epochs: a member of a fold of the 16-row table trains on 4 rows, possibly of one class, and the leapfrog loop
+    # -- unbounded in the reference, kmerLr_estimator.go:225 -- would then chase lambda -> 0 for ever)
+    cv = ["learn", "--lambda-auto=2", "--k-fold-cv=2", "--ensemble-size=2", "--ensemble-summary=mean", "--max-epochs=3", SFG, SBG]
+    run(["--type=scoresLr"] + cv + ["e1"], tmp_path)
+    run(["--type=scoresLr", "--ranks=2", "--transport=shm"] + cv + ["e2"], tmp_path)
+    for f in (1, 2):
+        m1, m2 = (json.load(open(tmp_path / ("%s_cv%d.json" % (b, f)))) for b in ("e1", "e2"))
+        assert m1["Name"] == "scoresLr [mean]" and len(m1["Distributions"]) == 3 and m1["Parameters"] == m2["Parameters"]
+        for a, b in zip(m1["Distributions"][:2], m2["Distributions"][:2]):
+            np.testing.assert_allclose(a["Parameters"], b["Parameters"], rtol=1e-7, atol=1e-12)
+    a = np.loadtxt(tmp_path / "e1.table", skiprows=1)
+    b = np.loadtxt(tmp_path / "e2.table", skiprows=1)
+    assert a.shape == (16, 2)
+    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
