@@ -238,6 +238,10 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
 
   std::vector<uint8_t> b((size_t)dim);
   for (int64_t epoch = 0; e->cfg.max_epochs == 0 || epoch < e->cfg.max_epochs; epoch++) {   // :225
+    // The reference's loop has no bound (kmerLr_estimator.go:225): on degenerate data -- a training set of one class, whose
+    // intercept runs off -- it selects new features at lambda -> 0 for ever.  A library must not: a run that is still
+    // going after a million epochs ends with an error (--max-epochs is the reference's own bound).
+    if (epoch >= 1000000) { rc = fail(e, KLR_EINVAL, "the leapfrog loop did not terminate after %lld epochs (lambda = %g): degenerate training data? (--max-epochs bounds it)", (long long)epoch, e->l1reg / (double)n_total); break; }
     if (have && lambda_auto) {
       int64_t d = 0;
       for (size_t j = 1; j < e->theta.size(); j++) if (e->theta[j] != 0.0) d++;             // r.Nonzero()
