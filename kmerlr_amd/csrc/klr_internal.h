@@ -64,6 +64,8 @@ struct klr_ctx {
   DevBuf       ws[WS_COUNT];
   // pinned host staging
   void*        pin = nullptr;
+  bool         sel_cursor_dirty = false;   // a hinted selection left its candidate count in the control block (k_fast_rank_out
+                                           // does not clear it: the next sweep's row pass does, or a memset before any other use)
   u64          sel_hint = 0;      // hinted compaction threshold (key) from the last selection, 0 = none
   i64          sel_hint_K = 0, sel_hint_m = 0;
   size_t       pin_cap = 0;
@@ -299,7 +301,7 @@ int   sweep_range_finish(klr_ctx* ctx, const klr_mat* mat, i64 col0, i64 col1, c
                          i64 nrowblk, hipStream_t st);
 int   launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                           const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
-                          const double* theta_host = nullptr, i64 theta_len = 0);
+                          const double* theta_host = nullptr, i64 theta_len = 0, u32* zero_u32 = nullptr);
 int   sel_prepare(klr_ctx* ctx, i64 m, u64** keys, u32** hist);
 int   apply_transform_dev(klr_ctx* ctx, double* gbuf, i64 dim, const double* scale, const double* offset);
 

@@ -451,6 +451,34 @@ __global__ __launch_bounds__(1024) void k_fast_rank(const FastCtl* __restrict__ 
   if (valid && part == 0) sorted_dev[r] = my;
 }
 
+// k_fast_rank that also delivers: a candidate lands at its rank in PINNED HOST memory (all n of them: the host reads v
+// and w off the sorted list), the first workgroup writes the state word and the caller's scalar.  No second launch; the
+// cursor is cleared by the row pass of the next sweep (RowPassArgs.zero_u32), the first kernel of every step.
+__global__ __launch_bounds__(1024) void k_fast_rank_out(const FastCtl* __restrict__ ctl, u64 tau, u32 K, const Cand* __restrict__ gcand,
+                                                        FastState* st, Cand* __restrict__ out, const double* __restrict__ extra_src,
+                                                        double* __restrict__ extra_dst) {
+  extern __shared__ Cand sc[];
+  const u32 n = ctl->cursor;
+  const u32 t = threadIdx.x;
+  const bool usable = n >= K && n <= FAST_CAP;
+  if (blockIdx.x == 0 && t == 0) {
+    if (extra_src) *extra_dst = *extra_src;
+    st->lowkey = tau; st->ncand = n; st->cursor = usable ? n : 0u; st->fallback = usable ? 0u : 2u; st->wfound = 0; st->vkey = 0; st->wkey = 0;
+  }
+  if (!usable) return;
+  for (u32 i = t; i < n; i += 1024) sc[i] = gcand[i];
+  __syncthreads();
+  const u32 per = (n + FAST_RANK_WGS - 1) / FAST_RANK_WGS;       // <= 32 candidates per workgroup
+  const u32 cl = t >> 5, part = t & 31u;
+  const u32 ci = blockIdx.x * per + cl;
+  const bool valid = cl < per && ci < n;
+  const Cand my = valid ? sc[ci] : Cand{0ull, 0xFFFFFFFFu, 0u};
+  u32 r = 0;
+  if (valid) for (u32 j = part; j < n; j += 32u) r += cand_before(sc[j], my) ? 1u : 0u;
+  r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 16, 64);
+  if (valid && part == 0) out[r] = my;
+}
+
 __global__ __launch_bounds__(1024) void k_fast_direct(u32* __restrict__ /*hist: untouched (not built when hinted)*/, FastCtl* __restrict__ ctl, u64 tau, u32 K, u32 Nth,
                                                       const Cand* __restrict__ sorted_dev, FastState* st, Cand* __restrict__ out,
                                                       const double* __restrict__ extra_src, double* __restrict__ extra_dst) {
@@ -577,7 +605,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     // 3 KB -- is written by k_fast_finish straight into pinned host memory (device-visible, coherent): no copy kernel
     KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&cand));
     char* pin;
-    KLR_TRY(pin_get(ctx, 64 + (size_t)K * sizeof(Cand), (void**)&pin));
+    KLR_TRY(pin_get(ctx, 64 + (size_t)std::max<i64>(K, FAST_CAP) * sizeof(Cand), (void**)&pin));
     FastState* fs = (FastState*)pin;
     double* extra_dst = (double*)(pin + 48);
     Cand* out = (Cand*)(pin + 64);
@@ -588,21 +616,41 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_finish, (int)(2 * FAST_CAP * sizeof(Cand))));
     KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_direct, (int)(2 * FAST_CAP * sizeof(Cand))));
     KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_rank, (int)(FAST_CAP * sizeof(Cand))));
-    bool direct_ok = false;
+    KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_rank_out, (int)(FAST_CAP * sizeof(Cand))));
+    bool direct_ok = false, ranked_out = false;
     if (hint_tau != 0 && keys_hist_ready) {
       // the candidates are already in `cand` (SelHint): one sort kernel, no pass over the keys
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
       Cand* sorted_dev = cand + GCAND_CAP;             // WS_TMP0 holds the candidates and, behind them, their sorted copy
-      hipLaunchKernelGGL(k_fast_rank, dim3(FAST_RANK_WGS), dim3(1024), FAST_CAP * sizeof(Cand), st, (const FastCtl*)ctl, (u32)K, (const Cand*)cand, sorted_dev);
-      hipLaunchKernelGGL(k_fast_direct, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, ctl, hint_tau, (u32)K, (u32)N, (const Cand*)sorted_dev, fs, out,
-                         extra_src, extra_dst);
+      if (ctx_opt(ctx, "KLR_SELECT_TWO_LAUNCHES")) {    // A/B: rank, then a one-workgroup kernel that copies out and finds v and w
+        hipLaunchKernelGGL(k_fast_rank, dim3(FAST_RANK_WGS), dim3(1024), FAST_CAP * sizeof(Cand), st, (const FastCtl*)ctl, (u32)K, (const Cand*)cand, sorted_dev);
+        hipLaunchKernelGGL(k_fast_direct, dim3(1), dim3(1024), FAST_CAP * sizeof(Cand), st, hist, ctl, hint_tau, (u32)K, (u32)N, (const Cand*)sorted_dev, fs, out,
+                           extra_src, extra_dst);
+      } else {
+        hipLaunchKernelGGL(k_fast_rank_out, dim3(FAST_RANK_WGS), dim3(1024), FAST_CAP * sizeof(Cand), st, (const FastCtl*)ctl, hint_tau, (u32)K, (const Cand*)cand,
+                           fs, out, extra_src, extra_dst);
+        ranked_out = true;
+        ctx->sel_cursor_dirty = true;
+      }
       KLR_HIP(ctx, hipGetLastError());
       KLR_HIP(ctx, hipStreamSynchronize(st));
       direct_ok = fs->fallback != 2;
+      if (direct_ok && ranked_out) {
+        // v = the N-th key of the sorted list, w = the first key below it (all n candidates are here, not only the first K)
+        const u32 n = fs->ncand;
+        const u64 vk = (N >= 1 && (u32)N <= n) ? out[(size_t)N - 1].key : 0ull;
+        fs->vkey = vk; fs->wfound = 0; fs->wkey = 0;
+        for (u32 i = (u32)std::max<i64>(N, 1); i < n; i++) if (out[i].key < vk) { fs->wfound = 1; fs->wkey = out[i].key; break; }
+      }
     }
     if (!direct_ok) {
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+      if (ctx->sel_cursor_dirty) {                   // a hinted selection's candidate count (this call's failed attempt, or an earlier call's)
+        KLR_HIP(ctx, hipMemsetAsync(ctl, 0, sizeof(FastCtl), st));
+        ctx->sel_cursor_dirty = false;
+      }
       if (hint_tau != 0 && keys_hist_ready) {        // the hinted sweep did not build the coarse histogram
+
         const unsigned hgrid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
         hipLaunchKernelGGL(k_hist_from_keys, dim3(hgrid), dim3(256), 0, st, keys, m, hist);
       }
@@ -1052,7 +1100,9 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     unsigned long long* rowblk; i64 nrowblk;
     (void)acc;
     KLR_TRY(launch_row_pass_fix(ctx, reduced ? reduced : full, thd, theta_red[0], reduced == nullptr, cw, scale_fx, S,
-                                &rowblk, &nrowblk, theta_inline ? theta_red : nullptr, theta_inline ? c_plus_1 : 0));
+                                &rowblk, &nrowblk, theta_inline ? theta_red : nullptr, theta_inline ? c_plus_1 : 0,
+                                &((FastCtl*)((char*)hist - sizeof(FastCtl)))->cursor));   // the row pass clears the candidate cursor
+    ctx->sel_cursor_dirty = false;
     const bool tr = scale != nullptr || offset != nullptr;
     // reduce-scatter form of the collective: wide matrices on several ranks with both hooks installed, nothing that
     // needs the whole vector on every rank (g_out, a transform), a selection the one-workgroup sort can hold

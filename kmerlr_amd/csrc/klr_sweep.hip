@@ -44,6 +44,8 @@ struct RowPassArgs {
   double fix_scale; i64* S; unsigned long long* acc;     // ROW_SWEEP_FIX
   int theta_inline_n;                                    // > 0: theta travels in the kernel arguments (no upload)
   int theta_lds_n;                                       // > 0: theta (device) is copied to LDS first: a.theta[col] becomes an LDS read
+  u32* zero_u32;                                         // nullable: a word the first block clears (the candidate cursor of the
+                                                         // hinted selection that follows the sweep: one launch less at its end)
   double theta_inline[THETA_INLINE_MAX];
 };
 
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
   const i64 gid = ((i64)blockIdx.x * 256 + threadIdx.x) / G;
   const int lane = threadIdx.x % G;
   double loss_term = 0.0;
+  if (a.zero_u32 && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_u32 = 0u;
   const bool inl = a.theta_inline_n > 0 || a.theta_lds_n > 0;   // theta of a reduced problem: kernel arguments / device -> LDS
   if (a.theta_inline_n > 0) {
     if ((int)threadIdx.x < a.theta_inline_n) sth[threadIdx.x] = a.theta_inline[threadIdx.x];
@@ -213,7 +216,7 @@ static int row_group(klr_ctx* ctx, const klr_mat* mat, bool const_mode) {
 static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                            int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev,
                            double fix_scale = 0.0, i64* S = nullptr, unsigned long long* acc = nullptr,
-                           const double* theta_host = nullptr, i64 theta_len = 0) {
+                           const double* theta_host = nullptr, i64 theta_len = 0, u32* zero_u32 = nullptr) {
   const i64 n = mat->n;
   const int g = row_group(ctx, mat, const_mode);
   const i64 nb = std::max<i64>(1, ceil_div(n * g, 256));
@@ -224,7 +227,7 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
   a.theta = theta_dev; a.n = n; a.inv_n = 1.0 / (double)mat->n_total; a.cw0 = cw[0]; a.cw1 = cw[1];
   a.out0 = out0; a.out1 = out1; a.blk = blk; a.theta0_only = theta0; a.const_mode = const_mode ? 1 : 0;
   a.fix_scale = fix_scale; a.S = S; a.acc = acc;
-  a.theta_inline_n = 0; a.theta_lds_n = 0;
+  a.theta_inline_n = 0; a.theta_lds_n = 0; a.zero_u32 = zero_u32;
   if (theta_host && !const_mode && theta_len > 0 && theta_len <= THETA_INLINE_MAX) {
     a.theta_inline_n = (int)theta_len;
     memcpy(a.theta_inline, theta_host, (size_t)theta_len * sizeof(double));
@@ -253,7 +256,7 @@ int launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, i
 
 int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                         const double cw[2], double scale, i64* S, unsigned long long** rowblk, i64* nrowblk,
-                        const double* theta_host, i64 theta_len) {
+                        const double* theta_host, i64 theta_len, u32* zero_u32) {
   // the kernel writes 5 integer partials per block into the WS_BLK block-partial buffer
   const int g = row_group(ctx, mat, const_mode);
   const i64 nb = std::max<i64>(1, ceil_div(mat->n * g, 256));
@@ -261,7 +264,7 @@ int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_de
   KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(unsigned long long), (void**)&blk));
   *rowblk = blk; *nrowblk = mat->n > 0 ? nb : 0;
   return row_pass_common(ctx, mat, theta_dev, theta0, const_mode, ROW_SWEEP_FIX, cw, nullptr, nullptr, nullptr, scale, S, blk,
-                         theta_host, theta_len);
+                         theta_host, theta_len, zero_u32);
 }
 
 int launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
