@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
         l1 = __double2ll_rn((ts - f) * 4398046511104.0);
       } else bad = 1;
     }
-    for (int o = 32; o > 0; o >>= 1) {
+    // only lane 0 of every G-lane group holds a value: the butterfly starts at distance G (4 levels instead of 6 at G = 4)
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) {
       hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64);
       l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64);
       bad += __shfl_xor(bad, o, 64);
