@@ -175,6 +175,8 @@ static int rccl_load(RcclState* st) {
 extern "C" int klr_rccl_unique_id(void* id128) {
   if (!id128) return klr_fail(nullptr, KLR_EINVAL, "id128 is NULL");
   static RcclState st;
+  static std::mutex mu;                              // hosts with one context per thread may all ask for an id
+  std::lock_guard<std::mutex> lk(mu);
   KLR_TRY(rccl_load(&st));
   int rc = st.GetUniqueId(id128);
   if (rc != 0) return klr_fail(nullptr, KLR_ECOMM, "ncclGetUniqueId failed (%d)", rc);
