@@ -417,12 +417,15 @@ def sweep_kernel_in_estimate(R, mat, lam_auto):
             "note": "sweep kernel timed inside klr_estimator_estimate (sub-select and reduced solve between sweeps)"}
 
 
-def sweep_collective(world, m, N):
+def sweep_collective(world, m, N, probe=None):
     """What klr_sweep_select posts per sweep (klr_select.hip): one rank nothing; from 131,072 columns on (KLR_RS_MIN_DIM)
-    a reduce-scatter of the int64 column sums + an all-gather of nranks x 2N candidates; below that one all-reduce."""
+    whichever the context MEASURED to be faster on this communicator (klr_ctx_comm_probe): a reduce-scatter of the int64
+    column sums + an all-gather of nranks x 2N candidates, or one all-reduce; below that one all-reduce."""
     if world <= 1:
         return "none (one rank)"
     if m + 1 >= int(os.environ.get("KLR_RS_MIN_DIM", "131072")) and 2 * N <= 4096:
+        if probe and probe.get("form") == "all-reduce" and probe.get("elements") == m + 6:
+            return "all-reduce of %d int64 (measured faster than reduce-scatter + all-gather here)" % (m + 6)
         return "reduce-scatter of %d int64 + all-gather of %d x %d candidates" % (m + 6, world, 2 * N)
     return "all-reduce of %d int64" % (m + 6)
 
@@ -464,7 +467,7 @@ def configs3_leg(R, estimate_leg, n_local=125000, m=1048576, draws=993, N=500, w
             "roofline": roofline,
             "comm": {"n_ranks_seen": (info["nranks"] if R.shm else info["rccl_ranks"]) if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
                      "allreduce_elements": m + 6 if R.comm else 0,
-                     "sweep_collective": sweep_collective(world, m, N), "stats": stats, "probe": ctx.comm_probe()},
+                     "sweep_collective": sweep_collective(world, m, N, ctx.comm_probe()), "stats": stats, "probe": ctx.comm_probe()},
             "estimate_lambda_auto": est,
             "step_check": {"lambda": out["lam"], "loss": out["loss"], "c": out["c"]}}
 

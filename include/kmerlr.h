@@ -105,10 +105,13 @@ int         klr_ctx_comm_selfcheck(klr_ctx* ctx);
 int         klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce, int64_t* sweeps_scatter,
                                int64_t* scatter_fallbacks, int* checked);
 
-/* what the context measured before its first reduce-scatter sweep: the installed reduce-scatter hook on a vector of
- * `elements` int64 (averaged over the ranks) and the number of strip ranges the overlapped sweep then uses (1 = the
- * sweep stays one launch).  Zeros before the first such sweep. */
-int         klr_ctx_comm_probe(const klr_ctx* ctx, int64_t* elements, double* reduce_scatter_ms, int* ranges);
+/* what the context measured before the first wide sweep it could reduce-scatter (averaged over the ranks): the installed
+ * reduce-scatter on a vector of `elements` int64, the all-gather of the candidate blocks, ONE all-reduce of the same
+ * vector; scatter_form = 1 when reduce-scatter + all-gather (+ 20 us of slice work) beat the all-reduce and that form is
+ * used (-1: nothing measured yet); ranges = strip ranges of the overlapped sweep (1 = one launch).  Any output may be
+ * NULL.  KLR_RS / KLR_SWEEP_RANGES override the choices. */
+int         klr_ctx_comm_probe(const klr_ctx* ctx, int64_t* elements, double* reduce_scatter_ms, double* allgather_ms,
+                               double* allreduce_ms, int* scatter_form, int* ranges);
 
 /* KLR_* switches.  A context reads the process environment ONCE, in klr_ctx_create; later changes
  * go through these calls (value NULL unsets).  klr_ctx_reload_env re-reads the environment. */

@@ -45,7 +45,7 @@ SIGNATURES = {
     "klr_allreduce_host": (_int, [_vp, _vp, _i64, _int]),
     "klr_ctx_comm_selfcheck": (_int, [_vp]),
     "klr_ctx_comm_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
-    "klr_ctx_comm_probe": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_int)]),
+    "klr_ctx_comm_probe": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_int), C.POINTER(_int)]),
     "klr_ctx_set_option": (_int, [_vp, C.c_char_p, C.c_char_p]),
     "klr_ctx_reload_env": (_int, [_vp]),
     "klr_mat_from_csr": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _PVP]),
@@ -225,9 +225,10 @@ class Context:
         return dict(sweeps_allreduce=a.value, sweeps_scatter=s_.value, scatter_fallbacks=f.value, checked=bool(c.value))
 
     def comm_probe(self):
-        n, ms, g = C.c_int64(0), C.c_double(0.0), C.c_int(0)
-        self.check(lib().klr_ctx_comm_probe(self._h, C.byref(n), C.byref(ms), C.byref(g)))
-        return dict(elements=n.value, reduce_scatter_ms=ms.value, ranges=g.value)
+        n, rs, ag, ar, f, g = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_int(0), C.c_int(0)
+        self.check(lib().klr_ctx_comm_probe(self._h, C.byref(n), C.byref(rs), C.byref(ag), C.byref(ar), C.byref(f), C.byref(g)))
+        return dict(elements=n.value, reduce_scatter_ms=rs.value, allgather_ms=ag.value, allreduce_ms=ar.value,
+                    form={1: "reduce-scatter + all-gather", 0: "all-reduce", -1: "not measured"}[f.value], ranges=g.value)
 
     def set_option(self, name, value):
         """KLR_* switch of this context (value None unsets); contexts read the environment only when they are created."""

@@ -42,11 +42,11 @@ def _stale(target, deps):
 
 
 def kernel_hash():
-    """Hash of the sources that decide what the roofline kernel does and reads (the sweep, the ingest that lays the stream
-    out, the shared header): klr_version() reports it, profiles/ record it, bench.py refuses PMC numbers of another build."""
+    """Hash of the sources that decide what the roofline kernel does and reads (the sweep, and the ingest that lays the
+    stream out): klr_version() reports it, profiles/ record it, bench.py refuses PMC numbers of another build."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("klr_sweep.hip", "klr_ingest.hip", "klr_internal.h"):
+    for f in ("klr_sweep.hip", "klr_ingest.hip"):
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:12]
 

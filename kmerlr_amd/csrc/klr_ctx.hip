@@ -362,10 +362,14 @@ extern "C" int klr_ctx_comm_selfcheck(klr_ctx* ctx) {
   return KLR_OK;
 }
 
-extern "C" int klr_ctx_comm_probe(const klr_ctx* ctx, int64_t* elements, double* reduce_scatter_ms, int* ranges) {
+extern "C" int klr_ctx_comm_probe(const klr_ctx* ctx, int64_t* elements, double* reduce_scatter_ms, double* allgather_ms,
+                                  double* allreduce_ms, int* scatter_form, int* ranges) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   if (elements) *elements = ctx->probe_dim ? ctx->probe_dim + IB_EXTRA : 0;
   if (reduce_scatter_ms) *reduce_scatter_ms = ctx->probe_ms;
+  if (allgather_ms) *allgather_ms = ctx->probe_ag_ms;
+  if (allreduce_ms) *allreduce_ms = ctx->probe_ar_ms;
+  if (scatter_form) *scatter_form = ctx->probe_dim ? (ctx->probe_scatter ? 1 : 0) : -1;
   if (ranges) *ranges = ctx->probe_G;
   return KLR_OK;
 }

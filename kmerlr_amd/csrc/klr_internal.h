@@ -112,6 +112,8 @@ struct klr_ctx {
   // strip ranges of the overlapped sweep, chosen once per vector length from the MEASURED reduce-scatter time of the
   // installed hook (sweep_ranges_auto, klr_select.hip): probe_dim = that length, probe_G = the choice, probe_ms = the time
   i64 probe_dim = 0; int probe_G = 1; double probe_ms = 0.0;
+  double probe_ag_ms = 0.0, probe_ar_ms = 0.0;   // ... of the all-gather of the candidate blocks and of ONE all-reduce of the vector
+  bool probe_scatter = true;                     // reduce-scatter + all-gather beat the all-reduce on this communicator
 };
 
 bool prof_take(klr_ctx* ctx);                                   // profiling on and this launch of the sweep is one to be timed

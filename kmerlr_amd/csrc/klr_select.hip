@@ -826,44 +826,65 @@ static ScatterPlan scatter_plan(i64 dim, int R, const Q64Ranges* qr) {
   return P;
 }
 
-// How many strip ranges the overlapped form should use for vectors of `dim` sums on THIS communicator.  Splitting the
-// sweep into G launches costs ~15 us per extra launch (start, tail, a second set of piece vectors) and ~13 us per
-// cross-stream event (measured on MI355X: 142.7 -> 171.9 us for G = 2 on the configs[3] shard with a collective that
-// costs nothing); it hides all but the last range's finish + reduce-scatter + key pass.  So it pays only when the
-// reduce-scatter is slow enough -- which depends on the links, the ranks and RCCL, not on this code: the hook is TIMED
-// once per vector length (3 calls after a warm-up, HIP events on the ctx stream), the times are averaged over the ranks
-// (one f64 all-reduce: every rank takes the same decision) and G = 2 is chosen when half of it exceeds that overhead.
-// KLR_SWEEP_RANGES=g overrides (1 = never split).
-static int sweep_ranges_auto(klr_ctx* ctx, i64 dim, int* G_out) {
-  if (ctx->sw.overlap >= 0) { *G_out = ctx->sw.overlap; return KLR_OK; }
-  if (ctx->probe_dim == dim) { *G_out = ctx->probe_G; return KLR_OK; }
-  const i64 R = ctx->nranks, slice = ceil_div(dim + IB_EXTRA, R);
-  i64* buf;
-  KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)(slice * R + slice) * 8, (void**)&buf));
-  KLR_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)(slice * R + slice) * 8, ctx->stream));
-  hipEvent_t e0, e1;
-  KLR_HIP(ctx, hipEventCreate(&e0));
-  KLR_HIP(ctx, hipEventCreate(&e1));
-  int rc = 0;
-  const int iters = 3;
-  for (int i = 0; i <= iters && rc == 0; i++) {
-    if (i == 1) (void)hipEventRecord(e0, ctx->stream);
+// Which collective the sweep of a vector of `dim` sums posts on THIS communicator, and in how many strip ranges.
+// Both questions depend on the links, the number of ranks and RCCL, not on this code, so the installed hooks are TIMED
+// once per vector length (3 calls after a warm-up each, HIP events on the ctx stream; the times are averaged over the
+// ranks with one f64 all-reduce, so every rank takes the same decisions):
+//   * form: reduce-scatter (dim + 5 int64) + all-gather (one 16 KB block per rank) + the slice work and the host merge
+//     that come with it (~20 us more than the all-reduce path's conversion + selection, measured with one rank) against
+//     ONE all-reduce of the vector.  The reduce-scatter moves half the bytes over the links but pays a second collective's
+//     latency: it is used when t_rs + t_ag + 20 us < t_ar.
+//   * ranges: splitting the sweep into G launches costs ~15 us per extra launch (start, tail, a second set of piece
+//     vectors) and ~13 us per cross-stream event (MI355X, configs[3] shard: 142.7 -> 171.9 us for G = 2 with a collective
+//     that costs nothing); it hides all but the last range's finish + reduce-scatter + key pass: G = 2 when half of t_rs
+//     exceeds that overhead.
+// KLR_RS=1 / 0 fixes the form, KLR_SWEEP_RANGES=g the ranges (1 = never split).
+static int sweep_collective_auto(klr_ctx* ctx, i64 dim, i64 blk_bytes, bool* scatter_out, int* G_out) {
+  if (ctx->probe_dim != dim) {
+    const i64 R = ctx->nranks, slice = ceil_div(dim + IB_EXTRA, R);
+    i64* buf;
+    KLR_TRY(ws_get(ctx, WS_TMP1, (size_t)(slice * R + slice) * 8 + (size_t)blk_bytes * (size_t)(R + 1), (void**)&buf));
+    KLR_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)(slice * R + slice) * 8 + (size_t)blk_bytes * (size_t)(R + 1), ctx->stream));
+    char* agb = (char*)(buf + slice * R + slice);
+    int rc = 0;
+    hipError_t he = hipSuccess;
+    const int iters = 3;
+    // warm-up: one call of each
     rc = ctx->rs_fn(ctx->coll_user, buf, buf + slice * R, slice, KLR_I64, (void*)ctx->stream);
+    if (rc == 0) rc = ctx->ag_fn(ctx->coll_user, agb, agb + blk_bytes, blk_bytes, (void*)ctx->stream);
+    if (rc == 0) rc = ctx->ar_fn(ctx->ar_user, buf, dim + IB_EXTRA, KLR_I64, (void*)ctx->stream);
+    if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "a collective hook failed while it was timed");
+    // exact timings, one collective at a time
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int which = 0; which < 3; which++) {
+      hipEvent_t a, b;
+      KLR_HIP(ctx, hipEventCreate(&a));
+      KLR_HIP(ctx, hipEventCreate(&b));
+      (void)hipEventRecord(a, ctx->stream);
+      for (int i = 0; i < iters && rc == 0; i++) {
+        if (which == 0) rc = ctx->rs_fn(ctx->coll_user, buf, buf + slice * R, slice, KLR_I64, (void*)ctx->stream);
+        else if (which == 1) rc = ctx->ag_fn(ctx->coll_user, agb, agb + blk_bytes, blk_bytes, (void*)ctx->stream);
+        else rc = ctx->ar_fn(ctx->ar_user, buf, dim + IB_EXTRA, KLR_I64, (void*)ctx->stream);
+      }
+      (void)hipEventRecord(b, ctx->stream);
+      he = hipEventSynchronize(b);
+      float m1 = 0.f;
+      if (he == hipSuccess) he = hipEventElapsedTime(&m1, a, b);
+      (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+      if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "a collective hook failed while it was timed");
+      if (he != hipSuccess) return klr_fail(ctx, KLR_EHIP, "timing the collectives failed: %s", hipGetErrorString(he));
+      t[which] = (double)m1 / iters;
+    }
+    KLR_TRY(klr_allreduce_host(ctx, t, 3, KLR_F64));
+    for (int i = 0; i < 3; i++) t[i] /= (double)R;
+    ctx->probe_ms = t[0]; ctx->probe_ag_ms = t[1]; ctx->probe_ar_ms = t[2];
+    const double overhead_ms = 0.030;                  // one extra launch + one event, measured
+    ctx->probe_G = t[0] * 0.5 > overhead_ms ? 2 : 1;
+    ctx->probe_scatter = t[0] + t[1] + 0.020 < t[2];
+    ctx->probe_dim = dim;
   }
-  (void)hipEventRecord(e1, ctx->stream);
-  hipError_t he = hipEventSynchronize(e1);
-  float ms = 0.f;
-  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (rc != 0) return klr_fail(ctx, KLR_ECOMM, "reduce-scatter hook failed while it was timed");
-  if (he != hipSuccess) return klr_fail(ctx, KLR_EHIP, "timing the reduce-scatter failed: %s", hipGetErrorString(he));
-  double t[1] = {(double)ms / iters};
-  KLR_TRY(klr_allreduce_host(ctx, t, 1, KLR_F64));
-  ctx->probe_ms = t[0] / (double)R;
-  const double overhead_ms = 0.030;                  // one extra launch + one event, measured
-  ctx->probe_G = ctx->probe_ms * 0.5 > overhead_ms ? 2 : 1;
-  ctx->probe_dim = dim;
-  *G_out = ctx->probe_G;
+  *scatter_out = ctx->sw.rs == 1 ? true : ctx->probe_scatter;
+  *G_out = ctx->sw.overlap >= 0 ? ctx->sw.overlap : ctx->probe_G;
   return KLR_OK;
 }
 
@@ -1111,12 +1132,19 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     // ... on a context whose hooks passed klr_ctx_comm_selfcheck (KLR_RS=0 keeps the all-reduce, KLR_RS=1 skips that test)
     const bool scatter = ctx->rs_fn && ctx->ag_fn && ctx->ar_fn && (ctx->nranks > 1 || rs_force) && !tr && !g_out && dim >= rs_min_dim &&
                          2 * N <= FAST_CAP && N >= 1 && ctx->sw.rs != 0 && (ctx->comm_checked || ctx->sw.rs == 1);
+    bool scatter_now = scatter;
+    int G_want = 1;
     if (scatter) {
-      // Strip ranges (sweep_ranges_auto: from the measured reduce-scatter time; KLR_SWEEP_RANGES overrides): the sweep runs as
-      // one launch per range and range g's sums are finished, reduce-scattered and keyed on a second stream while range
-      // g + 1 streams.
-      int G_want = 1;
-      if (full->fmt == FMT_Q64C12 || full->fmt == FMT_Q64C13) KLR_TRY(sweep_ranges_auto(ctx, dim, &G_want));
+      // the form (reduce-scatter + all-gather, or one all-reduce) and the strip ranges from the MEASURED collectives of this
+      // communicator (sweep_collective_auto); a forced form (KLR_RS=1, KLR_RS_FORCE) with fixed ranges needs no probe
+      if (ctx->sw.rs == 1 && ctx->sw.overlap >= 0) G_want = ctx->sw.overlap;
+      else KLR_TRY(sweep_collective_auto(ctx, dim, (i64)(SCAT_HDR + (size_t)std::max<i64>(std::min<i64>(m, 2 * N), 1) * sizeof(Cand)), &scatter_now, &G_want));
+      if (rs_force) scatter_now = true;
+      if (!(full->fmt == FMT_Q64C12 || full->fmt == FMT_Q64C13)) G_want = 1;
+    }
+    if (scatter_now) {
+      // Strip ranges: the sweep runs as one launch per range and range g's sums are finished, reduce-scattered and keyed on
+      // a second stream while range g + 1 streams.
       const Q64Ranges* qr = nullptr;
       i64* part_r = nullptr;
       KLR_TRY(sweep_ranges_prepare(ctx, full, G_want, &qr, &part_r));

@@ -126,6 +126,8 @@ def scatter_collective(K, dist, ctx, hip, rank, world, calls):
     ctx.comm_selfcheck()
     assert ctx.comm_stats()["checked"] and cnt == {"rs": 1, "ag": 1}, cnt
     ctx.set_option("KLR_SWEEP_RANGES", 1)                              # one reduce-scatter per sweep: the counts below
+    ctx.set_option("KLR_RS", 1)                                        # ... and no timing probe of the hooks (these serve the
+                                                                       # reduce-scatter through an all-reduce: the probe would choose that)
     i64_before = calls["i64"]
     s0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
     # the first reduce-scatter sweep on a matrix is repeated as an all-reduce and compared (one int64 all-reduce) ...
@@ -159,6 +161,15 @@ def scatter_collective(K, dist, ctx, hip, rank, world, calls):
             np.testing.assert_array_equal(a["b"], s_["b"])
             assert a["lam"] == s_["lam"] and a["loss"] == s_["loss"] and a["c"] == s_["c"] and a["ok"] == s_["ok"], (G, a["lam"], s_["lam"])
     ctx.set_option("KLR_SWEEP_RANGES", None)
+    ctx.set_option("KLR_RS", None)
+    # left to itself the context times the hooks and decides: every rank reports the same choice, and the result is the same
+    p0 = K.sweep_select(ctx, shard, None, None, np.zeros(1), cw, N)
+    pr = ctx.comm_probe()
+    assert pr["elements"] == m + 6 and pr["form"] in ("reduce-scatter + all-gather", "all-reduce") and pr["ranges"] in (1, 2), pr
+    both = np.zeros(world * 2); both[2 * rank] = 1.0 if pr["form"].startswith("reduce") else 0.0; both[2 * rank + 1] = pr["ranges"]
+    ctx.allreduce_host(both)
+    assert both[0] == both[2] and both[1] == both[3], both
+    np.testing.assert_array_equal(a0["b"], p0["b"]); assert a0["lam"] == p0["lam"]
     st_ = ctx.comm_stats()
     assert st_["sweeps_scatter"] >= 3 and st_["sweeps_allreduce"] >= 3, st_
     if rank == 0:
