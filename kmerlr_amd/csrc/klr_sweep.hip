@@ -49,8 +49,12 @@ struct RowPassArgs {
   double theta_inline[THETA_INLINE_MAX];
 };
 
-__device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i, double r, double& loss_term) {
-  if (a.active && !a.active[i] && mode != ROW_LOGPDF) {
+// y_in / act_in: the row's label and mask byte, fetched by the caller beside the row offsets (one round trip less than
+// reading them here, after the dot product); S_out: the fixed-point weight written to a.S (ROW_SWEEP_FIX), for the tail sums
+__device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i, double r, double& loss_term, int y_in, bool act_in,
+                                           i64& S_out) {
+  S_out = 0;
+  if (!act_in && mode != ROW_LOGPDF) {
     // row outside the current training / test split: it contributes nothing to any sum over samples
     loss_term = 0.0;
     if (mode == ROW_SWEEP) { a.out0[i] = 0.0; if (a.out1) a.out1[i] = 0.0; }
@@ -58,7 +62,7 @@ __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i
     else if (mode == ROW_IRLS) { a.out0[i] = 0.0; a.out1[i] = 0.0; }
     return;
   }
-  const int y = a.labels[i] != 0;
+  const int y = y_in;
   const double lp = -d_log_add0(-r);                 // log sigma(r), LogPdf (:147-149)
   if (mode == ROW_LOGPDF) { a.out0[i] = lp; loss_term = 0.0; return; }
   // Loss: r -= cw[y] * ClassLogPdf (:258-264)
@@ -68,7 +72,7 @@ __device__ __forceinline__ void row_finish(const RowPassArgs& a, int mode, i64 i
     // Gradient weights (:174-178), same association as the reference: 1/n * cw * (...)
     const double sv = y ? a.inv_n * a.cw1 * (e - 1.0) : a.inv_n * a.cw0 * e;
     if (mode == ROW_SWEEP) { a.out0[i] = sv; if (a.out1) a.out1[i] = loss_term; }
-    else a.S[i] = __double2ll_rn(sv * a.fix_scale);
+    else { S_out = __double2ll_rn(sv * a.fix_scale); a.S[i] = S_out; }
   } else if (mode == ROW_IRLS) {
     // estimate_coordinate (:97-111) with the guarded weight of oracle KLO_IRLS_WMIN
     const double p = exp(lp);
@@ -87,6 +91,13 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
   const int lane = threadIdx.x % G;
   double loss_term = 0.0;
   if (a.zero_u32 && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_u32 = 0u;
+  // everything that depends on the row id alone is requested first -- its offsets, its label, its mask byte -- so that these
+  // loads fly while theta is staged: the pass is a chain of dependent round trips (offsets -> entries -> ...) and nothing else
+  i64 rb = 0, re = 0, S_row = 0; int y_row = 0; bool act_row = true;
+  if (gid < a.n) {
+    if (!a.const_mode) { rb = a.rowptr[gid]; re = a.rowptr[gid + 1]; }
+    if (lane == 0) { y_row = a.labels[gid] != 0; if (a.active) act_row = a.active[gid] != 0; }
+  }
   const bool inl = a.theta_inline_n > 0 || a.theta_lds_n > 0;   // theta of a reduced problem: kernel arguments / device -> LDS
   if (a.theta_inline_n > 0) {
     if ((int)threadIdx.x < a.theta_inline_n) sth[threadIdx.x] = a.theta_inline[threadIdx.x];
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
     if (a.const_mode) {
       r = a.theta0_only;
     } else {
-      const i64 b = a.rowptr[gid], e = a.rowptr[gid + 1];
+      const i64 b = rb, e = re;
       const VT* val = (const VT*)a.val;
       // LinearPdf (:47-68): r = theta[0] + sum_{j>=1} v_j theta[i_j]; entry 0 is the bias
       double acc = 0.0;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
       acc = group_sum<G>(acc);
       r = (inl ? sth[0] : a.theta[0]) + acc;
     }
-    if (lane == 0) row_finish(a, MODE, gid, r, loss_term);
+    if (lane == 0) row_finish(a, MODE, gid, r, loss_term, y_row, act_row, S_row);
   }
   if (MODE == ROW_SWEEP_FIX) {
     // exact integer partials: bias sum as hi/lo halves of S, loss as two limbs (see k_fix_s)
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
     __shared__ u32 shbad[4];
     i64 hi = 0, lo = 0, l0 = 0, l1 = 0; u32 bad = 0;
     if (gid < a.n && lane == 0) {
-      const i64 v = a.S[gid];
+      const i64 v = S_row;                               // (not read back from a.S: the store has only just been issued)
       hi = v >> 32; lo = (i64)(v & 0xFFFFFFFFll);
       const double t = loss_term;
       if (t >= 0.0 && t < 1099511627776.0) {
@@ -218,7 +229,7 @@ static int row_group(klr_ctx* ctx, const klr_mat* mat, bool const_mode) {
 static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, double theta0, bool const_mode,
                            int mode, const double cw[2], double* out0, double* out1, double* loss_acc_dev,
                            double fix_scale = 0.0, i64* S = nullptr, unsigned long long* acc = nullptr,
-                           const double* theta_host = nullptr, i64 theta_len = 0, u32* zero_u32 = nullptr) {
+                           const double* theta_host = nullptr, i64 theta_len = 0, u32* zero_u32 = nullptr, i64* nblocks_out = nullptr) {
   const i64 n = mat->n;
   const int g = row_group(ctx, mat, const_mode);
   const i64 nb = std::max<i64>(1, ceil_div(n * g, 256));
@@ -236,6 +247,7 @@ static int row_pass_common(klr_ctx* ctx, const klr_mat* mat, const double* theta
   } else if (!const_mode && theta_dev && mat->dim <= THETA_LDS_MAX && (double)mat->dim <= 2.0 * (256 / g) * std::max(1.0, mat->avg_row)) {
     a.theta_lds_n = (int)mat->dim;                       // worth it while a block's rows use more entries than the copy moves
   }
+  if (nblocks_out) *nblocks_out = n > 0 ? nb : 0;      // blocks that write partials
   if (n > 0) {
     if (mat->val_f64) row_pass_group<double>(g, mode, n, ctx->stream, a);
     else              row_pass_group<float>(g, mode, n, ctx->stream, a);
@@ -264,9 +276,9 @@ int launch_row_pass_fix(klr_ctx* ctx, const klr_mat* mat, const double* theta_de
   const i64 nb = std::max<i64>(1, ceil_div(mat->n * g, 256));
   unsigned long long* blk;
   KLR_TRY(ws_get(ctx, WS_BLK, (size_t)nb * 5 * sizeof(unsigned long long), (void**)&blk));
-  *rowblk = blk; *nrowblk = mat->n > 0 ? nb : 0;
+  *rowblk = blk;
   return row_pass_common(ctx, mat, theta_dev, theta0, const_mode, ROW_SWEEP_FIX, cw, nullptr, nullptr, nullptr, scale, S, blk,
-                         theta_host, theta_len, zero_u32);
+                         theta_host, theta_len, zero_u32, nrowblk);
 }
 
 int launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
