@@ -147,6 +147,13 @@ void klr_cv_groups_val(int64_t n_all, int k_fold, double val_ratio, int64_t seed
  * Estimator of fold f after a cross-validation (its trace, path and classifiers: learn_parameters writes one
  * `_cv<f+1>` file set per fold, kmerLr_learn.go:45-66); owned by `est`, valid until its next call. */
 klr_estimator* klr_estimator_fold(const klr_estimator* est, int fold);
+/* With cfg.cooccurrence and cfg.copreselection = q > 0 klr_estimator_crossvalidate takes the BASE data and repeats the
+ * co-occurrence set-up inside every fold as the reference does (kmerLr_estimator_ensemble.go:99-117): pre-selection of q
+ * features on the fold's training rows, the pair matrix of the restricted data, its own transform (fitted by the backend
+ * when cfg.data_transform is set; scale / offset of the call are the base data's transform for the pre-selection).  The
+ * columns of a fold's classifiers are columns of ITS pair matrix: klr_estimator_base_cols on the fold's estimator gives
+ * the base columns it was built from (as klr_cooccurrence_prepare's base_cols). */
+int  klr_estimator_base_cols(const klr_estimator* fold_est, const int64_t** cols, int64_t* n);
 /* SaveCrossvalidation / SaveCrossvalidationLoss (kmerLr_crossvalidation.go:122-165): rows in fold order */
 int  klr_save_crossvalidation(const char* filename, const double* predictions, const uint8_t* labels,
                               const int32_t* groups, int64_t n, int k_fold);

@@ -54,6 +54,8 @@ def bind_driver(L):
     L.klr_estimator_crossvalidate.argtypes = [vp, vp, i64, i64, C.c_int, i64, vp, i64, vp, vp, vp, vp, vp, vp]
     L.klr_cv_groups.argtypes = [i64, C.c_int, i64, i64, i64, vp]
     L.klr_cv_groups_val.argtypes = [i64, C.c_int, C.c_double, i64, i64, i64, vp, vp]
+    L.klr_estimator_base_cols.restype = C.c_int
+    L.klr_estimator_base_cols.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.klr_estimator_fold.restype = vp
     L.klr_estimator_fold.argtypes = [vp, C.c_int]
     L.klr_save_crossvalidation.restype = C.c_int
@@ -151,6 +153,14 @@ class Estimator:
         fe.L, fe.backend, fe.cfg, fe._h = self.L, self.backend, self.cfg, C.c_void_p(h)
         fe.close = lambda: None
         return fe
+
+    def base_cols(self):
+        """Base columns of a fold's pair matrix (co-preselection inside the fold)."""
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.L.klr_estimator_base_cols(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.int64)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64)), shape=(n.value,)).copy()
 
     def crossvalidate(self, mat_handle, n_local, k_fold, lambda_auto, seed=1, row0=0, n_all=0, scale=None, offset=None):
         """Returns dict(predictions[nla, n_local], groups[n_local], loss_train[nla, k], loss_test[nla, k])."""

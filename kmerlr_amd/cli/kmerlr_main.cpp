@@ -667,8 +667,7 @@ int main(int argc, char** argv) {
     cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;
     cfg.copreselection = opt_int(o, "co-preselection", "0");
     if (cfg.copreselection != 0 && !cfg.cooccurrence) die("--co-preselection needs --co-occurrence");
-    if (cfg.cooccurrence && cfg.copreselection > 0 && cv_path)
-      die("--co-preselection together with --k-fold-cv is not part of this build (the pre-selection would have to run per fold)");
+    if (ensemble > 1 && cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
 
     // positionals: <M> <N> | <MODEL.json>, FG, BG, BASENAME (kmerLr_learn.go:153-189; scoresLr: [MODEL.json] FG BG BASENAME)
     DataSet d;
@@ -762,8 +761,11 @@ int main(int argc, char** argv) {
     klr_mat* base_mat = nullptr;
     std::vector<int64_t> base_cols;
     int64_t nb1 = 0;
-    if (cfg.cooccurrence) {
-      if (!warm_cols.empty()) die("warm start together with --co-occurrence is not part of this build");
+    // with folds / a validation set the pre-selection belongs to the fold (its training rows only): the cross-validation
+    // gets the base data and builds every fold's pair matrix itself (klr_estimator_crossvalidate)
+    const bool fold_copre = cfg.cooccurrence && cv_path && cfg.copreselection > 0 && cfg.copreselection < d.dim - 1;
+    if (cfg.cooccurrence && !warm_cols.empty()) die("warm start together with --co-occurrence is not part of this build");
+    if (cfg.cooccurrence && !fold_copre) {
       std::vector<double> ps, po;
       if (cfg.copreselection > 0) fit_transform(ctx, mat, d.dim, opt(o, "data-transform", ""), ps, po);
       base_cols.assign((size_t)d.dim, 0);
@@ -851,7 +853,14 @@ int main(int argc, char** argv) {
             if (cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
             if (!fe || klr_estimator_save_ensemble(fe, j, ensemble, ncol, mfn.c_str(), scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
                                                    summary.c_str()) != KLR_OK) die("failed");
-          } else if (save_model(est, f * ncol + j, mfn.c_str(), names) != KLR_OK) die("failed");
+          } else {
+            if (fold_copre) {                                            // the pairs are those of the fold's own pre-selection
+              const int64_t* bc = nullptr; int64_t nbc = 0;
+              if (!fe || klr_estimator_base_cols(fe, &bc, &nbc) != KLR_OK || nbc < 1) die("failed");
+              base_cols.assign(bc, bc + nbc); nb1 = nbc;
+            }
+            if (save_model(est, f * ncol + j, mfn.c_str(), names) != KLR_OK) die("failed");
+          }
           say(1, "done\n");
         }
       }

@@ -72,6 +72,7 @@ struct klr_estimator {
   // KmerLrFeatures parameters
   std::vector<klr_iter_rec> recs;     // scratch of solve_reduced
   std::vector<klr_estimator*> folds;  // estimators of the last cross-validation / ensemble, one per fold (klr_estimator_fold)
+  std::vector<int64_t> base_cols;     // a fold with its own co-preselection: the columns of the data its pair matrix was built from
   bool has_kmer = false;
   klr_kmer_features kf{};
   std::vector<int> kf_max_amb;
@@ -129,6 +130,13 @@ extern "C" void klr_estimator_destroy(klr_estimator* e) {
 extern "C" klr_estimator* klr_estimator_fold(const klr_estimator* e, int fold) {
   if (!e || fold < 0 || fold >= (int)e->folds.size()) return nullptr;
   return e->folds[(size_t)fold];
+}
+
+extern "C" int klr_estimator_base_cols(const klr_estimator* e, const int64_t** cols, int64_t* n) {
+  if (!e) return KLR_EINVAL;
+  if (cols) *cols = e->base_cols.empty() ? nullptr : e->base_cols.data();
+  if (n) *n = (int64_t)e->base_cols.size();
+  return KLR_OK;
 }
 
 // a fresh estimator for a fold or ensemble member: the configuration AND the starting model of `e`
@@ -434,6 +442,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
     return KLR_OK;
   };
   const int E = std::max(1, e->cfg.ensemble_size);
+  const bool copre = e->cfg.cooccurrence && e->cfg.copreselection > 0 && e->cfg.copreselection < dim - 1;
   // {Kmer,Scores}LrEnsemble.Summarize (kmerLr_classifier_ensemble.go:64-104)
   auto summarize = [&](const std::vector<double>& x) -> double {
     if (x.empty()) return NAN;
@@ -446,6 +455,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       default: r = 0.0; for (double v : x) r += v; return r / (double)x.size();
     }
   };
+  klr_mat* fold_ex = nullptr;          // the pair matrix of the fold at hand (co-preselection inside the fold)
   for (int f = 0; f < nfold && rc == KLR_OK; f++) {
     const int32_t ff = f;             // without folds every group id is -1: no row is a test row (crossvalidation :183-186)
     // the three row sets of fold f over the WHOLE data set (filterCvGroup :96-120): test, validation, training
@@ -469,6 +479,37 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
     klr_estimator* fe = fresh_like(e);
     if (!fe) { rc = fail(e, KLR_EINVAL, "cannot create fold estimator"); break; }
     e->folds.push_back(fe);
+    // Co-preselection inside the fold ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:99-115): `data`
+    // is the BASE matrix; on the fold's training rows a first leapfrog run without co-occurrence picks cfg.copreselection
+    // features (transform: the one fitted above on the training + test rows, or the caller's), the base data are restricted
+    // to them and the pair matrix of that restriction takes the place of the data for the rest of the fold; its own
+    // transform is fitted on its training + test rows (:116-117).
+    klr_mat* data_f = data;
+    int64_t dim_f = dim;
+    std::vector<double> xsc, xof;
+    if (copre) {
+      for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i);
+      if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_train) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+      fe->base_cols.assign((size_t)dim, 0);
+      int64_t nb1 = 0;
+      char eb[512] = "";
+      klr_config c1 = e->cfg; c1.verbose = 0;
+      rc = klr_cooccurrence_prepare(&e->be, &c1, data, sc, of, &fold_ex, fe->base_cols.data(), &nb1, eb, sizeof(eb));
+      if (rc != KLR_OK) { fail(e, rc, "co-preselection of fold %d failed: %s", f + 1, eb); break; }
+      fe->base_cols.resize((size_t)nb1);
+      data_f = fold_ex;
+      if (e->be.mat_shape(data_f, nullptr, &dim_f, nullptr, nullptr) != KLR_OK) { rc = fail(e, KLR_EINVAL, "bad pair matrix"); break; }
+      sc = nullptr; of = nullptr;
+      if (e->cfg.data_transform != 0) {
+        if (!e->be.transform_fit) { rc = fail(e, KLR_EINVAL, "co-preselection per fold with a data transform needs a backend that can fit it"); break; }
+        for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_val(i);
+        if (e->be.set_active_rows(e->be.ctx, data_f, mask.data(), n_train + n_test) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+        xsc.assign((size_t)dim_f, 0.0); xof.assign((size_t)dim_f, 0.0);
+        int has_off = 0;
+        if (e->be.transform_fit(e->be.ctx, data_f, e->cfg.data_transform, xsc.data(), xof.data(), &has_off) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "transform_fit"); break; }
+        sc = xsc.data(); of = has_off ? xof.data() : nullptr;
+      }
+    }
     // member groups (estimate_ensemble :75): getCvGroups over the TRAINING rows in data order; member k trains on the
     // training rows whose group is not k.  A local row's position among all training rows comes from the global arrays.
     std::vector<int32_t> wgrp;
@@ -490,7 +531,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       int64_t n_k = n_train;
       if (E > 1) { n_k = 0; for (int32_t g : wgrp) if (g != k) n_k++; }
       for (int64_t i = 0; i < n; i++) mask[(size_t)i] = !is_test(i) && !is_val(i) && (E == 1 || wgrp[(size_t)tpos[(size_t)i]] != k);
-      if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_k) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+      if (e->be.set_active_rows(e->be.ctx, data_f, mask.data(), n_k) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
       klr_estimator* me = fe;
       if (E > 1) {
         me = fresh_like(e);
@@ -498,7 +539,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
         fe->folds.push_back(me);
       }
       members.push_back(me);
-      rc = klr_estimator_estimate(me, data, lambda_auto, nla, sc, of);
+      rc = klr_estimator_estimate(me, data_f, lambda_auto, nla, sc, of);
       if (rc != KLR_OK) { e->err = me->err; break; }
       for (auto& r : me->trace) { e->trace.push_back(r); if (E > 1) fe->trace.push_back(r); }
     }
@@ -509,7 +550,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
     for (int k = 0; k < E && rc == KLR_OK; k++)
       for (size_t j = 0; j < ncls && rc == KLR_OK; j++) {
         const Classifier& c = members[(size_t)k]->out[j];
-        if (e->be.select_columns(e->be.ctx, data, c.cols.data(), (int64_t)c.cols.size(), c.scale.empty() ? nullptr : c.scale.data(),
+        if (e->be.select_columns(e->be.ctx, data_f, c.cols.data(), (int64_t)c.cols.size(), c.scale.empty() ? nullptr : c.scale.data(),
                                  c.offset.empty() ? nullptr : c.offset.data(), &reds[(size_t)k * ncls + j]) != KLR_OK) rc = be_fail(e, KLR_EHIP, "select_columns");
       }
     // the ensemble's loss on a row set: the summary of its members' losses (KmerLrEnsemble.Loss :108-123)
@@ -564,6 +605,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       }
     }
     for (klr_mat* r : reds) if (r) e->be.mat_destroy(r);
+    if (fold_ex) { e->be.mat_destroy(fold_ex); fold_ex = nullptr; }
     if (rc != KLR_OK) break;
     // what the fold keeps: member-major, kept classifier jo of member k at k * n_kept + jo
     {
@@ -573,6 +615,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       for (const Classifier& c : kept) all_cls.push_back(c);
     }
   }
+  if (fold_ex) e->be.mat_destroy(fold_ex);
   e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
   if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j (f alone with a validation
                                                  // set); with an ensemble the folds' member-major lists one after the other

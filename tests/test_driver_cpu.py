@@ -442,3 +442,51 @@ def test_crossvalidation_with_ensembles(summary):
                 lv = [-np.mean([O.class_log_pdf(x, i, t, labels[i]) for i in rows]) for t in full]
                 assert abs(r[key][j, f] - comb(lv)) < 1e-9
     OD.free_matrix(h)
+
+
+def _rows_subset(x, rows):
+    rp, col, val = [0], [], []
+    for i in rows:
+        s, e = x.rowptr[i], x.rowptr[i + 1]
+        col += list(x.col[s:e]); val += list(x.val[s:e]); rp.append(len(col))
+    return O.Csr(len(rows), x.dim, rp, col, val)
+
+
+def test_crossvalidation_with_copreselection_inside_the_folds():
+    """--co-occurrence --co-preselection=q together with --k-fold-cv: every fold pre-selects on ITS training rows
+    ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:99-115) == the explicit run on the filtered
+    rows; the fold's estimator reports the base columns of its pair matrix."""
+    from kmerlr_amd import _driver as D
+    x, labels = O.synth_csr(33, 0, 90, 90, 40, 18, 6)
+    h = OD.matrix(x, labels)
+    L = OD.lib()
+    q, k, la = 5, 3, [2, 4]
+    est = OD.estimator(cooccurrence=1, copreselection=q)
+    r = est.crossvalidate(h, x.n, k, la, seed=5)
+    groups = r["groups"]
+    assert len(r["classifiers"]) == k * len(la)
+    seen = set()
+    for f in range(k):
+        tr = np.nonzero(groups != f)[0]; te = np.nonzero(groups == f)[0]
+        xs = _rows_subset(x, tr)
+        hs = OD.matrix(xs, labels[tr])
+        e2 = OD.estimator(cooccurrence=1, copreselection=q)
+        exp_h, base_cols = D.cooccurrence_prepare(L, e2.backend, e2.cfg, hs, x.dim)
+        cs = e2.estimate(exp_h, la)
+        OD.free_matrix(exp_h); OD.free_matrix(hs)
+        np.testing.assert_array_equal(est.fold(f).base_cols(), base_cols)
+        assert len(base_cols) == q + 1
+        seen.add(tuple(base_cols))
+        # the whole data's pair matrix on the fold's base columns: predictions of the test rows
+        ex = O.expand_cooccurrence(O.select_columns(x, base_cols))
+        for j in range(len(la)):
+            c = r["classifiers"][f * len(la) + j]
+            np.testing.assert_array_equal(c["cols"], cs[j]["cols"])
+            np.testing.assert_allclose(c["theta"], cs[j]["theta"], rtol=1e-9, atol=1e-13)
+            theta_full = np.zeros(ex.dim); theta_full[c["cols"]] = c["theta"]
+            pred = np.array([O.class_log_pdf(ex, i, theta_full, 1) for i in te])
+            np.testing.assert_allclose(r["predictions"][j, te], pred, rtol=1e-12)
+            ls = -np.mean([O.class_log_pdf(ex, i, theta_full, labels[i]) for i in te])
+            assert abs(r["loss_test"][j, f] - ls) < 1e-12
+    assert len(seen) > 1, "the folds should not all pre-select the same features on this data"
+    OD.free_matrix(h)

@@ -206,6 +206,48 @@ def test_scores3_copreselection_cli(tmp_path):
     OD.free_matrix(exp_h); OD.free_matrix(h)
 
 
+def test_copreselection_inside_folds_cli(tmp_path):
+    # --co-occurrence --co-preselection=q with --k-fold-cv: the pre-selection runs on every fold's training rows
+    # (kmerLr_estimator_ensemble.go:99-115); models, pairs and tables against the oracle-served driver on the same tables
+    rng = np.random.default_rng(17)
+    n1, n0, m = 40, 40, 10
+    xf = rng.gamma(2.0, 1.0, (n1, m)); xf[:, 2] += 1.0; xf[:, 5] *= 1.5; xf[:, 7] += 0.5 * xf[:, 2]
+    xb = rng.gamma(2.0, 1.0, (n0, m))
+    for name, a in (("fg.table", xf), ("bg.table", xb)):
+        with open(tmp_path / name, "w") as f:
+            for r in a:
+                f.write(",".join(repr(float(v)) for v in r) + "\n")
+    _, xf = O.read_scores_table(str(tmp_path / "fg.table")); _, xb = O.read_scores_table(str(tmp_path / "bg.table"))
+    dense = np.concatenate([xf, xb]); labels = np.array([1] * n1 + [0] * n0, dtype=np.uint8)
+    q, k, la = 4, 2, [2, 3]
+    run(["--type=scoresLr", "learn", "--lambda-auto=2,3", "--co-occurrence", "--co-preselection=%d" % q, "--k-fold-cv=%d" % k, "--seed=3",
+         "fg.table", "bg.table", "cc"], tmp_path)
+    x = O.Csr.from_dense(dense)
+    h = OD.matrix(x, labels)
+    est = OD.estimator(cooccurrence=1, copreselection=q)
+    r = est.crossvalidate(h, x.n, k, la, seed=3)
+    for f in range(k):
+        base_cols = est.fold(f).base_cols()
+        for j, l in enumerate(la):
+            mjs = json.load(open(tmp_path / ("cc_cv%d_%d.json" % (f + 1, l))))
+            c = r["classifiers"][f * len(la) + j]
+            pairs = []
+            for col in c["cols"][1:]:
+                k1, k2 = O.coeff_sub2ind(q, int(col) - 1)
+                pairs.append((int(base_cols[k1 + 1] - 1), int(base_cols[k2 + 1] - 1)))
+            idx = mjs["Parameters"]["Index"]
+            assert [(idx[a], idx[b]) for a, b in mjs["Parameters"]["Features"]] == pairs
+            assert mjs["Parameters"]["Cooccurrence"] is True
+            np.testing.assert_allclose(mjs["Distributions"][0]["Parameters"], c["theta"], rtol=1e-6, atol=1e-9)
+    for j, l in enumerate(la):
+        t = open(tmp_path / ("cc_%d.table" % l)).read().splitlines()[1:]
+        order = [i for g in range(k) for i in range(x.n) if r["groups"][i] == g]
+        np.testing.assert_allclose([float(v.split("\t")[0]) for v in t], r["predictions"][j, order], rtol=1e-5, atol=1e-9)
+        lt = open(tmp_path / ("cc_%d_loss.table" % l)).read().splitlines()[1:]
+        np.testing.assert_allclose([float(v.split("\t")[1]) for v in lt], r["loss_test"][j], rtol=1e-5)
+    OD.free_matrix(h)
+
+
 def test_ensemble_cli(tmp_path):
     # learn --ensemble-size=3 (kmerLr_learn.go:129-130, estimate_ensemble): one model with 3 coefficient vectors;
     # predict / loss summarise the members (Summarize, kmerLr_classifier_ensemble.go:64-104)
