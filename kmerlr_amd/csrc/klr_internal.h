@@ -39,6 +39,7 @@ enum {
   WS_CD_G,         // Gram matrix
   WS_CD_VEC,       // xy, norm, theta, q, hist, deltas...
   WS_CD_LOSS,      // K losses (+ block partials)
+  WS_CD_CTL,       // {ticket, max bits} of k_irls_finish: zeroed when allocated, the kernel leaves it zero
   WS_TMP0,
   WS_TMP1,
   WS_TMP2,

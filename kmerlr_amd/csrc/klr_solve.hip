@@ -1215,27 +1215,49 @@ struct CdlLane { double xy0, xy1, dg0, dg1, inv0, inv1; };
 // stage the Gram matrix and the start iterate (all threads of the block), then __syncthreads
 __device__ __forceinline__ void cdl_stage(const CdArgs& a, const CdTheta& th0, double* Gl, double* pk) {
   const int d = a.d;
-#pragma unroll 4
-  for (int t = threadIdx.x; t < (d + 1) * CDL_STRIDE; t += blockDim.x) {
-    const int j = t >> 7, i = t & (CDL_STRIDE - 1);
-    Gl[t] = (j < d && i < d) ? a.G[(i64)j * d + i] : 0.0;
+  // ALL loads of a thread in flight at once (d <= 128: at most 17): the Gram matrix was written a moment ago by workgroups
+  // all over the chip, so the first batch of a re-linearisation fetches it from memory -- one trip instead of four
+  const int total = (d + 1) * CDL_STRIDE;
+  constexpr int NLD = ((128 + 1) * CDL_STRIDE + 1023) / 1024;
+  double v[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int t = (int)threadIdx.x + u * 1024, j = t >> 7, i = t & (CDL_STRIDE - 1);
+    v[u] = (t < total && j < d && i < d) ? a.G[(i64)j * d + i] : 0.0;
   }
+#pragma unroll
+  for (int u = 0; u < NLD; u++) { const int t = (int)threadIdx.x + u * 1024; if (t < total) Gl[t] = v[u]; }
   for (int t = threadIdx.x; t < 4 * (d + 1); t += blockDim.x)
     pk[t] = ((t & 3) == 3 && (t >> 2) < d) ? (th0.n > 0 ? th0.v[t >> 2] : a.theta[t >> 2]) : 0.0;
   __syncthreads();
 }
 
 // per-lane constants and q = G theta (skipping zero coefficients); one wavefront
-__device__ __forceinline__ void cdl_init(const CdArgs& a, int lane, const double* Gl, const double* pk, CdlLane& c,
-                                         double& q0, double& q1) {
+__device__ __forceinline__ void cdl_init(const CdArgs& a, int lane, const double* Gl, const double* pk, double xy0, double xy1,
+                                         CdlLane& c, double& q0, double& q1) {
   const int d = a.d, i0 = lane, i1 = 64 + lane;
-  c.xy0 = i0 < d ? a.xy[i0] : 0.0; c.xy1 = i1 < d ? a.xy[i1] : 0.0;
+  c.xy0 = xy0; c.xy1 = xy1;
   c.dg0 = i0 < d ? Gl[(size_t)i0 * CDL_STRIDE + i0] : 1.0; c.dg1 = i1 < d ? Gl[(size_t)i1 * CDL_STRIDE + i1] : 1.0;
   c.inv0 = 1.0 / (c.dg0 + a.l2reg); c.inv1 = 1.0 / (c.dg1 + a.l2reg);      // :69 as a reciprocal (<= 1 ulp)
   q0 = 0.0; q1 = 0.0;
-  for (int k = 0; k < d; k++) {
-    const double t = pk[4 * k + 3];
-    if (t != 0.0) { q0 += Gl[(size_t)k * CDL_STRIDE + i0] * t; q1 += Gl[(size_t)k * CDL_STRIDE + i1] * t; }
+  if (a.q_load) return;                                    // a later batch of the same inner loop: q comes from q_io
+  // theta in registers (lane l: coordinates l and 64 + l), picked out with v_readlane: the chain is the two additions,
+  // not an LDS round trip per coordinate.  Zero coefficients are skipped as before (same sums, same order).
+  const double tA = i0 < d ? pk[4 * i0 + 3] : 0.0, tB = i1 < d ? pk[4 * i1 + 3] : 0.0;
+  for (int k0 = 0; k0 < d; k0 += 4) {
+    double g0[4], g1[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {                          // row d is staged as zeros
+      const int kk = k0 + u < d ? k0 + u : d;
+      g0[u] = Gl[(size_t)kk * CDL_STRIDE + i0]; g1[u] = Gl[(size_t)kk * CDL_STRIDE + i1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + u;
+      const double t = k < d ? bcast_lane(k < 64 ? tA : tB, k & 63) : 0.0;
+      const double a0 = q0 + g0[u] * t, a1 = q1 + g1[u] * t;
+      q0 = t != 0.0 ? a0 : q0; q1 = t != 0.0 ? a1 : q1;
+    }
   }
 }
 
@@ -1318,14 +1340,18 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
   const int d = a.d, lane = threadIdx.x & 63;
   double* Gl = lds;                                         // (d+1) x 128
   double* pk = lds + (size_t)(d + 1) * CDL_STRIDE;          // (d+1) x 4
+  const int i0 = lane, i1 = 64 + lane;
+  // this lane's xy and (a later batch of the same inner loop) q are requested beside the Gram matrix, not after it
+  const double xy0 = i0 < d ? a.xy[i0] : 0.0, xy1 = i1 < d ? a.xy[i1] : 0.0;
+  double qin0 = 0.0, qin1 = 0.0;
+  if (a.q_load) { qin0 = i0 < d ? a.q_io[i0] : 0.0; qin1 = i1 < d ? a.q_io[i1] : 0.0; }
   cdl_stage(a, th0, Gl, pk);
   if (threadIdx.x >= 64) return;                       // the sweeps are one wavefront's work
   CdlLane c; double q0, q1;
-  cdl_init(a, lane, Gl, pk, c, q0, q1);
-  const int i0 = lane, i1 = 64 + lane;
+  cdl_init(a, lane, Gl, pk, xy0, xy1, c, q0, q1);
   // a later batch of the same inner loop continues with the q it left (re-forming q = G theta from theta rounds
   // differently: the results would depend on where the batches end)
-  if (a.q_load) { q0 = i0 < d ? a.q_io[i0] : 0.0; q1 = i1 < d ? a.q_io[i1] : 0.0; }
+  if (a.q_load) { q0 = qin0; q1 = qin1; }
   int zero_v;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));      // opaque: keeps the operand pointer in a vector register
   int done = 0;
@@ -1352,8 +1378,10 @@ __global__ __launch_bounds__(1024) void k_cd_lds2(CdArgs a, CdTheta th0) {
 // iterates are staged in LDS as [column][k].  32 rows per block, block partials in a fixed order.
 #define LM_THREADS 1024                 // 128 rows per block: the iterates are staged once per 128 rows
 #define LM_ROWS (LM_THREADS / KSPEC)
-template <bool LDS>
-__global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
+// TPB: threads per block -- 1024 for a batch (the iterates are staged once per 128 rows), 256 for a probe batch of one
+// sweep (a lane per row: 1024 rows per block would leave 98 blocks for 256 CUs at configs[2])
+template <bool LDS, int TPB = LM_THREADS>
+__global__ __launch_bounds__(TPB) void k_loss_multi(const i64* __restrict__ rowptr, const u32* __restrict__ col,
                                                     const double* __restrict__ val, const uint8_t* __restrict__ labels,
                                                     const uint8_t* __restrict__ active,
                                                     i64 n, int d, const double* __restrict__ hist, const int* __restrict__ ndone,
@@ -1361,18 +1389,18 @@ __global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict
   // kl = 1 << kl_log2 lanes per row (the batch holds at most kl iterates): a probe batch of one sweep keeps every
   // lane on a row of its own -- the exp / log1p chain costs a wavefront the same whether 1 or 8 of 8 lanes need it
   extern __shared__ double lm_lds[];            // KSPEC * d iterates, layout [column][k]
-  __shared__ double sh[KSPEC][LM_THREADS / 64];
+  __shared__ double sh[KSPEC][TPB / 64];
   const int K = *ndone;
   const int kl = 1 << kl_log2;
   if (LDS) {
-    for (int t = threadIdx.x; t < KSPEC * d; t += LM_THREADS) {
+    for (int t = threadIdx.x; t < KSPEC * d; t += TPB) {
       const int c = t / KSPEC, k = t % KSPEC;
       lm_lds[t] = k < K ? hist[(i64)k * d + c] : 0.0;
     }
     __syncthreads();
   }
   const int k = threadIdx.x & (kl - 1);
-  const i64 i = (i64)blockIdx.x * (LM_THREADS >> kl_log2) + (threadIdx.x >> kl_log2);
+  const i64 i = (i64)blockIdx.x * (TPB >> kl_log2) + (threadIdx.x >> kl_log2);
   double term = 0.0;
   if (i < n && k < K && (!active || active[i])) {
     const i64 b = rowptr[i], e = rowptr[i + 1];
@@ -1399,7 +1427,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_loss_multi(const i64* __restrict
   __syncthreads();
   if (threadIdx.x < KSPEC) {
     double acc = 0.0;
-    if ((int)threadIdx.x < kl) for (int ww = 0; ww < LM_THREADS / 64; ww++) acc += sh[threadIdx.x][ww];
+    if ((int)threadIdx.x < kl) for (int ww = 0; ww < TPB / 64; ww++) acc += sh[threadIdx.x][ww];
     blk[(i64)blockIdx.x * KSPEC + threadIdx.x] = acc;
   }
 }
@@ -1507,9 +1535,15 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   double* a0 = vec; double* nm = a0 + d; double* xy = nm + d; double* thd = xy + d + 2; double* hist = thd + d;
   double* delta = hist + (size_t)KSPEC * d; double* losses = delta + KSPEC; double* gsc = losses + KSPEC;
   int* stopf = (int*)(gsc + 2); int* ndone = stopf + KSPEC;
-  unsigned long long* fin_ctl = (unsigned long long*)(stopf + KSPEC + 8);     // {ticket, max bits} of k_irls_finish
-  KLR_HIP(ctx, hipMemsetAsync(fin_ctl, 0, 16, st));
-  double* q_dev = (double*)(fin_ctl + 2);                                      // q = G theta between batches (k_cd_wave)
+  // {ticket, max bits} of k_irls_finish, which resets both: zeroed once, when the block is allocated (a memset per call
+  // was 5 us at the head of every epoch)
+  unsigned long long* fin_ctl;
+  {
+    const bool fresh = ctx->ws[WS_CD_CTL].p == nullptr;
+    KLR_TRY(ws_get(ctx, WS_CD_CTL, 64, (void**)&fin_ctl));
+    if (fresh) KLR_HIP(ctx, hipMemsetAsync(fin_ctl, 0, 64, st));
+  }
+  double* q_dev = (double*)((unsigned long long*)(stopf + KSPEC + 8) + 2);     // q = G theta between batches (k_cd_wave)
   double* sb_th0 = q_dev + d; double* sb_dl = sb_th0 + d; int* sb_halt = (int*)(sb_dl + SBW * 64);   // super-block solver
   const size_t report_bytes = ((size_t)KSPEC * d + 2 * KSPEC + 2) * 8 + (KSPEC + 1) * sizeof(int);
   char* pin_report;
@@ -1685,8 +1719,16 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         // stages KSPEC * d values but uses ~KSPEC * 32 * (row length) of them
         int kl_log2 = 0;
         while ((1 << kl_log2) < Kb) kl_log2++;
-        const i64 nbl = std::max<i64>(1, ceil_div(n, (i64)(LM_THREADS >> kl_log2)));
-        if ((double)d <= (double)LM_ROWS * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024)
+        const bool lm_small = kl_log2 == 0 && n >= 64 * 256;         // a probe batch: blocks of 256 rows
+        const i64 nbl = std::max<i64>(1, ceil_div(n, (i64)((lm_small ? 256 : LM_THREADS) >> kl_log2)));
+        const bool lm_lds = (double)d <= (double)LM_ROWS * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024;
+        if (lm_small && lm_lds)
+          hipLaunchKernelGGL((k_loss_multi<true, 256>), dim3((unsigned)nbl), dim3(256), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
+                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
+        else if (lm_small)
+          hipLaunchKernelGGL((k_loss_multi<false, 256>), dim3((unsigned)nbl), dim3(256), 0, st, red->rowptr, red->col,
+                             (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
+        else if (lm_lds)
           hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nbl), dim3(LM_THREADS), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
         else
