@@ -171,6 +171,11 @@ int  klr_estimator_estimate_ensemble(klr_estimator* est, klr_mat* data, int64_t 
  * one coefficient vector per member over that union, the shared transform; Name = "<type> [<summary>]". */
 int  klr_estimator_save_ensemble(const klr_estimator* est, int64_t j, int ensemble_size, int64_t n_lambda_auto,
                                  const char* filename, const char* type_name, const char* const* names, const char* summary);
+/* The same for members trained on a pair matrix (cfg.cooccurrence): base_cols / nb1 as klr_cooccurrence_prepare or
+ * klr_estimator_base_cols report them; the file's Index holds the original features, Features the pair of every column. */
+int  klr_estimator_save_ensemble_pairs(const klr_estimator* est, int64_t j, int ensemble_size, int64_t n_lambda_auto,
+                                       const char* filename, const char* type_name, const char* const* names, const char* summary,
+                                       const int64_t* base_cols, int64_t n_base_cols);
 
 /* Co-occurrence set-up ({Kmer,Scores}LrEstimatorEnsemble.Estimate, kmerLr_estimator_ensemble.go:98-117,
  * scoresLr_estimator_ensemble.go:98-117).  With cfg.copreselection = q > 0 a first estimate_loop with lambda_auto = q

@@ -70,6 +70,8 @@ def bind_driver(L):
     L.klr_estimator_estimate_ensemble.argtypes = [vp, vp, i64, i64, C.c_int, i64, vp, i64, vp, vp]
     L.klr_estimator_save_ensemble.restype = C.c_int
     L.klr_estimator_save_ensemble.argtypes = [vp, i64, C.c_int, i64, C.c_char_p, C.c_char_p, vp, C.c_char_p]
+    L.klr_estimator_save_ensemble_pairs.restype = C.c_int
+    L.klr_estimator_save_ensemble_pairs.argtypes = [vp, i64, C.c_int, i64, C.c_char_p, C.c_char_p, vp, C.c_char_p, vp, i64]
     L.klr_cooccurrence_prepare.restype = C.c_int
     L.klr_cooccurrence_prepare.argtypes = [C.POINTER(Backend), C.POINTER(Config), vp, vp, vp, C.POINTER(vp), vp, C.POINTER(i64),
                                            C.c_char_p, i64]
@@ -193,6 +195,16 @@ class Estimator:
             arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
         self._check(self.L.klr_estimator_save_ensemble(self._h, j, ensemble_size, n_lambda_auto, filename.encode(), type_name.encode(),
                                                        None if arr is None else C.cast(arr, C.c_void_p), summary.encode()))
+
+    def save_ensemble_pairs(self, j, ensemble_size, n_lambda_auto, filename, base_cols, type_name="scoresLr", names=None, summary="mean"):
+        """An ensemble of co-occurrence models: base_cols as cooccurrence_prepare / base_cols() report them."""
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * len(names))(*[s.encode() for s in names])
+        bc = np.ascontiguousarray(base_cols, dtype=np.int64)
+        self._check(self.L.klr_estimator_save_ensemble_pairs(self._h, j, ensemble_size, n_lambda_auto, filename.encode(), type_name.encode(),
+                                                             None if arr is None else C.cast(arr, C.c_void_p), summary.encode(),
+                                                             bc.ctypes.data, len(bc)))
 
     def classifiers(self):
         out = []

@@ -390,19 +390,24 @@ static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& 
   }
   std::sort(order.begin(), order.end());
   std::vector<int64_t> ecols{0};
-  std::vector<double> th{theta[0]}, sc, of;
+  std::vector<double> sc, of;
   if (!scale.empty()) sc.push_back(scale[0]);
   if (!offset.empty()) of.push_back(offset[0]);
   for (auto& pr : order) {
-    ecols.push_back(pr.first); th.push_back(theta[pr.second + 1]);
+    ecols.push_back(pr.first);
     if (!scale.empty()) sc.push_back(scale[pr.second + 1]);
     if (!offset.empty()) of.push_back(offset[pr.second + 1]);
+  }
+  // every member's coefficients in the order of the selected pair columns
+  for (auto& mt : members) {
+    if (mt.size() != nf + 1) die("invalid config file");
+    std::vector<double> th{mt[0]};
+    for (auto& pr : order) th.push_back(mt[pr.second + 1]);
+    mt = th;
   }
   if (klr_mat_select_columns(ctx, ex, ecols.data(), (int64_t)ecols.size(), sc.empty() ? nullptr : sc.data(), of.empty() ? nullptr : of.data(), &red) != KLR_OK)
     die("%s", klr_last_error(ctx));
   klr_mat_destroy(ex); klr_mat_destroy(base);
-  if (members.size() != 1) die("co-occurrence ensembles are not part of this build");
-  theta = th;
   return red;
 }
 
@@ -667,7 +672,6 @@ int main(int argc, char** argv) {
     cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;
     cfg.copreselection = opt_int(o, "co-preselection", "0");
     if (cfg.copreselection != 0 && !cfg.cooccurrence) die("--co-preselection needs --co-occurrence");
-    if (ensemble > 1 && cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
 
     // positionals: <M> <N> | <MODEL.json>, FG, BG, BASENAME (kmerLr_learn.go:153-189; scoresLr: [MODEL.json] FG BG BASENAME)
     DataSet d;
@@ -850,8 +854,16 @@ int main(int argc, char** argv) {
           say(1, "Exporting model to `%s'... ", mfn.c_str());
           if (ensemble > 1) {
             // the fold's estimator holds its members' classifiers member-major ({Kmer,Scores}LrEnsemble of the fold)
-            if (cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
-            if (!fe || klr_estimator_save_ensemble(fe, j, ensemble, ncol, mfn.c_str(), scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
+            if (!fe) die("failed");
+            if (cfg.cooccurrence) {
+              if (fold_copre) {
+                const int64_t* bc = nullptr; int64_t nbc = 0;
+                if (klr_estimator_base_cols(fe, &bc, &nbc) != KLR_OK || nbc < 1) die("failed");
+                base_cols.assign(bc, bc + nbc); nb1 = nbc;
+              }
+              if (klr_estimator_save_ensemble_pairs(fe, j, ensemble, ncol, mfn.c_str(), scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
+                                                    summary.c_str(), base_cols.data(), nb1) != KLR_OK) die("failed");
+            } else if (klr_estimator_save_ensemble(fe, j, ensemble, ncol, mfn.c_str(), scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
                                                    summary.c_str()) != KLR_OK) die("failed");
           } else {
             if (fold_copre) {                                            // the pairs are those of the fold's own pre-selection
@@ -891,7 +903,6 @@ int main(int argc, char** argv) {
       _exit(0);
     }
     if (ensemble > 1) {
-      if (cfg.cooccurrence) die("--ensemble-size together with --co-occurrence is not part of this build");
       if (klr_estimator_estimate_ensemble(est, mat, row0, n_all, ensemble, seed, la.data(), (int64_t)la.size(), scale.empty() ? nullptr : scale.data(),
                                           offset.empty() ? nullptr : offset.data()) != KLR_OK)
         die("%s", klr_estimator_error(est));
@@ -906,8 +917,11 @@ int main(int argc, char** argv) {
       else snprintf(fn, sizeof(fn), "%s_%lld.json", base.c_str(), (long long)la[(size_t)i]);
       say(1, "Exporting model to `%s'... ", fn);
       if (ensemble > 1) {
-        if (klr_estimator_save_ensemble(est, i, ensemble, nc, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
-                                        summary.c_str()) != KLR_OK) die("failed");
+        if (cfg.cooccurrence) {
+          if (klr_estimator_save_ensemble_pairs(est, i, ensemble, nc, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
+                                                summary.c_str(), base_cols.data(), nb1) != KLR_OK) die("failed");
+        } else if (klr_estimator_save_ensemble(est, i, ensemble, nc, fn, scores ? "scoresLr" : "kmerLr", names.empty() ? nullptr : names.data(),
+                                               summary.c_str()) != KLR_OK) die("failed");
       } else if (save_model(est, i, fn, names) != KLR_OK) die("failed");
       say(1, "done\n");
     }

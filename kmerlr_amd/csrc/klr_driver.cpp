@@ -899,8 +899,36 @@ extern "C" int klr_estimator_estimate_ensemble(klr_estimator* e, klr_mat* data, 
   return rc;
 }
 
+static int save_ensemble_common(const klr_estimator* e, int64_t j, int ensemble_size, int64_t nla, const char* filename,
+                                const char* type_name, const char* const* names, const char* summary, const int64_t* base_cols, int64_t nb1);
+
+// CoeffIndex.Sub2Ind (kmerLr_coefficients_index.go:41-54; the library's klr_coeff_sub2ind, restated here because the driver
+// is also built without the HIP library): column i of the pair matrix of n features -> (k1, k2), k1 <= k2
+static void pair_of_column(int64_t n, int64_t i, int64_t* k1, int64_t* k2) {
+  if (i < n) { *k1 = i; *k2 = i; return; }
+  i -= n;
+  const int64_t a = n - 2 - (int64_t)std::floor(std::sqrt((double)(-8 * i + 4 * n * (n - 1) - 7)) / 2.0 - 0.5);
+  *k1 = a;
+  *k2 = i + a + 1 - n * (n - 1) / 2 + (n - a) * ((n - a) - 1) / 2;
+}
+
 extern "C" int klr_estimator_save_ensemble(const klr_estimator* e, int64_t j, int ensemble_size, int64_t nla, const char* filename,
                                            const char* type_name, const char* const* names, const char* summary) {
+  return save_ensemble_common(e, j, ensemble_size, nla, filename, type_name, names, summary, nullptr, 0);
+}
+
+// an ensemble of co-occurrence models: the members' columns are columns of the pair matrix of base_cols (nb1 columns incl.
+// the bias, as klr_cooccurrence_prepare / klr_estimator_base_cols report them); Index holds the original features, Features
+// the pair of every kept column (KmerLrFeatures of a co-occurrence ensemble, kmerLr_features.go:222-250)
+extern "C" int klr_estimator_save_ensemble_pairs(const klr_estimator* e, int64_t j, int ensemble_size, int64_t nla, const char* filename,
+                                                 const char* type_name, const char* const* names, const char* summary,
+                                                 const int64_t* base_cols, int64_t nb1) {
+  if (!base_cols || nb1 < 2) return KLR_EINVAL;
+  return save_ensemble_common(e, j, ensemble_size, nla, filename, type_name, names, summary, base_cols, nb1);
+}
+
+static int save_ensemble_common(const klr_estimator* e, int64_t j, int ensemble_size, int64_t nla, const char* filename,
+                                const char* type_name, const char* const* names, const char* summary, const int64_t* base_cols, int64_t nb1) {
   if (!e || !filename || ensemble_size < 1 || nla < 1 || j < 0 || j >= nla || (int64_t)e->out.size() < (int64_t)ensemble_size * nla)
     return KLR_EINVAL;
   // union of the members' features with a non-zero coefficient (AddKmerLr :277-286), ascending
@@ -918,7 +946,23 @@ extern "C" int klr_estimator_save_ensemble(const klr_estimator* e, int64_t j, in
   if (!f) return KLR_EINVAL;
   std::string name = type_name ? type_name : "scoresLr";
   if (summary && *summary) name += std::string(" [") + summary + "]";
-  {
+  if (base_cols) {
+    std::vector<int64_t> f1(nf), f2(nf), index;
+    for (size_t k = 0; k < nf; k++) {
+      int64_t k1 = 0, k2 = 0;
+      if (uni[k] < 1 || uni[k] - 1 >= (nb1 - 1) * nb1 / 2) { fclose(f); return KLR_EINVAL; }
+      pair_of_column(nb1 - 1, uni[k] - 1, &k1, &k2);
+      if (k1 < 0 || k2 < k1 || k2 + 1 >= nb1) { fclose(f); return KLR_EINVAL; }
+      f1[k] = base_cols[k1 + 1] - 1; f2[k] = base_cols[k2 + 1] - 1;
+      index.push_back(f1[k]); index.push_back(f2[k]);
+    }
+    std::sort(index.begin(), index.end());
+    index.erase(std::unique(index.begin(), index.end()), index.end());
+    auto pos = [&](int64_t v) { return (size_t)(std::lower_bound(index.begin(), index.end(), v) - index.begin()); };
+    std::vector<std::pair<size_t, size_t>> features(nf);
+    for (size_t k = 0; k < nf; k++) features[k] = {pos(f1[k]), pos(f2[k])};
+    write_head(f, e, name, true, index, features, names);
+  } else {
     std::vector<int64_t> index(nf);
     std::vector<std::pair<size_t, size_t>> features(nf);
     for (size_t k = 0; k < nf; k++) { index[k] = uni[k] - 1; features[k] = {k, k}; }

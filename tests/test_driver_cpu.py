@@ -490,3 +490,34 @@ def test_crossvalidation_with_copreselection_inside_the_folds():
             assert abs(r["loss_test"][j, f] - ls) < 1e-12
     assert len(seen) > 1, "the folds should not all pre-select the same features on this data"
     OD.free_matrix(h)
+
+
+def test_ensemble_of_cooccurrence_models_file(tmp_path):
+    """--ensemble-size with --co-occurrence --co-preselection: the members share one pair matrix; the model file lists the
+    original features (Index) and the pair of every kept column (Features), every member its coefficients over them."""
+    from kmerlr_amd import _driver as D
+    x, labels = O.synth_csr(35, 0, 90, 90, 40, 18, 6)
+    h = OD.matrix(x, labels)
+    L = OD.lib()
+    q, E = 5, 3
+    est = OD.estimator(cooccurrence=1, copreselection=q)
+    exp_h, base_cols = D.cooccurrence_prepare(L, est.backend, est.cfg, h, x.dim)
+    cls = est.estimate_ensemble(exp_h, x.n, E, [3], seed=4)
+    fn = str(tmp_path / "ens_co.json")
+    est.save_ensemble_pairs(0, E, 1, fn, base_cols, summary="mean")
+    m = json.load(open(fn))
+    assert m["Name"] == "scoresLr [mean]" and m["Parameters"]["Cooccurrence"] is True
+    idx, feats = m["Parameters"]["Index"], m["Parameters"]["Features"]
+    uni = sorted(set(int(cc) for c in cls for cc, t in zip(c["cols"][1:], c["theta"][1:]) if t != 0.0))
+    want = []
+    for col in uni:
+        k1, k2 = O.coeff_sub2ind(q, col - 1)
+        want.append((int(base_cols[k1 + 1] - 1), int(base_cols[k2 + 1] - 1)))
+    assert [(idx[a], idx[b]) for a, b in feats] == want
+    assert idx == sorted(set(v for pr in want for v in pr))
+    lr = [d for d in m["Distributions"] if d["Name"] == "vector:logistic regression"]
+    assert len(lr) == E
+    for k in range(E):
+        th = dict((int(cc), t) for cc, t in zip(cls[k]["cols"][1:], cls[k]["theta"][1:]))
+        np.testing.assert_allclose(lr[k]["Parameters"], [cls[k]["theta"][0]] + [th.get(u, 0.0) for u in uni], rtol=1e-15)
+    OD.free_matrix(exp_h); OD.free_matrix(h)

@@ -248,6 +248,53 @@ def test_copreselection_inside_folds_cli(tmp_path):
     OD.free_matrix(h)
 
 
+def test_ensemble_of_cooccurrence_models_cli(tmp_path):
+    # --ensemble-size=3 --co-occurrence --co-preselection=4: the members are trained on one pair matrix; the model lists
+    # the original features and the pairs, predict / loss summarise the members on the pair features
+    from kmerlr_amd import _driver as D
+    rng = np.random.default_rng(23)
+    n1, n0, m = 45, 45, 9
+    xf = rng.gamma(2.0, 1.0, (n1, m)); xf[:, 1] += 1.0; xf[:, 4] *= 1.6; xf[:, 6] += 0.5 * xf[:, 1]
+    xb = rng.gamma(2.0, 1.0, (n0, m))
+    for name, a in (("fg.table", xf), ("bg.table", xb)):
+        with open(tmp_path / name, "w") as f:
+            for r in a:
+                f.write(",".join(repr(float(v)) for v in r) + "\n")
+    _, xf = O.read_scores_table(str(tmp_path / "fg.table")); _, xb = O.read_scores_table(str(tmp_path / "bg.table"))
+    dense = np.concatenate([xf, xb]); labels = np.array([1] * n1 + [0] * n0, dtype=np.uint8)
+    q, E = 4, 3
+    run(["--type=scoresLr", "learn", "--lambda-auto=3", "--co-occurrence", "--co-preselection=%d" % q, "--ensemble-size=%d" % E,
+         "--ensemble-summary=mean", "--seed=7", "fg.table", "bg.table", "ec"], tmp_path)
+    mjs = json.load(open(tmp_path / "ec.json"))
+    assert mjs["Name"] == "scoresLr [mean]" and mjs["Parameters"]["Cooccurrence"] is True
+    x = O.Csr.from_dense(dense)
+    h = OD.matrix(x, labels)
+    est = OD.estimator(cooccurrence=1, copreselection=q)
+    exp_h, base_cols = D.cooccurrence_prepare(OD.lib(), est.backend, est.cfg, h, x.dim)
+    cls = est.estimate_ensemble(exp_h, x.n, E, [3], seed=7)
+    uni = sorted(set(int(cc) for c in cls for cc, t in zip(c["cols"][1:], c["theta"][1:]) if t != 0.0))
+    pairs = []
+    for col in uni:
+        k1, k2 = O.coeff_sub2ind(q, col - 1)
+        pairs.append((int(base_cols[k1 + 1] - 1), int(base_cols[k2 + 1] - 1)))
+    idx = mjs["Parameters"]["Index"]
+    assert [(idx[a], idx[b]) for a, b in mjs["Parameters"]["Features"]] == pairs
+    lr = [d for d in mjs["Distributions"] if d["Name"] == "vector:logistic regression"]
+    assert len(lr) == E
+    for k in range(E):
+        th = dict((int(cc), t) for cc, t in zip(cls[k]["cols"][1:], cls[k]["theta"][1:]))
+        np.testing.assert_allclose(lr[k]["Parameters"], [cls[k]["theta"][0]] + [th.get(u, 0.0) for u in uni], rtol=1e-6, atol=1e-9)
+    # predict: the mean of the members' log pdf on the pair features of the file
+    cols = np.ones((len(dense), 1 + len(pairs)))
+    for c, (a, b) in enumerate(pairs):
+        cols[:, c + 1] = dense[:, a] if a == b else dense[:, a] * dense[:, b]
+    red = O.Csr.from_dense(cols[:, 1:])
+    pred = run(["--type=scoresLr", "predict", "ec.json", "fg.table"], tmp_path).stdout.split()[1:]
+    want = [np.mean([O.class_log_pdf(red, i, d["Parameters"], y=1) for d in lr]) for i in range(n1)]
+    np.testing.assert_allclose([float(v) for v in pred], want, rtol=1e-6)
+    OD.free_matrix(exp_h); OD.free_matrix(h)
+
+
 def test_ensemble_cli(tmp_path):
     # learn --ensemble-size=3 (kmerLr_learn.go:129-130, estimate_ensemble): one model with 3 coefficient vectors;
     # predict / loss summarise the members (Summarize, kmerLr_classifier_ensemble.go:64-104)
