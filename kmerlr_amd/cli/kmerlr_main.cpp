@@ -666,7 +666,6 @@ int main(int argc, char** argv) {
     if (ensemble < 1) die("invalid --ensemble-size");
     if (summary != "mean" && summary != "product" && summary != "min" && summary != "max" && !summary.empty()) die("invalid --ensemble-summary");
     const bool cv_path = kfold > 1 || cfg.validation_size > 0.0;
-    if (ensemble > 1 && !std::isnan(cfg.lambda) && !cv_path) die("--ensemble-size needs --lambda-auto in this build");
     cfg.ensemble_size = ensemble;                                        // read by the cross-validation (members inside every fold)
     cfg.ensemble_summary = summary == "product" ? KLR_SUMMARY_PRODUCT : summary == "min" ? KLR_SUMMARY_MIN : summary == "max" ? KLR_SUMMARY_MAX : KLR_SUMMARY_MEAN;
     cfg.cooccurrence = flag(o, "co-occurrence") ? 1 : 0;

@@ -326,6 +326,26 @@ def test_ensemble_cli(tmp_path):
     assert abs(float(out) - ref) < 1e-6 * ref
 
 
+def test_ensemble_with_fixed_lambda_cli(tmp_path):
+    # --lambda=F with --ensemble-size: every member solves the fixed-lambda problem on its rows (estimate_fixed inside
+    # estimate_ensemble, kmerLr_estimator_ensemble.go:74-96)
+    fg, bg = os.path.join(GOLDEN, "scoresLr_test_fg.table"), os.path.join(GOLDEN, "scoresLr_test_bg.table")
+    run(["--type=scoresLr", "learn", "--lambda=2.5", "--ensemble-size=2", "--seed=3", fg, bg, "ef"], tmp_path)
+    m = json.load(open(tmp_path / "ef.json"))
+    lr = [d for d in m["Distributions"] if d["Name"] == "vector:logistic regression"]
+    assert len(lr) == 2
+    _, xf = O.read_scores_table(fg); _, xb = O.read_scores_table(bg)
+    x = O.Csr.from_dense(np.concatenate([xf, xb])); labels = np.array([1] * 8 + [0] * 8, dtype=np.uint8)
+    h = OD.matrix(x, labels)
+    cls = OD.estimator(lam=2.5).estimate_ensemble(h, x.n, 2, [0], seed=3)
+    uni = sorted(set(int(cc) - 1 for c in cls for cc, t in zip(c["cols"][1:], c["theta"][1:]) if t != 0.0))
+    assert m["Parameters"]["Index"] == uni
+    for k in range(2):
+        th = dict((int(cc) - 1, t) for cc, t in zip(cls[k]["cols"][1:], cls[k]["theta"][1:]))
+        np.testing.assert_allclose(lr[k]["Parameters"], [cls[k]["theta"][0]] + [th.get(u, 0.0) for u in uni], rtol=1e-6, atol=1e-9)
+    OD.free_matrix(h)
+
+
 def test_kmers6_cooccurrence_fasta_cli(tmp_path):
     # TestKmers6 (kmerLr_test.go:192-268): learn --lambda-auto=2 --binarize --revcomp --co-occurrence 2 6 on the co_*.fa
     # files.  Every fg sequence carries both motifs, every bg sequence one of them twice: no single k-mer separates
