@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -288,7 +289,14 @@ struct FastCtl { u32 cursor, n, above, pad0; u64 low; u32 pad[10]; };
 // hinted compaction: while the keys are produced, everything at or above `tau` (a little below the K-th key of the
 // previous selection on this context) goes straight into the candidate list -- the selection then needs no pass
 // over the keys at all.  tau = 0: off.
-struct SelHint { u64 tau; Cand* cand; FastCtl* ctl; };
+// lean: nobody reads g or the keys when the hint holds (no g_out, no transform): the conversion then writes the candidates
+// and the scalars only -- 16 bytes per column less, 16 MB at a million columns -- and sweep_fix_emit repeats it in full
+// when the hint fails.
+struct SelHint { u64 tau; Cand* cand; FastCtl* ctl; bool lean = false; };
+// the last stage of sweep_fix_finish / sweep_fix_tail alone, in full (g, keys, coarse histogram; no hint): from the piece
+// vectors (one rank) or the all-reduced sums (several) the sweep left behind
+int   sweep_fix_emit(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
+                     const unsigned long long* rowblk, i64 nrowblk);
 int   sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
                        const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint = nullptr, i64** ibuf_out = nullptr,
                        i64 ibuf_elems = 0);
@@ -324,7 +332,8 @@ int   select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i
                          double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
                          int* ok_out, i64* picked_out, bool keys_hist_ready = false,
                          const double* extra_src = nullptr, double* extra_out = nullptr,
-                         u64 hint_tau = 0);
+                         u64 hint_tau = 0, const std::function<int()>* refill = nullptr);   // refill: g / keys / histogram were not
+                                                                                             // written (SelHint.lean): call it before they are read
 
 // matrix construction helpers
 int   mat_build_chunks_and_upload(klr_ctx* ctx, klr_mat* mat);   // uses h_colptr/h_collen

@@ -591,7 +591,7 @@ static void select_finish_host(const std::vector<Cand>& hc, i64 K, u64 vkey, u64
 int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64 c_prev, i64 N,
                        double lambda_prev, double eps_lambda, double* lambda_out, i64* c_out,
                        int* ok_out, i64* picked_out, bool keys_hist_ready, const double* extra_src, double* extra_out,
-                       u64 hint_tau) {
+                       u64 hint_tau, const std::function<int()>* refill) {
   KLR_ARG(ctx, m >= 0 && N >= 0 && b != nullptr);
   if (extra_out) *extra_out = NAN;
   const i64 K = std::min<i64>(m, 2 * N);             // NLargestAbsFloat64(g_, 2N)
@@ -618,6 +618,7 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_rank, (int)(FAST_CAP * sizeof(Cand))));
     KLR_TRY(ctx_func_lds(ctx, (const void*)k_fast_rank_out, (int)(FAST_CAP * sizeof(Cand))));
     bool direct_ok = false, ranked_out = false;
+    bool lean_unfilled = hint_tau != 0 && keys_hist_ready && refill;   // g and the keys are not on the device yet
     if (hint_tau != 0 && keys_hist_ready) {
       // the candidates are already in `cand` (SelHint): one sort kernel, no pass over the keys
       FastCtl* ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
@@ -649,8 +650,10 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
         KLR_HIP(ctx, hipMemsetAsync(ctl, 0, sizeof(FastCtl), st));
         ctx->sel_cursor_dirty = false;
       }
-      if (hint_tau != 0 && keys_hist_ready) {        // the hinted sweep did not build the coarse histogram
-
+      if (hint_tau != 0 && keys_hist_ready && refill) {
+        KLR_TRY((*refill)());                        // a lean hinted sweep wrote neither g nor the keys: the conversion again, in full
+        lean_unfilled = false;
+      } else if (hint_tau != 0 && keys_hist_ready) {   // the hinted sweep did not build the coarse histogram
         const unsigned hgrid = (unsigned)std::max<i64>(1, std::min<i64>(ceil_div(m, 256 * 4), 256));
         hipLaunchKernelGGL(k_hist_from_keys, dim3(hgrid), dim3(256), 0, st, keys, m, hist);
       }
@@ -670,6 +673,10 @@ int select_from_device(klr_ctx* ctx, const double* g_dev, i64 m, uint8_t* b, i64
     ctx->sel_hint = 0;
     if (hs.fallback || (need_w && !hs.wfound)) {
       // exact 8-pass radix select (keys are already on the device)
+      if (lean_unfilled) {
+        KLR_TRY((*refill)());
+        ctx->sel_hist_zeroed = nullptr;              // the conversion also built the coarse histogram, which nobody consumes here
+      }
       KLR_TRY(select_exact_device(ctx, g_dev, keys, true, m, K, N, hc, &vkey, &wkey));
     } else if (hc[(size_t)K - 1].key != 0ull) {
       // next time: compact everything above 0.9 x this call's K-th |g| while the keys are produced
@@ -1105,6 +1112,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
   }
   bool keys_ready = false, restored = false;
   u64 hint_tau = 0;
+  std::function<int()> refill;                         // set when the hinted sweep wrote candidates only (SelHint.lean)
   if (use_int) {
     // count data: row pass -> int64 fixed-point weights + exact loss limbs; integer sweep; ONE int64
     // all-reduce of [g | bias | loss]; conversion to f64 emits the selection keys + histogram
@@ -1115,6 +1123,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
       KLR_TRY(ws_get(ctx, WS_TMP0, (size_t)(GCAND_CAP + FAST_CAP) * sizeof(Cand), (void**)&hint.cand));
       hint.tau = ctx->sel_hint;
       hint.ctl = (FastCtl*)((char*)hist - sizeof(FastCtl));
+      hint.lean = g_out == nullptr && !ctx_opt(ctx, "KLR_SELECT_NO_LEAN");     // nothing reads g or the keys while the hint holds
       hint_tau = hint.tau;
     }
     KLR_TRY(sweep_fix_begin(ctx, full, cw, &scale_fx, &S, &acc));
@@ -1195,6 +1204,8 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     } else {
       if (ctx->ar_fn) ctx->n_ar_sweeps++;
       KLR_TRY(sweep_fix_finish(ctx, full, scale_fx, gbuf, tr ? nullptr : keys, tr ? nullptr : hist, rowblk, nrowblk, hint.tau ? &hint : nullptr));
+      if (hint.tau && hint.lean && !tr)
+        refill = [=]() { return sweep_fix_emit(ctx, full, scale_fx, gbuf, keys, hist, rowblk, nrowblk); };
     }
     keys_ready = m > 0 && !tr;
   } else {
@@ -1210,7 +1221,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
 
   double loss_sum = NAN;
   KLR_TRY(select_from_device(ctx, gbuf, m, b, c_prev, N, lambda_prev, eps_lambda, lambda_out, c_out, ok_out, nullptr, keys_ready,
-                             gbuf + dim, &loss_sum, hint_tau));
+                             gbuf + dim, &loss_sum, hint_tau, refill ? &refill : nullptr));
   KLR_HIP(ctx, hipStreamSynchronize(ctx->stream));     // g_out copy (select may not have synchronised)
   if (loss_out) *loss_out = full->n_total ? loss_sum / (double)full->n_total : 0.0;
   return KLR_OK;

@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
                                                      const i64* __restrict__ rowblk, i64 nrowblk, u32 CT, u32 PSTRIDE,
                                                      double inv_scale, double* __restrict__ g, u64* __restrict__ keys,
                                                      u32* __restrict__ hist, u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor,
-                                                     u32 ITER) {
+                                                     u32 ITER, u32 lean) {
   __shared__ i64 sh[4][256];
   __shared__ u32 shh[FUSE ? FAST_BINS : 1];
   // hinted compaction: the workgroup gathers its candidates in LDS and claims their slots with ONE atomic on the global
@@ -1081,10 +1081,10 @@ __global__ __launch_bounds__(1024) void k_finish_coo(const i64* __restrict__ par
   auto emit = [&](i64 j, i64 sum) {
     if (FUSE) {
       const double gv = (double)sum * inv_scale;                // inv_scale is a power of two: exact
-      g[j] = gv;
+      if (!lean) g[j] = gv;                                     // lean (SelHint): candidates only
       if (keys) {
         const u64 kk = abs_key(gv);
-        keys[j - 1] = kk;
+        if (!lean) keys[j - 1] = kk;
         if (hist) atomicAdd(&shh[(u32)(kk >> FAST_SHIFT)], 1u);
         if (tau != 0ull && kk >= tau) {                       // hinted compaction (SelHint)
           const u32 wp = atomicAdd(&wcnt, 1u);
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_fix_s(const double* __restrict__ s, con
 
 __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, i64 dim, double inv_scale,
                                                   double* __restrict__ g, u64* __restrict__ keys, u32* __restrict__ hist,
-                                                  u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor) {
+                                                  u64 tau, Cand* __restrict__ cand, u32* __restrict__ cursor, u32 lean) {
   // grid-stride; the coarse key histogram is privatised in LDS (most keys share a few bins); hinted candidates are
   // gathered per workgroup and claim their slots with one atomic on the global cursor
   __shared__ u32 sh[FAST_BINS];
@@ -1209,10 +1209,10 @@ __global__ __launch_bounds__(256) void k_int_to_g(const i64* __restrict__ ibuf, 
       g[0] = ((double)ibuf[dim] * 4294967296.0 + (double)ibuf[dim + 1]) * inv_scale;
     } else if (j < dim) {
       const double v = (double)ibuf[j] * inv_scale;           // inv_scale is a power of two: exact
-      g[j] = v;
+      if (!lean) g[j] = v;                                    // lean (SelHint): candidates only
       if (keys) {                                             // selection key of feature j-1
         const u64 k = abs_key(v);
-        keys[j - 1] = k;
+        if (!lean) keys[j - 1] = k;
         if (hist) atomicAdd(&sh[(u32)(k >> FAST_SHIFT)], 1u);
         if (tau != 0ull && k >= tau) {                          // hinted compaction (SelHint)
           const u32 wp = atomicAdd(&wcnt, 1u);
@@ -1296,6 +1296,36 @@ int sweep_fix_begin(klr_ctx* ctx, const klr_mat* mat, const double cw[2], double
   return KLR_OK;
 }
 
+// piece vectors -> column sums: converted, keyed and (hinted) compacted right here on one rank, left as integers for the
+// collective otherwise
+static int finish_launch(klr_ctx* ctx, const klr_mat* mat, const i64* part, i64* ibuf, double scale, double* gbuf, u64* keys, u32* hist,
+                         const unsigned long long* rowblk, i64 nrowblk, u64 tau, Cand* hcand, u32* hcur, bool lean) {
+  const i64 dim = mat->dim;
+  hipStream_t st = ctx->stream;
+  const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;      // width of a piece vector
+  const u32 ln = lean ? 1u : 0u;
+  // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
+  u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
+  if (ctx->sw.finish_iter > 0) fiter = (u32)std::max(1, std::min(8, ctx->sw.finish_iter));          // A/B tooling
+  // (one pass of 1024 columns per workgroup, 8x the workgroups, measured 3x slower on the 1M-column step: keep ITER)
+  const bool flat = mat->max_ct_pieces >= 1 && mat->max_ct_pieces <= 8 && fiter % 4 == 0 && !ctx->sw.finish_no_flat;
+  const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
+  if (!ctx->ar_fn) {
+    // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
+    if (flat) hipLaunchKernelGGL((k_finish_coo<true, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
+                                 nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter, ln);
+    else hipLaunchKernelGGL((k_finish_coo<true, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
+                            nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter, ln);
+  } else {
+    if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
+                                 nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter, 0u);
+    else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
+                            nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter, 0u);
+  }
+  KLR_HIP(ctx, hipGetLastError());
+  return KLR_OK;
+}
+
 // integer sweep over the packed stream, int64 all-reduce of [column sums | bias | loss], back to f64
 int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
                      const unsigned long long* rowblk, i64 nrowblk, const SelHint* hint, i64** ibuf_out, i64 ibuf_elems) {
@@ -1318,24 +1348,8 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
   }
   KLR_TRY(dispatch_sweep_coo(ctx, mat, S, part, e0, e1));
   if (timed) ctx->prof_ev.emplace_back(e0, e1);
-  // 256 columns per pass of a workgroup; wide matrices take up to 8 passes per workgroup (fewer, fuller candidate claims)
-  u32 fiter = (u32)std::max<i64>(1, std::min<i64>(8, dim / (256 * 512)));
-  if (ctx->sw.finish_iter > 0) fiter = (u32)std::max(1, std::min(8, ctx->sw.finish_iter));          // A/B tooling
-  // (one pass of 1024 columns per workgroup, 8x the workgroups, measured 3x slower on the 1M-column step: keep ITER)
-  const bool flat = mat->max_ct_pieces >= 1 && mat->max_ct_pieces <= 8 && fiter % 4 == 0 && !ctx->sw.finish_no_flat;
-  const dim3 fgrid((unsigned)ceil_div(dim, (i64)256 * fiter) + 1);
-  if (!ctx->ar_fn) {
-    // one rank, no hook: nothing happens between the piece sums and their conversion -- one kernel
-    if (flat) hipLaunchKernelGGL((k_finish_coo<true, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
-                                 nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
-    else hipLaunchKernelGGL((k_finish_coo<true, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
-                            nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, fiter);
-  } else {
-    if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
-                                 nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
-    else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, mat->t_ctptr, mat->t_ctlist, (i64)0, dim, ibuf, (const i64*)rowblk,
-                            nrowblk, mat->tile_c, pstride, 1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
-    KLR_HIP(ctx, hipGetLastError());
+  KLR_TRY(finish_launch(ctx, mat, part, ibuf, scale, gbuf, keys, hist, rowblk, nrowblk, tau, hcand, hcur, hint && hint->lean));
+  if (ctx->ar_fn) {
     if (ibuf_out) {                                // the caller runs the collective (reduce-scatter form, klr_select.hip)
       if (ibuf_elems > dim + IB_EXTRA) KLR_HIP(ctx, hipMemsetAsync(ibuf + dim + IB_EXTRA, 0, (size_t)(ibuf_elems - dim - IB_EXTRA) * 8, st));
       *ibuf_out = ibuf;
@@ -1343,6 +1357,23 @@ int sweep_fix_finish(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbu
     }
     return sweep_fix_tail(ctx, mat, scale, ibuf, gbuf, keys, hist, hint);
   }
+  return KLR_OK;
+}
+
+// The conversion stage alone, in full: after a lean hinted sweep whose hint failed (klr_select.hip).  One rank: the piece
+// vectors are still in WS_PART; several: the all-reduced sums are still in WS_TMP2.
+int sweep_fix_emit(klr_ctx* ctx, const klr_mat* mat, double scale, double* gbuf, u64* keys, u32* hist,
+                   const unsigned long long* rowblk, i64 nrowblk) {
+  const i64 dim = mat->dim;
+  i64 *part, *ibuf;
+  KLR_TRY(ws_get(ctx, WS_TMP2, (size_t)(dim + IB_EXTRA) * 8, (void**)&ibuf));
+  if (!ctx->ar_fn) {
+    const u32 pstride = mat->fmt == FMT_Q64C13 ? 8192u : TILE_DIM;
+    KLR_TRY(ws_get(ctx, WS_PART, (size_t)std::max<u32>(mat->npiece, 1) * pstride * 8, (void**)&part));
+    return finish_launch(ctx, mat, part, ibuf, scale, gbuf, keys, hist, rowblk, nrowblk, 0ull, nullptr, nullptr, false);
+  }
+  hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, ctx->stream, ibuf, dim,
+                     1.0 / scale, gbuf, keys, hist, 0ull, (Cand*)nullptr, (u32*)nullptr, 0u);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }
@@ -1355,7 +1386,7 @@ int sweep_fix_tail(klr_ctx* ctx, const klr_mat* mat, double scale, i64* ibuf, do
   const i64 dim = mat->dim;
   KLR_TRY(klr_allreduce(ctx, ibuf, dim + IB_EXTRA, KLR_I64));
   hipLaunchKernelGGL(k_int_to_g, dim3((unsigned)std::max<i64>(1, std::min<i64>(ceil_div(dim + 1, 1024), 256))), dim3(256), 0, ctx->stream, ibuf, dim,
-                     1.0 / scale, gbuf, keys, hist, tau, hcand, hcur);
+                     1.0 / scale, gbuf, keys, hist, tau, hcand, hcur, (hint && hint->lean && tau) ? 1u : 0u);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }
@@ -1404,9 +1435,9 @@ int sweep_range_finish(klr_ctx* ctx, const klr_mat* mat, i64 col0, i64 col1, con
   const bool flat = qr->max_ct_pieces >= 1 && qr->max_ct_pieces <= 8 && fiter % 4 == 0 && !ctx->sw.finish_no_flat;
   const dim3 fgrid((unsigned)ceil_div(ncol, (i64)256 * fiter) + 1);
   if (flat) hipLaunchKernelGGL((k_finish_coo<false, true>), fgrid, dim3(1024), 0, st, part, qr->t_ctptr, qr->t_ctlist, col0, col1, vec - col0, (const i64*)rowblk,
-                               nrowblk, mat->tile_c, pstride, 1.0, (double*)nullptr, (u64*)nullptr, (u32*)nullptr, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
+                               nrowblk, mat->tile_c, pstride, 1.0, (double*)nullptr, (u64*)nullptr, (u32*)nullptr, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter, 0u);
   else hipLaunchKernelGGL((k_finish_coo<false, false>), fgrid, dim3(1024), 0, st, part, qr->t_ctptr, qr->t_ctlist, col0, col1, vec - col0, (const i64*)rowblk,
-                          nrowblk, mat->tile_c, pstride, 1.0, (double*)nullptr, (u64*)nullptr, (u32*)nullptr, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter);
+                          nrowblk, mat->tile_c, pstride, 1.0, (double*)nullptr, (u64*)nullptr, (u32*)nullptr, 0ull, (Cand*)nullptr, (u32*)nullptr, fiter, 0u);
   KLR_HIP(ctx, hipGetLastError());
   return KLR_OK;
 }
