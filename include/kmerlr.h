@@ -104,6 +104,9 @@ int         klr_ctx_comm_selfcheck(klr_ctx* ctx);
  * (a rank's candidate list could not prove lambda: klr_ctx_set_collectives); checked = the self-check passed */
 int         klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce, int64_t* sweeps_scatter,
                                int64_t* scatter_fallbacks, int* checked);
+/* how many of the reduce-scatter sweeps ran as one launch per strip range with the collective of a range behind the next
+ * range's launch (the overlapped form) */
+int         klr_ctx_comm_ranged(const klr_ctx* ctx, int64_t* sweeps_ranged);
 
 /* what the context measured before the first wide sweep it could reduce-scatter (averaged over the ranks): the installed
  * reduce-scatter on a vector of `elements` int64, the all-gather of the candidate blocks, ONE all-reduce of the same

@@ -45,6 +45,7 @@ SIGNATURES = {
     "klr_allreduce_host": (_int, [_vp, _vp, _i64, _int]),
     "klr_ctx_comm_selfcheck": (_int, [_vp]),
     "klr_ctx_comm_stats": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
+    "klr_ctx_comm_ranged": (_int, [_vp, C.POINTER(_i64)]),
     "klr_ctx_comm_probe": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_int), C.POINTER(_int)]),
     "klr_ctx_set_option": (_int, [_vp, C.c_char_p, C.c_char_p]),
     "klr_ctx_reload_env": (_int, [_vp]),
@@ -222,7 +223,9 @@ class Context:
     def comm_stats(self):
         a, s_, f, c = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
         self.check(lib().klr_ctx_comm_stats(self._h, C.byref(a), C.byref(s_), C.byref(f), C.byref(c)))
-        return dict(sweeps_allreduce=a.value, sweeps_scatter=s_.value, scatter_fallbacks=f.value, checked=bool(c.value))
+        rg = C.c_int64(0)
+        self.check(lib().klr_ctx_comm_ranged(self._h, C.byref(rg)))
+        return dict(sweeps_allreduce=a.value, sweeps_scatter=s_.value, scatter_fallbacks=f.value, sweeps_ranged=rg.value, checked=bool(c.value))
 
     def comm_probe(self):
         n, rs, ag, ar, f, g = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_int(0), C.c_int(0)

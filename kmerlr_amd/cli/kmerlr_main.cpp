@@ -337,6 +337,16 @@ static double summarize(const std::string& summary, const std::vector<double>& x
   return r;
 }
 
+// -v with several ranks: the full-width sweeps by the collective they posted
+static void comm_report(klr_ctx* ctx) {
+  if (g_nranks <= 1 || g_rank != 0) return;
+  int64_t ar = 0, rs = 0, fb = 0, rg = 0;
+  klr_ctx_comm_stats(ctx, &ar, &rs, &fb, nullptr);
+  klr_ctx_comm_ranged(ctx, &rg);
+  say(1, "Sweep collectives: %lld all-reduce, %lld reduce-scatter + all-gather (%lld repeated as all-reduce, %lld in strip ranges)\n",
+      (long long)ar, (long long)rs, (long long)fb, (long long)rg);
+}
+
 // members: one coefficient vector per ensemble member (a single one for plain models); summary from "Name [summary]"
 static klr_mat* model_data(klr_ctx* ctx, const klr_mat* mat, const std::string& js, std::vector<std::vector<double>>& members,
                            std::string& summary, const std::vector<double>* kmer_index = nullptr) {
@@ -897,6 +907,7 @@ int main(int argc, char** argv) {
       klr_estimator_destroy(est);
       klr_mat_destroy(mat);
       if (base_mat) klr_mat_destroy(base_mat);
+      comm_report(ctx);
       klr_ctx_destroy(ctx);
       fflush(stdout); fflush(stderr);
       _exit(0);
@@ -998,6 +1009,7 @@ int main(int argc, char** argv) {
     if (f != stdout) fclose(f);
     klr_mat_destroy(red); klr_mat_destroy(mat);
   }
+  comm_report(ctx);
   klr_ctx_destroy(ctx);
   fflush(stdout); fflush(stderr);
   if (g_nranks > 1) _exit(0);

@@ -383,6 +383,12 @@ extern "C" int klr_ctx_comm_stats(const klr_ctx* ctx, int64_t* sweeps_allreduce,
   return KLR_OK;
 }
 
+extern "C" int klr_ctx_comm_ranged(const klr_ctx* ctx, int64_t* sweeps_ranged) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  if (sweeps_ranged) *sweeps_ranged = ctx->n_ranged_sweeps;
+  return KLR_OK;
+}
+
 extern "C" int klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_allgather_fn ag, void* user) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, (rs == nullptr) == (ag == nullptr));

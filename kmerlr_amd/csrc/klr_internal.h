@@ -109,7 +109,7 @@ struct klr_ctx {
   // process-wide latch would leave a second GPU's kernels without it)
   std::set<const void*> lds_attr;
   // sweep collectives that fell back from the reduce-scatter form to the all-reduce (klr_ctx_comm_stats)
-  i64 n_rs_sweeps = 0, n_rs_fallbacks = 0, n_ar_sweeps = 0;
+  i64 n_rs_sweeps = 0, n_rs_fallbacks = 0, n_ar_sweeps = 0, n_ranged_sweeps = 0;
   bool comm_checked = false;     // the installed collectives passed klr_ctx_comm_selfcheck
   // strip ranges of the overlapped sweep, chosen once per vector length from the MEASURED reduce-scatter time of the
   // installed hook (sweep_ranges_auto, klr_select.hip): probe_dim = that length, probe_G = the choice, probe_ms = the time

@@ -1167,6 +1167,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
       KLR_TRY(sweep_select_scatter(ctx, full, scale_fx, P, ibuf, qr != nullptr, part_r, rowblk, nrowblk, N, b, c_prev, lambda_prev, eps_lambda,
                                    lambda_out, c_out, ok_out, &loss_sum_s, &done));
       ctx->n_rs_sweeps++;
+      if (qr) ctx->n_ranged_sweeps++;
       if (done && full->rs_verified) {
         if (loss_out) *loss_out = full->n_total ? loss_sum_s / (double)full->n_total : 0.0;
         return KLR_OK;

@@ -108,15 +108,15 @@ def write_fasta(path, seqs):
 
 @pytest.fixture(scope="module")
 def big_fasta(tmp_path_factory):
-    """Count data large enough for the packed integer stream on EACH of two shards (n >= 2048 rows, nnz >= 2^20):
-    2 x 2,400 sequences of 700 bp, a few planted 6-mers per class."""
+    """Count data large enough for the packed integer stream on EACH of two or three shards (n >= 2048 rows, nnz >= 2^20):
+    2 x 3,300 sequences of 700 bp, a few planted 6-mers per class."""
     d = tmp_path_factory.mktemp("bigfa")
     rng = np.random.default_rng(20261005)
     motifs = {1: ["acgtgc", "ttgaca", "ggatcc"], 0: ["cccggg", "atatat", "gattac"]}
     out = {}
     for label, name in ((1, "fg.fa"), (0, "bg.fa")):
         seqs = []
-        for _ in range(2400):
+        for _ in range(3300):
             s = rng.integers(0, 4, size=700)
             t = "".join("acgt"[c] for c in s)
             for mt in motifs[label]:
@@ -143,8 +143,35 @@ def test_two_ranks_integer_stream_path(tmp_path, big_fasta):
     for la in (6, 12):
         same_model(tmp_path / ("one_%d.json" % la), tmp_path / ("two_%d.json" % la))
         same_model(tmp_path / ("two_%d.json" % la), tmp_path / ("three_%d.json" % la), rtol=0)      # same sums, same rank order
-    lam = [[ln for ln in r.stderr.splitlines() if ln.startswith("Estimating parameters")] for r in (r1, r2, r3)]
-    assert lam[0][0] == lam[1][0] == lam[2][0]                         # first epoch (theta = 0): exact integer sums
+    # three ranks (slices of a third, a three-way merge of the candidates), the sweep in two strip ranges with the collective
+    # of the first range behind the second range's launch
+    env = dict(os.environ, KLR_RS_MIN_DIM="1", KLR_RS="1", KLR_SWEEP_RANGES="2")
+    r4 = subprocess.run([CLI, "-v", "--ranks=3", "--transport=shm"] + common + ["four"], cwd=tmp_path, capture_output=True, text=True,
+                        timeout=600, env=env)
+    assert r4.returncode == 0, r4.stderr[-3000:]
+    for la in (6, 12):
+        same_model(tmp_path / ("one_%d.json" % la), tmp_path / ("four_%d.json" % la))
+    lam = [[ln for ln in r.stderr.splitlines() if ln.startswith("Estimating parameters")] for r in (r1, r2, r3, r4)]
+    assert lam[0][0] == lam[1][0] == lam[2][0] == lam[3][0]            # first epoch (theta = 0): exact integer sums
+
+
+def test_three_ranks_strip_ranges(tmp_path, big_fasta):
+    """8-mers (32,896 revcomp classes: nine strips): three ranks, the reduce-scatter form in two strip ranges -- the collective
+    of the first range runs behind the second range's launch -- against the one-rank run."""
+    import re
+    common = ["learn", "--lambda-auto=8", "--revcomp", "8", "8", big_fasta[1], big_fasta[0]]
+    r1 = run(["-v"] + common + ["one"], tmp_path)
+    env = dict(os.environ, KLR_RS_MIN_DIM="1", KLR_RS="1", KLR_SWEEP_RANGES="2")
+    r3 = subprocess.run([CLI, "-v", "--ranks=3", "--transport=shm"] + common + ["three"], cwd=tmp_path, capture_output=True, text=True,
+                        timeout=600, env=env)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    same_model(tmp_path / "one.json", tmp_path / "three.json")
+    lam = [[ln for ln in r.stderr.splitlines() if ln.startswith("Estimating parameters")] for r in (r1, r3)]
+    assert lam[0][0] == lam[1][0]
+    rep = re.search(r"Sweep collectives: (\d+) all-reduce, (\d+) reduce-scatter \+ all-gather \((\d+) repeated as all-reduce, (\d+) in strip ranges\)", r3.stderr)
+    assert rep, r3.stderr[-2000:]
+    ar, rs, fb, rg = (int(v) for v in rep.groups())
+    assert rs >= 2 and rg == rs and fb <= 1          # every wide sweep in the ranged form; the first one is verified against the all-reduce
 
 
 def test_unknown_options_and_getopt_spelling(tmp_path):
