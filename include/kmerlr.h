@@ -44,6 +44,13 @@ typedef struct klr_mat klr_mat;
 
 /* ---- context ------------------------------------------------------------------------- */
 int         klr_ctx_create(int device_id, klr_ctx** out);
+/* A second context on the same device with the switches of `parent` (own stream, own workspaces), for concurrent work on
+ * shared data from another host thread: one fold of a cross-validation per context, on klr_mat_view's of the data
+ * (klr_config.threads_cv; the reference runs its folds in threads too, kmerLr_crossvalidation.go:176).  A context with
+ * a communicator is not forked.  klr_ctx_release hands it back to the parent, which keeps it (warm workspaces) for the
+ * next fork and destroys it when it is destroyed itself; klr_ctx_destroy ends it at once. */
+int         klr_ctx_fork(klr_ctx* parent, klr_ctx** out);
+void        klr_ctx_release(klr_ctx* forked);
 void        klr_ctx_destroy(klr_ctx* ctx);
 const char* klr_last_error(const klr_ctx* ctx);
 /* run the ctx's kernels on an existing HIP stream (hipStream_t passed as void*); NULL = the
@@ -198,6 +205,9 @@ void    klr_coeff_sub2ind(int64_t nb, int64_t i, int64_t* k1, int64_t* k2);
  * rows over all shards (takes the place of len(data) in 1/n and lambda = L1Reg/n).  mask = NULL restores
  * all rows.  Reduced matrices inherit the mask in force when they are created.  klr_log_pdf ignores it. */
 int  klr_mat_set_active_rows(klr_ctx* ctx, klr_mat* mat, const uint8_t* mask, int64_t n_active_total);
+/* A matrix for another context of the same device that SHARES the device storage of `mat` (which must outlive it) and has
+ * its own row mask: what a concurrent fold works on.  Destroyed with klr_mat_destroy (frees the mask only). */
+int         klr_mat_view(klr_ctx* ctx, const klr_mat* mat, klr_mat** out);
 
 /* compute_class_weights (kmerLr_data.go:178-193) over the (all-reduced) label counts */
 int  klr_class_weights(klr_ctx* ctx, const klr_mat* mat, double cw[2]);

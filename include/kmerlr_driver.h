@@ -44,6 +44,11 @@ typedef struct klr_backend {
   int  (*log_pdf)(klr_ctx*, const klr_mat*, const double*, double*);
   int  (*expand_cooccurrence)(klr_ctx*, const klr_mat*, klr_mat**);      /* co-occurrence mode only; may be NULL */
   int  (*transform_fit)(klr_ctx*, const klr_mat*, int, double*, double*, int*);   /* per-fold TransformFull.Fit (validation sets only); may be NULL */
+  /* concurrent folds (klr_config.threads_cv > 1); all three or none.  ctx_fork: another context for another host thread;
+   * mat_view: the data for that context -- shared storage, its own row mask; ctx_release ends a forked context */
+  int  (*ctx_fork)(klr_ctx*, klr_ctx**);
+  void (*ctx_release)(klr_ctx*);
+  int  (*mat_view)(klr_ctx*, const klr_mat*, klr_mat**);
 } klr_backend;
 
 /* the HIP table for an existing context */
@@ -76,6 +81,11 @@ typedef struct klr_config {
   int     data_transform;    /* --data-transform as KLR_TR_* (0 none): only read where the driver has to FIT the
                               * transform itself, i.e. per fold when a validation set is split off
                               * (kmerLr_estimator_ensemble.go:116-117 fits on train + test rows)            */
+  int     threads_cv;        /* --threads-cv: folds of klr_estimator_crossvalidate that run at once, each in its own
+                              * host thread on a forked context and a view of the data (kmerLr_crossvalidation.go:176
+                              * runs its folds in a thread pool); 0 / 1 = one after the other.  Needs the backend's
+                              * ctx_fork / mat_view and a single rank; otherwise the folds run in turn.  The results
+                              * do not depend on it.                                                          */
 } klr_config;
 
 #define KLR_SUMMARY_MEAN    0   /* {Kmer,Scores}LrEnsemble.Summarize, kmerLr_classifier_ensemble.go:64-104 */

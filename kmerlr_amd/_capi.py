@@ -29,6 +29,8 @@ _PVP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "klr_ctx_create": (_int, [_int, _PVP]),
     "klr_ctx_destroy": (None, [_vp]),
+    "klr_ctx_fork": (_int, [_vp, C.POINTER(_vp)]),
+    "klr_ctx_release": (None, [_vp]),
     "klr_last_error": (C.c_char_p, [_vp]),
     "klr_ctx_set_stream": (_int, [_vp, _vp]),
     "klr_ctx_synchronize": (_int, [_vp]),
@@ -63,6 +65,7 @@ SIGNATURES = {
                               C.POINTER(_int), C.POINTER(_int)]),
     "klr_mat_to_csr": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "klr_mat_set_active_rows": (_int, [_vp, _vp, _vp, _i64]),
+    "klr_mat_view": (_int, [_vp, _vp, C.POINTER(_vp)]),
     "klr_mat_expand_cooccurrence": (_int, [_vp, _vp, _PVP]),
     "klr_coeff_dim": (_i64, [_i64]),
     "klr_coeff_ind2sub": (_i64, [_i64, _i64, _i64]),

@@ -12,7 +12,8 @@ from . import _capi
 class Backend(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ctx", "last_error", "mat_shape", "mat_destroy", "class_weights", "gradient",
                                           "loss", "select_columns", "sweep_select", "cd_solve", "set_active_rows",
-                                          "log_pdf", "expand_cooccurrence", "transform_fit")]
+                                          "log_pdf", "expand_cooccurrence", "transform_fit", "ctx_fork", "ctx_release",
+                                          "mat_view")]
 
 
 class Config(C.Structure):
@@ -22,7 +23,7 @@ class Config(C.Structure):
                 ("epsilon_loss", C.c_double), ("eval_loss", C.c_int), ("balance", C.c_int), ("penalty_free", C.c_int),
                 ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double),
                 ("cooccurrence", C.c_int), ("copreselection", C.c_int64), ("validation_size", C.c_double),
-                ("ensemble_size", C.c_int), ("ensemble_summary", C.c_int), ("data_transform", C.c_int)]
+                ("ensemble_size", C.c_int), ("ensemble_summary", C.c_int), ("data_transform", C.c_int), ("threads_cv", C.c_int)]
 
 
 def bind_driver(L):

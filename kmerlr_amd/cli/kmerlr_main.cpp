@@ -666,7 +666,11 @@ int main(int argc, char** argv) {
     cfg.data_transform = transform_kind(opt(o, "data-transform", ""));
     // SAGA's knobs (step size, its thread pools): accepted like the reference's, without effect on the coordinate-descent solver
     (void)opt_float(o, "scale-step-size", "1.0");
-    for (const char* k : {"threads-cv", "threads-saga", "threads-lr"}) (void)opt_int(o, k, "1");
+    for (const char* k : {"threads-saga", "threads-lr"}) (void)opt_int(o, k, "1");
+    // --threads-cv (kmerLr_learn.go:146, the pool of kmerLr_crossvalidation.go:176): folds that run at once, each in its
+    // own host thread on its own context (one rank only; with --ranks > 1 the folds run in turn)
+    cfg.threads_cv = (int)opt_int(o, "threads-cv", "1");
+    if (cfg.threads_cv < 1) die("invalid --threads-cv");
     if (flag(o, "adaptive-step-size") || flag(o, "scale-step-size")) say(1, "note: the step-size options belong to the reference's SAGA solver and have no effect here\n");
     const int kfold = (int)opt_int(o, "k-fold-cv", "1");
     const long long seed = atoll(g_seed.c_str());

@@ -118,6 +118,44 @@ extern "C" int klr_ctx_create(int device_id, klr_ctx** out) {
   return KLR_OK;
 }
 
+// A second context on the parent's device with the parent's switches: own stream, own workspaces.  For concurrent work
+// on shared data -- a fold of a cross-validation per context (klr_mat_view).  A context with a communicator is not
+// forked: the folds of all ranks would have to post their collectives in one agreed order.
+extern "C" int klr_ctx_fork(klr_ctx* parent, klr_ctx** out) {
+  if (!parent) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(parent, out != nullptr);
+  *out = nullptr;
+  if (parent->ar_fn || parent->nranks > 1) return klr_fail(parent, KLR_EINVAL, "klr_ctx_fork: a context with collectives is not forked");
+  klr_ctx* c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(parent->fork_mu);
+    if (!parent->fork_idle.empty()) { c = parent->fork_idle.back(); parent->fork_idle.pop_back(); }
+  }
+  if (!c) {
+    KLR_TRY(klr_ctx_create(parent->device, &c));
+    c->fork_parent = parent;
+  }
+  c->opts = parent->opts;
+  ctx_parse_switches(c);
+  *out = c;
+  return KLR_OK;
+}
+
+// A forked context goes back to its parent (stream drained, workspaces kept) and ends with it; any other context, or a
+// fork whose parent is gone, is destroyed.
+extern "C" void klr_ctx_release(klr_ctx* ctx) {
+  if (!ctx) return;
+  klr_ctx* parent = ctx->fork_parent;
+  if (parent && ctx_alive(parent)) {
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    std::lock_guard<std::mutex> lk(parent->fork_mu);
+    parent->fork_idle.push_back(ctx);
+    return;
+  }
+  klr_ctx_destroy(ctx);
+}
+
 // ---- RCCL, loaded lazily so that single-GPU use has no dependency on it -------------------
 struct Id128 { char b[128]; };
 struct RcclState {
@@ -463,6 +501,11 @@ int stage_get(klr_ctx* ctx, size_t bytes, void** out) {
 
 extern "C" void klr_ctx_destroy(klr_ctx* ctx) {
   if (!ctx) return;
+  {
+    std::vector<klr_ctx*> idle;
+    { std::lock_guard<std::mutex> lk(ctx->fork_mu); idle.swap(ctx->fork_idle); }
+    for (klr_ctx* c : idle) { c->fork_parent = nullptr; klr_ctx_destroy(c); }
+  }
   ctx_unregister(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -663,5 +706,8 @@ extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
   out->log_pdf = klr_log_pdf;
   out->expand_cooccurrence = klr_mat_expand_cooccurrence;
   out->transform_fit = klr_transform_fit;
+  out->ctx_fork = klr_ctx_fork;
+  out->ctx_release = klr_ctx_release;
+  out->mat_view = klr_mat_view;
   return KLR_OK;
 }

@@ -14,7 +14,10 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -403,35 +406,33 @@ extern "C" void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t r
   klr_cv_groups_val(n_all, k_fold, 0.0, seed, row0, n_local, groups, nullptr);
 }
 
-extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int64_t row0, int64_t n_all, int k_fold,
-                                           int64_t seed, const int64_t* lambda_auto, int64_t nla, const double* scale,
-                                           const double* offset, double* predictions, int32_t* groups_out,
-                                           double* loss_train, double* loss_test) {
-  if (!e) return KLR_EINVAL;
-  const double vr = e->cfg.validation_size;
-  const bool val = vr > 0.0;
-  if (!data || k_fold < 1 || (k_fold < 2 && !val) || !lambda_auto || nla < 1 || !loss_train || !loss_test || (k_fold > 1 && !predictions))
-    return fail(e, KLR_EINVAL, "crossvalidate: invalid argument");
-  if (!e->be.set_active_rows || !e->be.log_pdf) return fail(e, KLR_EINVAL, "backend lacks set_active_rows / log_pdf");
-  int64_t n = 0, dim = 0;
-  if (e->be.mat_shape(data, &n, &dim, nullptr, nullptr) != KLR_OK) return fail(e, KLR_EINVAL, "bad data matrix");
-  if (n_all < k_fold) return fail(e, KLR_EINVAL, "not enough training samples (%lld) for %d-fold cross-validation", (long long)n_all, k_fold);
-  if (val && n_all < 2 * (int64_t)k_fold)
-    return fail(e, KLR_EINVAL, "not enough training samples for creating validation set with %d-fold cross-validation", k_fold);
-  std::vector<int32_t> all((size_t)n_all);
-  std::vector<uint8_t> vall((size_t)n_all);
-  klr_cv_groups_val(n_all, k_fold, vr, seed, 0, n_all, all.data(), vall.data());
+// what the folds of one cross-validation share (read-only while they run)
+struct CvShared {
+  int64_t n = 0, dim = 0, n_all = 0, row0 = 0, seed = 0, nla = 0;
+  int k_fold = 0, nfold = 0, E = 1;
+  bool val = false, copre = false;
+  const int64_t* lambda_auto = nullptr;
+  const double* scale = nullptr; const double* offset = nullptr;
+  const std::vector<int32_t>* all = nullptr; const std::vector<uint8_t>* vall = nullptr;
+  double* predictions = nullptr; double* loss_train = nullptr; double* loss_test = nullptr;
+};
+
+// One fold (crossvalidation's loop body, kmerLr_crossvalidation.go:176-195) on e's backend and `data`: the fold's estimator
+// is appended to e->folds, its records to e->trace, the classifiers it keeps go to kept_out.  Folds write disjoint slots of
+// predictions / loss_train / loss_test; with threads_cv every fold runs on an estimator, a context and a view of its own.
+static int cv_fold(klr_estimator* e, klr_mat* data, const CvShared& S, int f, std::vector<Classifier>& kept_out) {
+  const int64_t n = S.n, dim = S.dim, n_all = S.n_all, row0 = S.row0, seed = S.seed, nla = S.nla;
+  const int nfold = S.nfold, E = S.E;
+  const bool val = S.val, copre = S.copre;
+  const int64_t* lambda_auto = S.lambda_auto;
+  const double* scale = S.scale; const double* offset = S.offset;
+  const std::vector<int32_t>& all = *S.all; const std::vector<uint8_t>& vall = *S.vall;
   const int32_t* grp = all.data() + row0;
   const uint8_t* vfl = vall.data() + row0;
-  if (groups_out) for (int64_t i = 0; i < n; i++) groups_out[i] = grp[i];
+  double* predictions = S.predictions; double* loss_train = S.loss_train; double* loss_test = S.loss_test;
   std::vector<uint8_t> mask((size_t)std::max<int64_t>(n, 1));
-  std::vector<double> lp((size_t)std::max<int64_t>(n, 1));
   std::vector<double> fsc, fof;                       // per-fold transform (validation sets)
   int rc = KLR_OK;
-  e->out.clear();
-  drop_folds(e);
-  std::vector<Classifier> all_cls;
-  const int nfold = k_fold <= 1 ? 1 : k_fold;
   // classifier.Loss on a row set ({Kmer,Scores}LrEnsemble.Loss, kmerLr_classifier_ensemble.go:108-123): Lambda = config.Lambda
   // (NaN with --lambda-auto: no penalty term), class weights [1,1] unless --balance (then those of the row set itself)
   auto set_loss = [&](klr_mat* red, const std::vector<uint8_t>& rows, int64_t n_rows, const std::vector<double>& theta, double* out) -> int {
@@ -441,8 +442,6 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
     if (e->be.loss(e->be.ctx, red, theta.data(), cwl, e->cfg.lambda, out) != KLR_OK) return be_fail(e, KLR_EHIP, "loss");
     return KLR_OK;
   };
-  const int E = std::max(1, e->cfg.ensemble_size);
-  const bool copre = e->cfg.cooccurrence && e->cfg.copreselection > 0 && e->cfg.copreselection < dim - 1;
   // {Kmer,Scores}LrEnsemble.Summarize (kmerLr_classifier_ensemble.go:64-104)
   auto summarize = [&](const std::vector<double>& x) -> double {
     if (x.empty()) return NAN;
@@ -455,8 +454,8 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       default: r = 0.0; for (double v : x) r += v; return r / (double)x.size();
     }
   };
-  klr_mat* fold_ex = nullptr;          // the pair matrix of the fold at hand (co-preselection inside the fold)
-  for (int f = 0; f < nfold && rc == KLR_OK; f++) {
+  klr_mat* fold_ex = nullptr;          // the pair matrix of the fold (co-preselection inside the fold)
+  do {
     const int32_t ff = f;             // without folds every group id is -1: no row is a test row (crossvalidation :183-186)
     // the three row sets of fold f over the WHOLE data set (filterCvGroup :96-120): test, validation, training
     int64_t n_test = 0, n_val = 0;
@@ -612,11 +611,114 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       std::vector<Classifier> kept;
       for (int k = 0; k < E; k++) for (size_t j = j_first; j < j_end; j++) kept.push_back(members[(size_t)k]->out[j]);
       fe->out = kept;
-      for (const Classifier& c : kept) all_cls.push_back(c);
+      kept_out = kept;
     }
-  }
+  } while (0);
   if (fold_ex) e->be.mat_destroy(fold_ex);
-  e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
+  return rc;
+}
+
+extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int64_t row0, int64_t n_all, int k_fold,
+                                           int64_t seed, const int64_t* lambda_auto, int64_t nla, const double* scale,
+                                           const double* offset, double* predictions, int32_t* groups_out,
+                                           double* loss_train, double* loss_test) {
+  if (!e) return KLR_EINVAL;
+  const double vr = e->cfg.validation_size;
+  const bool val = vr > 0.0;
+  if (!data || k_fold < 1 || (k_fold < 2 && !val) || !lambda_auto || nla < 1 || !loss_train || !loss_test || (k_fold > 1 && !predictions))
+    return fail(e, KLR_EINVAL, "crossvalidate: invalid argument");
+  if (!e->be.set_active_rows || !e->be.log_pdf) return fail(e, KLR_EINVAL, "backend lacks set_active_rows / log_pdf");
+  int64_t n = 0, dim = 0;
+  if (e->be.mat_shape(data, &n, &dim, nullptr, nullptr) != KLR_OK) return fail(e, KLR_EINVAL, "bad data matrix");
+  if (n_all < k_fold) return fail(e, KLR_EINVAL, "not enough training samples (%lld) for %d-fold cross-validation", (long long)n_all, k_fold);
+  if (val && n_all < 2 * (int64_t)k_fold)
+    return fail(e, KLR_EINVAL, "not enough training samples for creating validation set with %d-fold cross-validation", k_fold);
+  std::vector<int32_t> all((size_t)n_all);
+  std::vector<uint8_t> vall((size_t)n_all);
+  klr_cv_groups_val(n_all, k_fold, vr, seed, 0, n_all, all.data(), vall.data());
+  const int32_t* grp = all.data() + row0;
+  if (groups_out) for (int64_t i = 0; i < n; i++) groups_out[i] = grp[i];
+  int rc = KLR_OK;
+  e->out.clear();
+  drop_folds(e);
+  std::vector<Classifier> all_cls;
+  const int nfold = k_fold <= 1 ? 1 : k_fold;
+  CvShared S;
+  S.n = n; S.dim = dim; S.n_all = n_all; S.row0 = row0; S.seed = seed; S.nla = nla;
+  S.k_fold = k_fold; S.nfold = nfold; S.E = std::max(1, e->cfg.ensemble_size);
+  S.val = val; S.copre = e->cfg.cooccurrence && e->cfg.copreselection > 0 && e->cfg.copreselection < dim - 1;
+  S.lambda_auto = lambda_auto; S.scale = scale; S.offset = offset; S.all = &all; S.vall = &vall;
+  S.predictions = predictions; S.loss_train = loss_train; S.loss_test = loss_test;
+  std::vector<std::vector<Classifier>> kept((size_t)nfold);
+  // Folds at once (cfg.threads_cv, the reference's --threads-cv): every worker thread forks a context and takes a view of
+  // the data (shared storage, its own row mask), a fold runs on an estimator of its own; the results are put together in
+  // fold order afterwards, so nothing depends on the number of threads.  One rank only: the folds of several ranks would
+  // have to post their collectives in one agreed order.
+  int T = std::min(std::max(1, e->cfg.threads_cv), nfold);
+  if (T > 1 && !(e->be.ctx_fork && e->be.ctx_release && e->be.mat_view)) T = 1;
+  std::vector<klr_ctx*> wctx;
+  std::vector<klr_mat*> wdata;
+  const auto t_fork0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < T && T > 1; t++) {
+    klr_ctx* c = nullptr; klr_mat* v = nullptr;
+    if (e->be.ctx_fork(e->be.ctx, &c) != KLR_OK || !c) break;             // e.g. a context with a communicator
+    if (e->be.mat_view(c, data, &v) != KLR_OK || !v) { e->be.ctx_release(c); break; }
+    wctx.push_back(c); wdata.push_back(v);
+  }
+  if (T > 1 && (int)wctx.size() < 2) {
+    say(e, 1, "Cross-validation folds run one after the other (%s)\n", wctx.empty() ? "this backend context cannot be forked" : "one worker");
+    for (size_t t = 0; t < wctx.size(); t++) { e->be.mat_destroy(wdata[t]); e->be.ctx_release(wctx[t]); }
+    wctx.clear(); wdata.clear();
+    T = 1;
+  } else if (T > 1) T = (int)wctx.size();
+  if (T > 1) say(e, 2, "%d folds at once: contexts and views ready after %.1f ms\n", T,
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fork0).count() * 1e3);
+  if (T <= 1) {
+    for (int f = 0; f < nfold && rc == KLR_OK; f++) rc = cv_fold(e, data, S, f, kept[(size_t)f]);
+    e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
+  } else {
+    std::vector<klr_estimator*> west((size_t)nfold, nullptr);
+    std::vector<int> wrc((size_t)nfold, KLR_OK);
+    std::atomic<int> next(0);
+    std::atomic<bool> failed(false);
+    auto worker = [&](int t) {
+      klr_backend be = e->be;
+      be.ctx = wctx[(size_t)t];
+      for (;;) {
+        const int f = next.fetch_add(1);
+        if (f >= nfold || failed.load()) break;
+        klr_estimator* w = fresh_like(e);
+        if (!w) { wrc[(size_t)f] = KLR_EINVAL; failed.store(true); break; }
+        w->be = be;
+        west[(size_t)f] = w;
+        wrc[(size_t)f] = cv_fold(w, wdata[(size_t)t], S, f, kept[(size_t)f]);
+        if (wrc[(size_t)f] != KLR_OK) failed.store(true);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (std::thread& x : th) x.join();
+    say(e, 2, "folds done after %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fork0).count() * 1e3);
+    // in fold order: the fold estimators (handed to e, on e's backend from now on), the records, the first error
+    for (int f = 0; f < nfold; f++) {
+      klr_estimator* w = west[(size_t)f];
+      if (rc == KLR_OK && wrc[(size_t)f] != KLR_OK) { rc = wrc[(size_t)f]; e->err = w ? w->err : std::string("cannot create fold estimator"); }
+      if (!w) { if (rc == KLR_OK) rc = fail(e, KLR_EINVAL, "fold %d did not run", f + 1); continue; }
+      if (rc == KLR_OK) {
+        for (klr_estimator* fe : w->folds) {
+          fe->be = e->be;
+          for (klr_estimator* me : fe->folds) me->be = e->be;
+          e->folds.push_back(fe);
+        }
+        w->folds.clear();
+        for (auto& r : w->trace) e->trace.push_back(r);
+      }
+      klr_estimator_destroy(w);
+    }
+    for (size_t t = 0; t < wctx.size(); t++) { e->be.mat_destroy(wdata[t]); e->be.ctx_release(wctx[t]); }
+  }
+  if (rc == KLR_OK) for (auto& k : kept) for (const Classifier& c : k) all_cls.push_back(c);
   if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j (f alone with a validation
                                                  // set); with an ensemble the folds' member-major lists one after the other
   return rc;

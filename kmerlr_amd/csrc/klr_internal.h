@@ -8,6 +8,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -110,6 +111,11 @@ struct klr_ctx {
   std::set<const void*> lds_attr;
   // sweep collectives that fell back from the reduce-scatter form to the all-reduce (klr_ctx_comm_stats)
   i64 n_rs_sweeps = 0, n_rs_fallbacks = 0, n_ar_sweeps = 0, n_ranged_sweeps = 0;
+  // klr_ctx_fork: the contexts forked from this one that are not in use (klr_ctx_release puts them back: warm workspaces
+  // for the next cross-validation); they end with this context
+  klr_ctx* fork_parent = nullptr;
+  std::vector<klr_ctx*> fork_idle;
+  std::mutex fork_mu;
   bool comm_checked = false;     // the installed collectives passed klr_ctx_comm_selfcheck
   // strip ranges of the overlapped sweep, chosen once per vector length from the MEASURED reduce-scatter time of the
   // installed hook (sweep_ranges_auto, klr_select.hip): probe_dim = that length, probe_G = the choice, probe_ms = the time
@@ -170,6 +176,7 @@ struct klr_mat {
   int  group = 64;               // lanes per chunk
   uint8_t* labels = nullptr;     // n
   uint8_t* active = nullptr;     // n row mask (nullable): rows that take part in sums over samples
+  bool view = false;             // klr_mat_view: every device array but `active` belongs to another matrix
   // reduced matrices: every device array above is a slice of ONE pooled block (arena); active_slot = the n bytes
   // reserved for a row mask
   void*    arena = nullptr;

@@ -30,6 +30,16 @@ void mat_free(klr_mat* m) {
     delete m;
     return;
   }
+  if (m->view) {
+    // a view owns its row mask and nothing else
+    if (m->active) {
+      if (ctx_alive(m->ctx) && m->ctx->device == m->device) (void)hipStreamSynchronize(m->ctx->stream);   // its own context's work only
+      else (void)hipDeviceSynchronize();
+      (void)hipFree(m->active);
+    }
+    delete m;
+    return;
+  }
   (void)hipDeviceSynchronize();
   q64_free_ranges(m);
   void* ps[] = {m->rowptr, m->col, m->val, m->colptr, m->crow, m->cval,
@@ -40,6 +50,29 @@ void mat_free(klr_mat* m) {
 }
 
 extern "C" void klr_mat_destroy(klr_mat* mat) { mat_free(mat); }
+
+// A matrix for ANOTHER context of the same device that shares `mat`'s device storage: its own row mask, its own
+// protocol / range state, everything else read-only and common.  `mat` must outlive the view and must not be destroyed
+// or re-masked while views of it are in use by other threads (row masks are per view: klr_mat_set_active_rows).
+extern "C" int klr_mat_view(klr_ctx* ctx, const klr_mat* mat, klr_mat** out) {
+  if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
+  KLR_ARG(ctx, mat != nullptr && out != nullptr);
+  *out = nullptr;
+  if (mat->device != ctx->device) return klr_fail(ctx, KLR_EINVAL, "klr_mat_view: the matrix lives on device %d, the context on %d", mat->device, ctx->device);
+  if (mat->arena) return klr_fail(ctx, KLR_EINVAL, "klr_mat_view: reduced matrices are not shared");
+  klr_mat* v = new klr_mat(*mat);
+  v->ctx = ctx;
+  v->view = true;
+  v->active = nullptr;
+  v->qr = nullptr;
+  v->rs_verified = 0;
+  v->n_total = mat->n_total_all;
+  v->n_active_local = mat->n;
+  v->n1_local = 0;
+  for (uint8_t l : v->h_labels) if (l) v->n1_local++;
+  *out = v;
+  return KLR_OK;
+}
 
 extern "C" int klr_mat_shape(const klr_mat* mat, int64_t* n, int64_t* dim, int64_t* nnz, int64_t* n_total) {
   if (!mat) return klr_fail(nullptr, KLR_EINVAL, "mat is NULL");

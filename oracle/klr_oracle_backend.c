@@ -18,6 +18,7 @@ struct klr_mat {
   /* all rows (owner arrays) */
   klo_csr all; int64_t* a_rowptr; int64_t* a_col; double* a_val; uint8_t* a_labels; int64_t n_total_all;
   uint8_t* mask;
+  int shared;                /* ob_mat_view: the owner arrays belong to another matrix */
 };
 
 static const char* ob_last_error(const klr_ctx* c) { return c ? c->err : ""; }
@@ -47,6 +48,7 @@ static void drop_view(klr_mat* m) {
 static void ob_mat_destroy(klr_mat* m) {
   if (!m) return;
   drop_view(m);
+  if (m->shared) { free(m); return; }
   free(m->a_rowptr); free(m->a_col); free(m->a_val); free(m->a_labels); free(m);
 }
 
@@ -165,6 +167,21 @@ static int ob_cd_solve(klr_ctx* c, const klr_mat* red, double* theta, const doub
                       (klo_iter_rec*)recs, cap, nrecs);
 }
 
+/* concurrent folds (klr_config.threads_cv): a context and a view of the data per host thread */
+static int ob_ctx_fork(klr_ctx* c, klr_ctx** out) { (void)c; *out = (klr_ctx*)calloc(1, sizeof(klr_ctx)); return *out ? 0 : 1; }
+static void ob_ctx_release(klr_ctx* c) { free(c); }
+static int ob_mat_view(klr_ctx* c, const klr_mat* m, klr_mat** out) {
+  (void)c;
+  klr_mat* v = (klr_mat*)calloc(1, sizeof(klr_mat));
+  if (!v) return 1;
+  v->all = m->all; v->a_rowptr = m->a_rowptr; v->a_col = m->a_col; v->a_val = m->a_val; v->a_labels = m->a_labels;
+  v->n_total_all = m->n_total_all;
+  v->rowptr = v->a_rowptr; v->col = v->a_col; v->val = v->a_val; v->labels = v->a_labels;
+  v->x = v->all; v->n_total = v->n_total_all; v->mask = NULL; v->shared = 1;
+  *out = v;
+  return 0;
+}
+
 void klo_backend_table(klr_backend* out) {
   static klr_ctx ctx;
   out->ctx = &ctx;
@@ -181,6 +198,9 @@ void klo_backend_table(klr_backend* out) {
   out->log_pdf = ob_log_pdf;
   out->expand_cooccurrence = ob_expand_cooccurrence;
   out->transform_fit = 0;                                /* the driver then keeps the caller's transform for every fold */
+  out->ctx_fork = ob_ctx_fork;
+  out->ctx_release = ob_ctx_release;
+  out->mat_view = ob_mat_view;
 }
 
 void klo_backend_mat_destroy(klr_mat* m) { ob_mat_destroy(m); }

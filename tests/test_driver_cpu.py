@@ -521,3 +521,37 @@ def test_ensemble_of_cooccurrence_models_file(tmp_path):
         th = dict((int(cc), t) for cc, t in zip(cls[k]["cols"][1:], cls[k]["theta"][1:]))
         np.testing.assert_allclose(lr[k]["Parameters"], [cls[k]["theta"][0]] + [th.get(u, 0.0) for u in uni], rtol=1e-15)
     OD.free_matrix(exp_h); OD.free_matrix(h)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(validation_size=0.2), dict(ensemble_size=2), dict(cooccurrence=1, copreselection=5)])
+def test_crossvalidation_folds_in_threads_change_nothing(kw):
+    """cfg.threads_cv (--threads-cv, kmerLr_crossvalidation.go:176): the folds run at once on forked contexts and views of
+    the data; predictions, losses, classifiers, fold estimators and the order of the trace equal the sequential run's."""
+    x, labels = O.synth_csr(41, 0, 150, 150, 48, 20, 6)
+    k, la = 5, [3, 6]
+    res = []
+    for threads in (1, 3):
+        h = OD.matrix(x, labels)
+        est = OD.estimator(threads_cv=threads, save_trace=1, **kw)
+        r = est.crossvalidate(h, x.n, k, la, seed=9)
+        r["trace"] = est.trace()
+        r["fold_cols"] = [[c["cols"] for c in est.fold(f).classifiers()] for f in range(k)]
+        r["base_cols"] = [est.fold(f).base_cols() for f in range(k)]
+        res.append(r)
+        OD.free_matrix(h)
+    a, b = res
+    np.testing.assert_array_equal(a["groups"], b["groups"])
+    np.testing.assert_array_equal(a["predictions"], b["predictions"])
+    np.testing.assert_array_equal(a["loss_train"], b["loss_train"])
+    np.testing.assert_array_equal(a["loss_test"], b["loss_test"])
+    assert len(a["classifiers"]) == len(b["classifiers"]) > 0
+    for ca, cb in zip(a["classifiers"], b["classifiers"]):
+        np.testing.assert_array_equal(ca["cols"], cb["cols"])
+        np.testing.assert_array_equal(ca["theta"], cb["theta"])
+    assert [(t["iteration"], t["nonzero"], t["loss"]) for t in a["trace"]] == [(t["iteration"], t["nonzero"], t["loss"]) for t in b["trace"]]
+    for fa, fb in zip(a["fold_cols"], b["fold_cols"]):
+        assert len(fa) == len(fb)
+        for u, v in zip(fa, fb):
+            np.testing.assert_array_equal(u, v)
+    for u, v in zip(a["base_cols"], b["base_cols"]):
+        np.testing.assert_array_equal(u, v)

@@ -204,6 +204,37 @@ def test_crossvalidation_on_gpu_matches_oracle_driver(ctx):
     np.testing.assert_allclose(rg["loss_test"], ro["loss_test"], rtol=1e-8)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(validation_size=0.2, data_transform=1), dict(ensemble_size=2)])
+def test_crossvalidation_folds_in_threads_on_gpu(ctx, kw):
+    """klr_config.threads_cv: three folds at once, each on a forked context and a view of the data (shared device storage,
+    its own row mask); every number equals the run with the folds in turn."""
+    x, labels = O.synth_csr(43, 0, 3000, 3000, 2048, 200, 20)
+    m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    res = []
+    for threads in (1, 3):
+        est = K.hip_estimator(ctx, balance=1, threads_cv=threads, save_trace=1, **kw)
+        r = est.crossvalidate(m._h, x.n, 5, [4, 10], seed=2)
+        r["trace"] = [(t["iteration"], t["nonzero"], t["loss"]) for t in est.trace()]
+        r["folds"] = [[c["theta"] for c in est.fold(f).classifiers()] for f in range(5)]
+        res.append(r)
+        est.close()
+    a, b = res
+    np.testing.assert_array_equal(a["predictions"], b["predictions"])
+    np.testing.assert_array_equal(a["loss_train"], b["loss_train"])
+    np.testing.assert_array_equal(a["loss_test"], b["loss_test"])
+    assert len(a["classifiers"]) == len(b["classifiers"]) > 0
+    for ca, cb in zip(a["classifiers"], b["classifiers"]):
+        np.testing.assert_array_equal(ca["cols"], cb["cols"])
+        np.testing.assert_array_equal(ca["theta"], cb["theta"])
+    assert a["trace"] == b["trace"]
+    for fa, fb in zip(a["folds"], b["folds"]):
+        for u, v in zip(fa, fb):
+            np.testing.assert_array_equal(u, v)
+    # the matrix is untouched by the views: a plain estimate afterwards sees all rows
+    assert m.n_total == x.n
+    m.close()
+
+
 def test_full_size_estimate_kkt_and_reproducibility(ctx, setopt):
     """The whole leapfrog run at BASELINE configs[2] size (100k x 65,536, --lambda-auto=100), without the oracle (it would
     take minutes): the classifier has exactly N nonzero coefficients, satisfies the KKT conditions of the L1 problem at
