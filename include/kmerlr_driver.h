@@ -86,6 +86,8 @@ typedef struct klr_config {
                               * runs its folds in a thread pool); 0 / 1 = one after the other.  Needs the backend's
                               * ctx_fork / mat_view and a single rank; otherwise the folds run in turn.  The results
                               * do not depend on it.                                                          */
+  int     threads;           /* --threads (config.Pool): members of klr_estimator_estimate_ensemble that run at once
+                              * (kmerLr_estimator_ensemble.go:81), by the same means; 0 / 1 = in turn         */
 } klr_config;
 
 #define KLR_SUMMARY_MEAN    0   /* {Kmer,Scores}LrEnsemble.Summarize, kmerLr_classifier_ensemble.go:64-104 */

@@ -23,7 +23,7 @@ class Config(C.Structure):
                 ("epsilon_loss", C.c_double), ("eval_loss", C.c_int), ("balance", C.c_int), ("penalty_free", C.c_int),
                 ("save_trace", C.c_int), ("save_path", C.c_int), ("verbose", C.c_int), ("l2reg", C.c_double),
                 ("cooccurrence", C.c_int), ("copreselection", C.c_int64), ("validation_size", C.c_double),
-                ("ensemble_size", C.c_int), ("ensemble_summary", C.c_int), ("data_transform", C.c_int), ("threads_cv", C.c_int)]
+                ("ensemble_size", C.c_int), ("ensemble_summary", C.c_int), ("data_transform", C.c_int), ("threads_cv", C.c_int), ("threads", C.c_int)]
 
 
 def bind_driver(L):

@@ -670,6 +670,7 @@ int main(int argc, char** argv) {
     // --threads-cv (kmerLr_learn.go:146, the pool of kmerLr_crossvalidation.go:176): folds that run at once, each in its
     // own host thread on its own context (one rank only; with --ranks > 1 the folds run in turn)
     cfg.threads_cv = (int)opt_int(o, "threads-cv", "1");
+    cfg.threads = (int)opt_int(go, "threads", "1");                      // config.Pool: the members of an ensemble (:81)
     if (cfg.threads_cv < 1) die("invalid --threads-cv");
     if (flag(o, "adaptive-step-size") || flag(o, "scale-step-size")) say(1, "note: the step-size options belong to the reference's SAGA solver and have no effect here\n");
     const int kfold = (int)opt_int(o, "k-fold-cv", "1");

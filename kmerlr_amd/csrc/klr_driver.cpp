@@ -406,6 +406,47 @@ extern "C" void klr_cv_groups(int64_t n_all, int k_fold, int64_t seed, int64_t r
   klr_cv_groups_val(n_all, k_fold, 0.0, seed, row0, n_local, groups, nullptr);
 }
 
+// Worker contexts for jobs that run at once on one device (folds of a cross-validation, members of an ensemble): every
+// worker has a forked context and a view of the data -- shared storage, its own row mask.  Fewer than two workers (the
+// backend cannot fork, a context with a communicator): the caller runs its jobs in turn on e's own context.
+struct Workers { std::vector<klr_ctx*> ctx; std::vector<klr_mat*> data; };
+static int workers_open(klr_estimator* e, klr_mat* data, int T, Workers& W) {
+  if (T < 2 || !(e->be.ctx_fork && e->be.ctx_release && e->be.mat_view)) return 0;
+  for (int t = 0; t < T; t++) {
+    klr_ctx* c = nullptr; klr_mat* v = nullptr;
+    if (e->be.ctx_fork(e->be.ctx, &c) != KLR_OK || !c) break;             // e.g. a context with a communicator
+    if (e->be.mat_view(c, data, &v) != KLR_OK || !v) { e->be.ctx_release(c); break; }
+    W.ctx.push_back(c); W.data.push_back(v);
+  }
+  if (W.ctx.size() < 2) {
+    for (size_t t = 0; t < W.ctx.size(); t++) { e->be.mat_destroy(W.data[t]); e->be.ctx_release(W.ctx[t]); }
+    W.ctx.clear(); W.data.clear();
+    return 0;
+  }
+  return (int)W.ctx.size();
+}
+static void workers_close(klr_estimator* e, Workers& W) {
+  for (size_t t = 0; t < W.ctx.size(); t++) { e->be.mat_destroy(W.data[t]); e->be.ctx_release(W.ctx[t]); }
+  W.ctx.clear(); W.data.clear();
+}
+// job(t, j): job j on worker t; false ends the run (the other workers finish the job they are on)
+template <class F>
+static void workers_run(const Workers& W, int njobs, F&& job) {
+  std::atomic<int> next(0);
+  std::atomic<bool> failed(false);
+  auto worker = [&](int t) {
+    for (;;) {
+      const int j = next.fetch_add(1);
+      if (j >= njobs || failed.load()) break;
+      if (!job(t, j)) failed.store(true);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < (int)W.ctx.size(); t++) th.emplace_back(worker, t);
+  worker(0);
+  for (std::thread& x : th) x.join();
+}
+
 // what the folds of one cross-validation share (read-only while they run)
 struct CvShared {
   int64_t n = 0, dim = 0, n_all = 0, row0 = 0, seed = 0, nla = 0;
@@ -654,52 +695,23 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
   // the data (shared storage, its own row mask), a fold runs on an estimator of its own; the results are put together in
   // fold order afterwards, so nothing depends on the number of threads.  One rank only: the folds of several ranks would
   // have to post their collectives in one agreed order.
-  int T = std::min(std::max(1, e->cfg.threads_cv), nfold);
-  if (T > 1 && !(e->be.ctx_fork && e->be.ctx_release && e->be.mat_view)) T = 1;
-  std::vector<klr_ctx*> wctx;
-  std::vector<klr_mat*> wdata;
-  const auto t_fork0 = std::chrono::steady_clock::now();
-  for (int t = 0; t < T && T > 1; t++) {
-    klr_ctx* c = nullptr; klr_mat* v = nullptr;
-    if (e->be.ctx_fork(e->be.ctx, &c) != KLR_OK || !c) break;             // e.g. a context with a communicator
-    if (e->be.mat_view(c, data, &v) != KLR_OK || !v) { e->be.ctx_release(c); break; }
-    wctx.push_back(c); wdata.push_back(v);
-  }
-  if (T > 1 && (int)wctx.size() < 2) {
-    say(e, 1, "Cross-validation folds run one after the other (%s)\n", wctx.empty() ? "this backend context cannot be forked" : "one worker");
-    for (size_t t = 0; t < wctx.size(); t++) { e->be.mat_destroy(wdata[t]); e->be.ctx_release(wctx[t]); }
-    wctx.clear(); wdata.clear();
-    T = 1;
-  } else if (T > 1) T = (int)wctx.size();
-  if (T > 1) say(e, 2, "%d folds at once: contexts and views ready after %.1f ms\n", T,
-                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fork0).count() * 1e3);
-  if (T <= 1) {
+  Workers W;
+  const int T = workers_open(e, data, std::min(std::max(1, e->cfg.threads_cv), nfold), W);
+  if (T == 0 && e->cfg.threads_cv > 1 && nfold > 1) say(e, 1, "Cross-validation folds run one after the other (this context is not forked)\n");
+  if (T == 0) {
     for (int f = 0; f < nfold && rc == KLR_OK; f++) rc = cv_fold(e, data, S, f, kept[(size_t)f]);
     e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
   } else {
     std::vector<klr_estimator*> west((size_t)nfold, nullptr);
     std::vector<int> wrc((size_t)nfold, KLR_OK);
-    std::atomic<int> next(0);
-    std::atomic<bool> failed(false);
-    auto worker = [&](int t) {
-      klr_backend be = e->be;
-      be.ctx = wctx[(size_t)t];
-      for (;;) {
-        const int f = next.fetch_add(1);
-        if (f >= nfold || failed.load()) break;
-        klr_estimator* w = fresh_like(e);
-        if (!w) { wrc[(size_t)f] = KLR_EINVAL; failed.store(true); break; }
-        w->be = be;
-        west[(size_t)f] = w;
-        wrc[(size_t)f] = cv_fold(w, wdata[(size_t)t], S, f, kept[(size_t)f]);
-        if (wrc[(size_t)f] != KLR_OK) failed.store(true);
-      }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(worker, t);
-    worker(0);
-    for (std::thread& x : th) x.join();
-    say(e, 2, "folds done after %.1f ms\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fork0).count() * 1e3);
+    workers_run(W, nfold, [&](int t, int f) {
+      klr_estimator* w = fresh_like(e);
+      if (!w) { wrc[(size_t)f] = KLR_EINVAL; return false; }
+      w->be.ctx = W.ctx[(size_t)t];
+      west[(size_t)f] = w;
+      wrc[(size_t)f] = cv_fold(w, W.data[(size_t)t], S, f, kept[(size_t)f]);
+      return wrc[(size_t)f] == KLR_OK;
+    });
     // in fold order: the fold estimators (handed to e, on e's backend from now on), the records, the first error
     for (int f = 0; f < nfold; f++) {
       klr_estimator* w = west[(size_t)f];
@@ -716,7 +728,7 @@ extern "C" int klr_estimator_crossvalidate(klr_estimator* e, klr_mat* data, int6
       }
       klr_estimator_destroy(w);
     }
-    for (size_t t = 0; t < wctx.size(); t++) { e->be.mat_destroy(wdata[t]); e->be.ctx_release(wctx[t]); }
+    workers_close(e, W);
   }
   if (rc == KLR_OK) for (auto& k : kept) for (const Classifier& c : k) all_cls.push_back(c);
   if (rc == KLR_OK) e->out.swap(all_cls);        // fold-major: classifier of fold f, lambda_auto j at f*nla + j (f alone with a validation
@@ -985,18 +997,54 @@ extern "C" int klr_estimator_estimate_ensemble(klr_estimator* e, klr_mat* data, 
   int rc = KLR_OK;
   e->out.clear();
   drop_folds(e);
-  for (int k = 0; k < ensemble_size && rc == KLR_OK; k++) {
-    for (int64_t i = 0; i < n; i++) mask[(size_t)i] = grp[i] != k;                 // filterCvGroup(data_train, groups, nil, k) :84
-    if (e->be.set_active_rows(e->be.ctx, data, mask.data(), n_all - size[(size_t)k]) != KLR_OK) { rc = be_fail(e, KLR_EHIP, "set_active_rows"); break; }
+  // member k on backend `be` and matrix `d` (e's own, or a worker's forked context and view)
+  auto member = [&](const klr_backend& be, klr_mat* d, int k, klr_estimator** out, std::string& err) -> int {
+    std::vector<uint8_t> mk((size_t)std::max<int64_t>(n, 1));
+    for (int64_t i = 0; i < n; i++) mk[(size_t)i] = grp[i] != k;                   // filterCvGroup(data_train, groups, nil, k) :84
+    if (be.set_active_rows(be.ctx, d, mk.data(), n_all - size[(size_t)k]) != KLR_OK) {
+      err = std::string("set_active_rows failed: ") + (be.last_error ? be.last_error(be.ctx) : "");
+      return KLR_EHIP;
+    }
     klr_estimator* me = fresh_like(e);
-    if (!me) { rc = fail(e, KLR_EINVAL, "cannot create member estimator"); break; }
+    if (!me) { err = "cannot create member estimator"; return KLR_EINVAL; }
+    me->be = be;
+    *out = me;
+    const int r = klr_estimator_estimate(me, d, lambda_auto, nla, scale, offset);
+    if (r != KLR_OK) err = me->err;
+    return r;
+  };
+  std::vector<klr_estimator*> mem((size_t)ensemble_size, nullptr);
+  std::vector<int> mrc((size_t)ensemble_size, KLR_OK);
+  std::vector<std::string> merr((size_t)ensemble_size);
+  // members at once (cfg.threads: the reference runs them in config.Pool, kmerLr_estimator_ensemble.go:81), as the folds
+  // of a cross-validation do
+  Workers W;
+  const int T = workers_open(e, data, std::min(std::max(1, e->cfg.threads), ensemble_size), W);
+  if (T == 0) {
+    for (int k = 0; k < ensemble_size; k++) {
+      mrc[(size_t)k] = member(e->be, data, k, &mem[(size_t)k], merr[(size_t)k]);
+      if (mrc[(size_t)k] != KLR_OK) break;
+    }
+    e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
+  } else {
+    workers_run(W, ensemble_size, [&](int t, int k) {
+      klr_backend be = e->be;
+      be.ctx = W.ctx[(size_t)t];
+      mrc[(size_t)k] = member(be, W.data[(size_t)t], k, &mem[(size_t)k], merr[(size_t)k]);
+      return mrc[(size_t)k] == KLR_OK;
+    });
+    workers_close(e, W);
+  }
+  for (int k = 0; k < ensemble_size; k++) {
+    klr_estimator* me = mem[(size_t)k];
+    if (rc == KLR_OK && mrc[(size_t)k] != KLR_OK) { rc = mrc[(size_t)k]; e->err = merr[(size_t)k]; }
+    if (!me) { if (rc == KLR_OK) rc = fail(e, KLR_EINVAL, "ensemble member %d did not run", k + 1); continue; }
+    me->be = e->be;
     e->folds.push_back(me);
-    rc = klr_estimator_estimate(me, data, lambda_auto, nla, scale, offset);
-    if (rc != KLR_OK) { e->err = me->err; break; }
+    if (rc != KLR_OK) continue;
     for (auto& r : me->trace) e->trace.push_back(r);                               // GetTrace :56-62
     for (int64_t j = 0; j < nla; j++) all_cls.push_back(me->out[(size_t)j]);
   }
-  e->be.set_active_rows(e->be.ctx, data, nullptr, 0);
   if (rc == KLR_OK) e->out.swap(all_cls);
   return rc;
 }

@@ -555,3 +555,20 @@ def test_crossvalidation_folds_in_threads_change_nothing(kw):
             np.testing.assert_array_equal(u, v)
     for u, v in zip(a["base_cols"], b["base_cols"]):
         np.testing.assert_array_equal(u, v)
+
+
+def test_ensemble_members_in_threads_change_nothing():
+    """cfg.threads (--threads, config.Pool of kmerLr_estimator_ensemble.go:81): the members of an ensemble at once."""
+    x, labels = O.synth_csr(45, 0, 200, 200, 48, 20, 6)
+    res = []
+    for threads in (1, 3):
+        h = OD.matrix(x, labels)
+        est = OD.estimator(threads=threads, save_trace=1)
+        cls = est.estimate_ensemble(h, x.n, 4, [3, 6], seed=2)
+        res.append((cls, [(t["iteration"], t["nonzero"], t["loss"]) for t in est.trace()]))
+        OD.free_matrix(h)
+    (ca, ta), (cb, tb) = res
+    assert len(ca) == len(cb) == 8 and ta == tb
+    for a, b in zip(ca, cb):
+        np.testing.assert_array_equal(a["cols"], b["cols"])
+        np.testing.assert_array_equal(a["theta"], b["theta"])

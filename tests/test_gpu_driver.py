@@ -235,6 +235,23 @@ def test_crossvalidation_folds_in_threads_on_gpu(ctx, kw):
     m.close()
 
 
+def test_ensemble_members_in_threads_on_gpu(ctx):
+    """klr_config.threads: the members of an ensemble at once on forked contexts; the same classifiers as in turn."""
+    x, labels = O.synth_csr(47, 0, 3000, 3000, 2048, 200, 20)
+    m = K.Matrix.from_csr(ctx, x.n, x.dim, x.rowptr, x.col, x.val, labels)
+    res = []
+    for threads in (1, 3):
+        est = K.hip_estimator(ctx, threads=threads)
+        res.append(est.estimate_ensemble(m._h, x.n, 4, [4, 10], seed=2))
+        est.close()
+    assert len(res[0]) == len(res[1]) == 8
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a["cols"], b["cols"])
+        np.testing.assert_array_equal(a["theta"], b["theta"])
+    assert m.n_total == x.n
+    m.close()
+
+
 def test_full_size_estimate_kkt_and_reproducibility(ctx, setopt):
     """The whole leapfrog run at BASELINE configs[2] size (100k x 65,536, --lambda-auto=100), without the oracle (it would
     take minutes): the classifier has exactly N nonzero coefficients, satisfies the KKT conditions of the L1 problem at
