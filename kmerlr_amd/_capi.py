@@ -148,9 +148,28 @@ class Context:
         """Contexts that have not been closed (tests set KLR_* switches on all of them)."""
         return [c for c in (Context._live or ()) if c._h]
 
+    def fork(self):
+        """klr_ctx_fork: a second context on this device with this one's switches (own stream and workspaces), for another
+        host thread; release() hands it back to this context."""
+        c = Context.__new__(Context)
+        c._h = C.c_void_p()
+        self.check(lib().klr_ctx_fork(self._h, C.byref(c._h)))
+        c._cb = None
+        c._forked = True
+        Context._live.add(c)
+        return c
+
+    def release(self):
+        if self._h:
+            lib().klr_ctx_release(self._h)
+            self._h = C.c_void_p()
+
     def close(self):
         if self._h:
-            lib().klr_ctx_destroy(self._h)
+            if getattr(self, "_forked", False):
+                lib().klr_ctx_release(self._h)
+            else:
+                lib().klr_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -366,6 +385,15 @@ class Matrix:
         ctx.check(lib().klr_mat_from_sequences(ctx._h, C.c_char_p(blob), _p(off), len(bs), M, N, int(revcomp), int(binarize),
                                                _p(labels), n_total, C.byref(h)))
         return Matrix(ctx, h)
+
+    def view(self, ctx):
+        """klr_mat_view: this matrix for another context of the same device -- shared device storage, its own row mask.
+        The matrix must outlive the view."""
+        h = C.c_void_p()
+        ctx.check(lib().klr_mat_view(ctx._h, self._h, C.byref(h)))
+        v = Matrix(ctx, h)
+        v._base = self
+        return v
 
     def close(self):
         if self._h:

@@ -81,3 +81,46 @@ def test_options_belong_to_the_context(monkeypatch):
     for m_ in (ma, mb, mc, md):
         m_.close()
     a.close(); b.close()
+
+
+def test_forked_context_and_matrix_view():
+    """klr_ctx_fork / klr_mat_view: a view shares the device storage of the matrix and has its own row mask -- the base
+    matrix keeps its rows, two views with different masks work side by side from two threads, and a released context
+    comes back warm on the next fork."""
+    ctx = K.Context(0)
+    n, mm = 6000, 4096
+    rowptr, col, val, labels = K.synth_csr(61, 0, n, n, mm, 300, 10)
+    m = K.Matrix.from_csr(ctx, n, mm + 1, rowptr, col, val, labels)
+    theta = np.zeros(mm + 1)
+    g_all = K.gradient_dense(ctx, m, theta)
+    rng = np.random.default_rng(3)
+    masks = [(rng.random(n) < 0.6).astype(np.uint8) for _ in range(2)]
+    want = []
+    for mk in masks:
+        m.set_active_rows(mk, int(mk.sum()))
+        want.append(K.gradient_dense(ctx, m, theta))
+    m.set_active_rows(None)
+    got = [None, None]
+    forks = [ctx.fork(), ctx.fork()]
+
+    def work(t):
+        v = m.view(forks[t])
+        v.set_active_rows(masks[t], int(masks[t].sum()))
+        for _ in range(5):
+            got[t] = K.gradient_dense(forks[t], v, theta)
+        v.close()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    for t in range(2):
+        np.testing.assert_array_equal(got[t], want[t])
+    np.testing.assert_array_equal(K.gradient_dense(ctx, m, theta), g_all)        # the base never saw a mask
+    handles = {forks[0]._h.value, forks[1]._h.value}
+    forks[0].release(); forks[1].release()
+    again = ctx.fork()
+    assert again._h.value in handles                                             # a pooled context comes back
+    again.release()
+    m.close(); ctx.close()
