@@ -494,6 +494,48 @@ static const OptSpec PREDICT_OPTS[] = {{"header", false}, {"help", false}, {null
 static const char* KMER_ONLY[] = {"alphabet", "binarize", "complement", "max-ambiguous", "reverse", "revcomp", nullptr};
 static const char* SCORES_ONLY[] = {"header", nullptr};
 
+// <command> --help: the options of the reference's tables with what they do HERE
+static void print_help(const std::string& cmd, bool scores) {
+  if (cmd == "learn") {
+    printf("usage: kmerlr %slearn [options] %s\n\n", scores ? "--type=scoresLr " : "",
+           scores ? "[MODEL.json] FG.table BG.table BASENAME" : "<<M> <N>|<MODEL.json>> FG.fa BG.fa BASENAME");
+    if (!scores) printf(
+      "  --alphabet=NAME            nucleotide (default), gapped-nucleotide or iupac-nucleotide\n"
+      "  --binarize                 count a k-mer at most once per sequence\n"
+      "  --complement, --reverse, --revcomp\n"
+      "                             count a k-mer together with its complement / reverse / reverse complement\n"
+      "  --max-ambiguous=N[,N..]    most ambiguous positions of a k-mer: one number, or one per k-mer length M..N\n");
+    else printf("  --header                   the tables start with a line of feature names\n");
+    printf(
+      "  --lambda-auto=N[,N..]      features to select; one classifier per value, each starting from the one before\n"
+      "  --lambda=F                 fixed regularisation strength instead (--max-features=N caps the selection)\n"
+      "  --balance                  class weights n / (2 n_class)\n"
+      "  --co-occurrence            pair features x_i x_j; --co-preselection=Q builds them on Q pre-selected features\n"
+      "  --ensemble-size=E          E members, member k trained without the k-th part of the rows;\n"
+      "  --ensemble-summary=S       their predictions summarised by mean (default), product, min or max\n"
+      "  --k-fold-cv=K              K-fold cross-validation: BASENAME_cv<f>*.json, BASENAME*.table, BASENAME*_loss.table\n"
+      "  --validation-size=F        fraction of the rows set aside to choose among the --lambda-auto classifiers\n"
+      "  --data-transform=T         none (default), standardizer, variance-scaler, max-abs-scaler, mean-scaler\n"
+      "  --max-samples=N            use the first N samples (split evenly over the two classes)\n"
+      "  --max-epochs=N, --max-iterations=N, --epsilon=F, --epsilon-lambda=F, --epsilon-loss=F (1e-8), --eval-loss\n"
+      "                             stopping rules of the leapfrog loop and of the solver\n"
+      "  --penalty-free             re-estimate the selected coefficients without the penalty\n"
+      "  --save-trace, --save-path  write BASENAME.trace / BASENAME.path\n"
+      "  --threads-cv=T             folds that run at once on the device (one rank)\n"
+      "  --threads-saga, --threads-lr, --scale-step-size, --adaptive-step-size\n"
+      "                             accepted for the reference's command lines; its SAGA solver is not used here\n"
+      "global: --type=kmerLr|scoresLr, -v, --seed=S, --threads=T (ensemble members at once), --device=N,\n"
+      "        --ranks=N [--transport=rccl|shm] [--devices=a,b,..]: one process per GPU over row shards\n");
+  } else if (cmd == "loss") {
+    printf("usage: kmerlr %sloss [--lambda=F] [--balance]%s MODEL.json FG BG [RESULT.table]\n"
+           "  the model's loss on the data: mean negative log-likelihood (+ lambda |theta|_1), class-weighted with --balance\n",
+           scores ? "--type=scoresLr " : "", scores ? " [--header]" : "");
+  } else {
+    printf("usage: kmerlr %spredict%s MODEL.json DATA [RESULT.table]\n"
+           "  log sigma(x . theta) per row (ensembles: the summary of the members)\n", scores ? "--type=scoresLr " : "", scores ? " [--header]" : "");
+  }
+}
+
 struct Options { std::map<std::string, std::string> kv; std::vector<std::string> pos; };
 static const OptSpec* find_opt(const OptSpec* table, const std::string& name) {
   for (const OptSpec* o = table; o->name; o++) if (name == o->name) return o;
@@ -668,6 +710,7 @@ int main(int argc, char** argv) {
   const OptSpec* table = cmd == "learn" ? LEARN_OPTS : cmd == "loss" ? LOSS_OPTS : cmd == "predict" ? PREDICT_OPTS : nullptr;
   if (!table) die("unknown command `%s' (this build provides learn, loss and predict)", cmd.c_str());
   Options o = parse(argc, argv, ci + 1, table, false, nullptr);
+  if (flag(o, "help")) { print_help(cmd, scores); return 0; }
   for (const char** k = scores ? KMER_ONLY : SCORES_ONLY; *k; k++)
     if (flag(o, *k)) die("unknown option `--%s' for --type=%s", *k, scores ? "scoresLr" : "kmerLr");
   if (flag(o, "seed")) g_seed = opt(o, "seed", "1");

@@ -70,3 +70,20 @@ def test_no_device_fails_loudly_also_through_the_rank_launcher(tmp_path):
         r = run(["--type=scoresLr", "--ranks=2", "--transport=" + transport, "learn", "--lambda-auto=2", SFG, SBG, str(tmp_path / "y")], timeout=180)
         assert r.returncode != 0 and r.stderr.count("no HIP device") == 2 and "[rank 0]" in r.stderr and "[rank 1]" in r.stderr, r.stderr
     assert not os.path.exists(tmp_path / "x.json") and not os.path.exists(tmp_path / "y.json")
+
+
+def test_command_help_lists_every_option_of_the_tables():
+    """`kmerlr <command> --help` needs no device and names every option the command accepts."""
+    r = run(["learn", "--help"])
+    assert r.returncode == 0 and r.stdout.startswith("usage: kmerlr learn")
+    for opt in ("lambda-auto", "lambda", "max-features", "balance", "co-occurrence", "co-preselection", "ensemble-size",
+                "ensemble-summary", "max-epochs", "max-iterations", "max-samples", "epsilon", "epsilon-lambda", "epsilon-loss",
+                "save-trace", "save-path", "eval-loss", "data-transform", "k-fold-cv", "validation-size", "scale-step-size",
+                "penalty-free", "adaptive-step-size", "threads-cv", "threads-saga", "threads-lr", "alphabet", "binarize",
+                "complement", "max-ambiguous", "reverse", "revcomp"):
+        assert "--" + opt in r.stdout, opt
+    r = run(["--type=scoresLr", "learn", "-h"])
+    assert r.returncode == 0 and "--header" in r.stdout and "--binarize" not in r.stdout
+    for cmd in ("loss", "predict"):
+        r = run([cmd, "--help"])
+        assert r.returncode == 0 and r.stdout.startswith("usage: kmerlr " + cmd)
