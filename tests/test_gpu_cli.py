@@ -126,6 +126,24 @@ def test_scores_learn_kfold_cv(tmp_path):
     assert lt[0] == "%15s\t%15s" % ("train", "test") and len(lt) == 5
 
 
+def test_threads_cv_writes_the_same_files(tmp_path):
+    # --threads-cv (kmerLr_learn.go:146): the folds at once on the device; every file byte for byte the sequential run's
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
+    common = ["learn", "--lambda-auto=3,6", "--k-fold-cv=4", "--save-trace", "--seed=2", "3", "4", fg, bg]
+    run(common + ["s"], tmp_path)
+    run(common[:1] + ["--threads-cv=3"] + common[1:] + ["t"], tmp_path)
+    names = sorted(f[1:] for f in os.listdir(tmp_path) if f.startswith("s"))
+    assert len(names) >= 4 * 2 + 4 and any(n.endswith(".table") for n in names)
+    for nm in names:
+        a = open(tmp_path / ("s" + nm)).read()
+        b = open(tmp_path / ("t" + nm)).read()
+        if nm.endswith(".trace"):
+            strip = lambda t: [ln.split()[1:] for ln in t.splitlines()]       # the first column is wall-clock time
+            assert strip(a) == strip(b), nm
+        else:
+            assert a == b, nm
+
+
 def test_predict_and_data_transform(tmp_path):
     # TestKmers6-style constant predictions are covered by G7; here: predict == log sigma(x.theta) of the model,
     # and --data-transform=variance-scaler goes through the device fit
