@@ -86,33 +86,73 @@ static void reduce_samples(int64_t max_samples, int64_t* n1, int64_t* n2) {
 // ---- scores tables: read_scores_table + convert_scores (scoresLr_data.go:56-145) ---------------------
 // rows [first, last) of the table go into d (a rank's block); every row is parsed for the checks the reference makes.
 // Returns the number of data rows in the file.
+// the whole file in memory (tables and FASTA files are read once, in one piece)
+static void read_whole(const std::string& fn, std::string& b, const char* failed_prefix) {
+  FILE* f = fopen(fn.c_str(), "rb");
+  if (!f) die("%scannot open `%s'", failed_prefix, fn.c_str());
+  b.clear();
+  if (fseek(f, 0, SEEK_END) == 0) { const long sz = ftell(f); if (sz > 0) b.reserve((size_t)sz); }
+  rewind(f);
+  std::vector<char> chunk((size_t)4 << 20);
+  size_t got;
+  while ((got = fread(chunk.data(), 1, chunk.size(), f)) > 0) b.append(chunk.data(), got);
+  fclose(f);
+}
+
 static int64_t read_scores(const std::string& fn, bool header, uint8_t label, DataSet& d, int64_t first = 0, int64_t last = INT64_MAX) {
   say(1, "Reading scores from `%s'... ", fn.c_str());
-  std::ifstream f(fn);
-  if (!f) die("failed\ncannot open `%s'", fn.c_str());
-  std::string line;
+  std::string buf;
+  read_whole(fn, buf, "failed\n");
   bool need_header = header;
   int64_t lineno = 0, row = 0;
-  while (std::getline(f, line)) {
+  const char* p = buf.data(); const char* const e = p + buf.size();
+  std::vector<double> vals;
+  while (p < e) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+    const char* le = nl ? nl : e;
+    const char* a = p;
+    p = nl ? nl + 1 : e;
     lineno++;
-    if (line.empty()) continue;
-    std::vector<std::string> fields;
-    { std::stringstream ss(line); std::string t; while (std::getline(ss, t, ',')) if (!t.empty()) fields.push_back(t); }
-    if (need_header) { if (d.names.empty()) d.names = fields; need_header = false; continue; }
-    if (d.dim == 0) d.dim = (int64_t)fields.size() + 1;
-    if ((int64_t)fields.size() + 1 != d.dim) die("failed\nError: data has variable number of features");
-    const bool keep = row >= first && row < last;
-    if (keep) { d.col.push_back(0); d.val.push_back(1.0); }        // bias
-    for (size_t j = 0; j < fields.size(); j++) {
-      char* end = nullptr;
-      std::string t = fields[j];
-      size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r");
-      t = a == std::string::npos ? "" : t.substr(a, b - a + 1);
-      const double v = strtod(t.c_str(), &end);
-      if (t.empty() || *end) die("failed\nparsing scores failed at line `%lld'", (long long)lineno);
-      if (keep) { d.col.push_back((int64_t)j + 1); d.val.push_back(v); }   // every column stored, zeros included
+    if (le == a) continue;                                             // empty line
+    if (need_header) {
+      if (d.names.empty()) {                                           // fields as they are; empty ones dropped
+        for (const char* q = a; q <= le;) {
+          const char* c = (const char*)memchr(q, ',', (size_t)(le - q));
+          const char* fe = c ? c : le;
+          if (fe > q) d.names.emplace_back(q, (size_t)(fe - q));
+          q = fe + 1;
+        }
+      }
+      need_header = false;
+      continue;
     }
-    if (keep) { d.rowptr.push_back((int64_t)d.col.size()); d.labels.push_back(label); }
+    // fields between commas, empty ones dropped, the others trimmed and parsed (read_scores_table, scoresLr_data.go:56-100)
+    vals.clear();
+    for (const char* q = a; q <= le;) {
+      const char* c = (const char*)memchr(q, ',', (size_t)(le - q));
+      const char* fe = c ? c : le;
+      if (fe > q) {
+        const char* t0 = q; const char* t1 = fe;
+        while (t0 < t1 && (*t0 == ' ' || *t0 == '\t' || *t0 == '\r')) t0++;
+        while (t1 > t0 && (t1[-1] == ' ' || t1[-1] == '\t' || t1[-1] == '\r')) t1--;
+        char tok[128];
+        const size_t len = (size_t)(t1 - t0);
+        if (len == 0 || len >= sizeof(tok)) die("failed\nparsing scores failed at line `%lld'", (long long)lineno);
+        memcpy(tok, t0, len); tok[len] = 0;
+        char* end = nullptr;
+        const double v = strtod(tok, &end);
+        if (*end) die("failed\nparsing scores failed at line `%lld'", (long long)lineno);
+        vals.push_back(v);
+      }
+      q = fe + 1;
+    }
+    if (d.dim == 0) d.dim = (int64_t)vals.size() + 1;
+    if ((int64_t)vals.size() + 1 != d.dim) die("failed\nError: data has variable number of features");
+    if (row >= first && row < last) {
+      d.col.push_back(0); d.val.push_back(1.0);                        // bias
+      for (size_t j = 0; j < vals.size(); j++) { d.col.push_back((int64_t)j + 1); d.val.push_back(vals[j]); }   // every column stored, zeros included
+      d.rowptr.push_back((int64_t)d.col.size()); d.labels.push_back(label);
+    }
     row++;
   }
   say(1, "done\n");
@@ -120,10 +160,16 @@ static int64_t read_scores(const std::string& fn, bool header, uint8_t label, Da
 }
 
 static int64_t count_scores_rows(const std::string& fn, bool header) {
-  std::ifstream f(fn);
-  if (!f) die("cannot open `%s'", fn.c_str());
-  std::string line; int64_t n = 0; bool need_header = header;
-  while (std::getline(f, line)) { if (line.empty()) continue; if (need_header) { need_header = false; continue; } n++; }
+  std::string buf;
+  read_whole(fn, buf, "");
+  int64_t n = 0; bool need_header = header;
+  const char* p = buf.data(); const char* const e = p + buf.size();
+  while (p < e) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+    const char* le = nl ? nl : e;
+    if (le > p) { if (need_header) need_header = false; else n++; }
+    p = nl ? nl + 1 : e;
+  }
   return n;
 }
 
@@ -189,15 +235,8 @@ struct FastaFile {
 
 static void load_fasta(const std::string& fn, FastaFile& F) {
   F.fn = fn; F.buf.clear(); F.rec.clear();
-  FILE* f = fopen(fn.c_str(), "rb");
-  if (!f) die("cannot open `%s'", fn.c_str());
   std::string& b = F.buf;
-  if (fseek(f, 0, SEEK_END) == 0) { const long sz = ftell(f); if (sz > 0) b.reserve((size_t)sz); }
-  rewind(f);
-  std::vector<char> chunk((size_t)4 << 20);
-  size_t got;
-  while ((got = fread(chunk.data(), 1, chunk.size(), f)) > 0) b.append(chunk.data(), got);
-  fclose(f);
+  read_whole(fn, b, "");
   // header lines: '>' at the start of a line
   const char* p = b.data(); const char* const e = p + b.size();
   while (p < e) {
