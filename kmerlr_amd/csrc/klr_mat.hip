@@ -12,6 +12,8 @@
 // integers), else f64; all accumulation is f64.
 #include "klr_internal.h"
 
+#include <memory>
+
 #include <algorithm>
 #include <cstring>
 #include <cmath>
@@ -458,8 +460,9 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
   // large inputs also get their narrow copy (u32 column, f32 value) in this pass: if they turn out to be count data,
   // the device builds CSC and tiles from it (KLR_HOST_INGEST=1 keeps everything on the host)
   const bool maybe_device = n >= 2048 && nnz >= (1 << 20) && !ctx_opt(ctx, "KLR_HOST_INGEST");
-  std::vector<u32> n_col(maybe_device ? (size_t)nnz : 0);
-  std::vector<float> n_val(maybe_device ? (size_t)nnz : 0);
+  // (not value-initialised: a vector would touch 8 bytes per entry on ONE thread before the worker threads fill them)
+  std::unique_ptr<u32[]> n_col(maybe_device ? new u32[(size_t)std::max<i64>(nnz, 1)] : nullptr);
+  std::unique_ptr<float[]> n_val(maybe_device ? new float[(size_t)std::max<i64>(nnz, 1)] : nullptr);
   auto rows_of = [&](int t, i64& r0, i64& r1) { r0 = n * t / T; r1 = n * (t + 1) / T; };
   {
     std::vector<std::thread> th;
@@ -506,8 +509,8 @@ extern "C" int klr_mat_from_csr(klr_ctx* ctx, int64_t n, int64_t dim, const int6
       if ((rc = dev_alloc(ctx, &m->val, (size_t)nnz * 4))) break;
       if ((rc = dev_alloc(ctx, (void**)&m->labels, (size_t)n))) break;
       hipError_t e = hipMemcpy(m->rowptr, rowptr, (size_t)(n + 1) * sizeof(i64), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(m->col, n_col.data(), (size_t)nnz * sizeof(u32), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(m->val, n_val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(m->col, n_col.get(), (size_t)nnz * sizeof(u32), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(m->val, n_val.get(), (size_t)nnz * 4, hipMemcpyHostToDevice);
       if (e == hipSuccess) e = hipMemcpy(m->labels, labels, (size_t)n, hipMemcpyHostToDevice);
       if (e != hipSuccess) { rc = klr_fail(ctx, KLR_EHIP, "matrix upload failed: %s", hipGetErrorString(e)); break; }
       rc = device_finish_csr(ctx, m);
