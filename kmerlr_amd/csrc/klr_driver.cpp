@@ -248,6 +248,10 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
   if (e->cols.size() > 1) { if ((rc = rebuild()) != KLR_OK) return rc; }
 
   std::vector<uint8_t> b((size_t)dim);
+  // -vvv: where the host's time goes (seconds in the backend's sweep_select / select_columns / reduced solve, and in between)
+  double t_sweep = 0.0, t_sub = 0.0, t_solve = 0.0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   for (int64_t epoch = 0; e->cfg.max_epochs == 0 || epoch < e->cfg.max_epochs; epoch++) {   // :225
     // The reference's loop has no bound (kmerLr_estimator.go:225): on degenerate data -- a training set of one class, whose
     // intercept runs off -- it selects new features at lambda -> 0 for ever.  A library must not: a run that is still
@@ -262,8 +266,10 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
     double lambda = 0.0; int64_t c = 0; int ok = 0;
     if (lambda_auto) {
       // featureSelector.Select (kmerLr_estimator.go:235)
+      const auto t0 = std::chrono::steady_clock::now();
       rc = e->be.sweep_select(e->be.ctx, data, red, e->cols.data(), e->theta.data(), (int64_t)e->cols.size(), e->cw, N,
                               e->l1reg, e->cfg.epsilon_lambda, scale, offset, b.data(), &lambda, &c, &ok, nullptr, nullptr);
+      t_sweep += since(t0);
       if (rc != KLR_OK) { rc = be_fail(e, rc, "sweep_select"); break; }
     } else {
       // featureSelector.SelectFixed (kmerLr_feature_selection.go:136-159)
@@ -285,10 +291,12 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
     if (!ok && have) break;                                                                   // :236-238
     e->l1reg = lambda * (double)n_total;                                                      // :239
     adopt_selection(e, b);                                                                    // :240-242
-    if ((rc = rebuild()) != KLR_OK) break;                                                    // :244 selection.Data
+    { const auto t0 = std::chrono::steady_clock::now(); rc = rebuild(); t_sub += since(t0); }  // :244 selection.Data
+    if (rc != KLR_OK) break;
     if (lambda_auto) say(e, 1, "Estimating parameters with lambda=%e...\n", lambda);          // :246
     else say(e, 1, "Estimating parameters with lambda=%e and %lld features...\n", lambda, (long long)(e->cols.size() - 1));
-    if ((rc = solve_reduced(e, red, n_total, e->l1reg, e->theta)) != KLR_OK) break;           // :247
+    { const auto t0 = std::chrono::steady_clock::now(); rc = solve_reduced(e, red, n_total, e->l1reg, e->theta); t_solve += since(t0); }   // :247
+    if (rc != KLR_OK) break;
     if (e->cfg.save_path) {                                                                   // :168-170
       std::vector<int64_t> feat; std::vector<double> th;
       for (size_t p = 1; p < e->cols.size(); p++) { feat.push_back(e->cols[p] - 1); th.push_back(e->theta[p]); }
@@ -299,6 +307,8 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
     e->ep_lambda.push_back(lambda); e->ep_nonzero.push_back(nz);
     have = true;
   }
+  say(e, 3, "leapfrog loop: %.3f ms in all, sweep + selection %.3f, column sub-select %.3f, reduced solve %.3f, the driver itself %.3f\n",
+      since(t_begin) * 1e3, t_sweep * 1e3, t_sub * 1e3, t_solve * 1e3, (since(t_begin) - t_sweep - t_sub - t_solve) * 1e3);
   if (rc == KLR_OK && have) {
     Classifier cl;
     cl.cols = e->cols; cl.theta = e->theta; cl.lambda = e->l1reg / (double)n_total;
