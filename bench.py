@@ -355,6 +355,7 @@ def main(argv=None):
     info = ctx.comm_info()
     ar_ms = ctx.allreduce_time(m + 6, dtype=1, iters=20) if R.comm else 0.0
     stats_c2 = ctx.comm_stats()
+    probe_c2 = ctx.comm_probe()                      # what the context measured for THIS shape (a later shape measures again)
 
     configs3 = None
     if not args.no_configs3:                   # at EVERY N: the 1 -> 8 curve of the 1M-column shape needs all its points
@@ -381,8 +382,8 @@ def main(argv=None):
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "comm": {"n_ranks_seen": (info["nranks"] if R.shm else info["rccl_ranks"]) if R.comm else 1, "allreduce_ms": round(ar_ms, 4),
-                     "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N),
-                     "selfcheck": "passed" if R.comm else "no communicator", "stats": stats_c2, "probe": ctx.comm_probe()},
+                     "allreduce_elements": m + 6 if R.comm else 0, "sweep_collective": sweep_collective(world, m, N, probe_c2),
+                     "selfcheck": "passed" if R.comm else "no communicator", "stats": stats_c2, "probe": probe_c2},
             "cd_sweeps_per_s": cd["sweeps_per_s"], "cd_sweeps": cd,
             "cd_solve": {"sweeps_to_converge": n_sweeps_solve, "seconds": round(t_solve, 4), "nonzero": int(np.count_nonzero(theta[1:]))},
             "estimate_lambda_auto": estimate,
@@ -418,12 +419,12 @@ def sweep_kernel_in_estimate(R, mat, lam_auto):
 
 
 def sweep_collective(world, m, N, probe=None):
-    """What klr_sweep_select posts per sweep (klr_select.hip): one rank nothing; from 131,072 columns on (KLR_RS_MIN_DIM)
+    """What klr_sweep_select posts per sweep (klr_select.hip): one rank nothing; from 32,768 columns on (KLR_RS_MIN_DIM)
     whichever the context MEASURED to be faster on this communicator (klr_ctx_comm_probe): a reduce-scatter of the int64
     column sums + an all-gather of nranks x 2N candidates, or one all-reduce; below that one all-reduce."""
     if world <= 1:
         return "none (one rank)"
-    if m + 1 >= int(os.environ.get("KLR_RS_MIN_DIM", "131072")) and 2 * N <= 4096:
+    if m + 1 >= int(os.environ.get("KLR_RS_MIN_DIM", "32768")) and 2 * N <= 4096:
         if probe and probe.get("form") == "all-reduce" and probe.get("elements") == m + 6:
             return "all-reduce of %d int64 (measured faster than reduce-scatter + all-gather here)" % (m + 6)
         return "reduce-scatter of %d int64 + all-gather of %d x %d candidates" % (m + 6, world, 2 * N)

@@ -101,7 +101,7 @@ struct klr_ctx {
     int  stream_nt = 1;          // KLR_STREAM_NT
     int  finish_iter = 0;        // KLR_FINISH_ITER (0: by width)
     bool finish_no_flat = false; // KLR_FINISH_NO_FLAT
-    i64  rs_min_dim = 131072;    // KLR_RS_MIN_DIM
+    i64  rs_min_dim = 32768;     // KLR_RS_MIN_DIM: from here on the two forms of the collective are TIMED and the faster one used
     bool rs_force = false;       // KLR_RS_FORCE
     int  rs = -1;                // KLR_RS: 1 reduce-scatter form on, 0 off, -1 default (on once the communicator passed its self-check)
     int  overlap = -1;           // KLR_SWEEP_RANGES: strip ranges of the overlapped sweep (0/1: off; -1: default)
