@@ -49,6 +49,10 @@ typedef struct klr_backend {
   int  (*ctx_fork)(klr_ctx*, klr_ctx**);
   void (*ctx_release)(klr_ctx*);
   int  (*mat_view)(klr_ctx*, const klr_mat*, klr_mat**);
+  /* optional: a new run of consecutive reduced solves begins (klr_estimator_estimate).  The HIP backend sizes the first
+   * batch of sweeps of a re-linearisation by what the same re-linearisation took in the solve before (the iterates do not
+   * depend on it); the call forgets that history, so that a run is the same whatever the context did before */
+  void (*solve_run_begin)(klr_ctx*);
 } klr_backend;
 
 /* the HIP table for an existing context */

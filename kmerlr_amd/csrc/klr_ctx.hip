@@ -427,6 +427,13 @@ extern "C" int klr_ctx_comm_ranged(const klr_ctx* ctx, int64_t* sweeps_ranged) {
   return KLR_OK;
 }
 
+// klr_backend.solve_run_begin: a new run of reduced solves (one leapfrog estimate) starts on this context
+extern "C" void klr_solve_run_begin(klr_ctx* ctx) {
+  if (!ctx) return;
+  ctx->cd_pred.clear();
+  ctx->cd_pred_on = !ctx_opt(ctx, "KLR_CD_NO_PREDICT");
+}
+
 extern "C" int klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_allgather_fn ag, void* user) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, (rs == nullptr) == (ag == nullptr));
@@ -709,5 +716,6 @@ extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
   out->ctx_fork = klr_ctx_fork;
   out->ctx_release = klr_ctx_release;
   out->mat_view = klr_mat_view;
+  out->solve_run_begin = klr_solve_run_begin;
   return KLR_OK;
 }

@@ -233,6 +233,7 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
     if (e->be.class_weights(e->be.ctx, data, e->cw) != KLR_OK) return be_fail(e, KLR_EHIP, "class_weights");
   } else { e->cw[0] = 1.0; e->cw[1] = 1.0; }
 
+  if (e->be.solve_run_begin) e->be.solve_run_begin(e->be.ctx);
   klr_mat* red = nullptr;
   std::vector<double> sc, of;
   int rc = KLR_OK;

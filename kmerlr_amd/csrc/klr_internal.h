@@ -113,6 +113,10 @@ struct klr_ctx {
   i64 n_rs_sweeps = 0, n_rs_fallbacks = 0, n_ar_sweeps = 0, n_ranged_sweeps = 0;
   // klr_ctx_fork: the contexts forked from this one that are not in use (klr_ctx_release puts them back: warm workspaces
   // for the next cross-validation); they end with this context
+  // klr_cd_solve: accepted sweeps of re-linearisation r in the previous solve of this run (klr_solve_run_begin clears it
+  // and switches the prediction on): sizes the first batch of re-linearisation r of the next solve
+  std::vector<int> cd_pred;
+  bool cd_pred_on = false;
   klr_ctx* fork_parent = nullptr;
   std::vector<klr_ctx*> fork_idle;
   std::mutex fork_mu;

@@ -1574,6 +1574,9 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   };
 
   int relin = 0;                   // re-linearisations so far
+  // accepted sweeps per re-linearisation of the PREVIOUS solve of this run (klr_solve_run_begin); this solve leaves its own
+  std::vector<int> cd_prev;
+  if (ctx->cd_pred_on) { cd_prev.swap(ctx->cd_pred); ctx->cd_pred.clear(); }
   const int first_k = ctx_opt(ctx, "KLR_CD_FIRST_BATCH") ? std::max(1, std::min(KSPEC, atoi(ctx_opt(ctx, "KLR_CD_FIRST_BATCH")))) : 1;
   // sweeps per speculative batch: a batch costs ~45 us beside its sweeps (launches, loss pass, report, host turn) and
   // wastes (K-1)/2 sweeps on average when the loss rule stops it; a sweep is ~8 us at d = 101 and ~67 us at d = 501:
@@ -1669,8 +1672,13 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       // sweeps are launched in speculative batches; the loss rule usually ends the inner loop of a LATER
       // re-linearisation at its first sweep (the model barely moves any more): probe with one sweep first
       const bool probe = relin >= 1 && first_batch && eps_loss != 0.0;
+      // ... unless the same re-linearisation of the previous solve of this run took sweeps (the early epochs of a leapfrog
+      // run: 7, 10, 9, 8, ... accepted sweeps in the second re-linearisation): then that many + the stopping one
+      int probe_k = first_k;
+      if (probe && relin < (int)cd_prev.size() && cd_prev[(size_t)relin] > 0)
+        probe_k = std::min(batch_k, cd_prev[(size_t)relin] + 1);
       first_batch = false;
-      const int Kb = (int)std::min<i64>(probe ? first_k : batch_k, max_iter - iter);
+      const int Kb = (int)std::min<i64>(probe ? probe_k : batch_k, max_iter - iter);
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
@@ -1774,6 +1782,10 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (nd == 0) inner_done = true;
     }
     if (ctx_opt(ctx, "KLR_CD_DEBUG")) fprintf(stderr, "[cd] d=%d inner sweeps=%lld stopf=%d\n", d, (long long)(iter - dbg_iter0), dbg_stopk);
+    if (ctx->cd_pred_on) {
+      if ((int)ctx->cd_pred.size() <= relin) ctx->cd_pred.resize((size_t)relin + 1, 0);
+      ctx->cd_pred[(size_t)relin] = (int)std::min<i64>(iter - dbg_iter0, 1 << 20);
+    }
     // ---- outer checks -----------------------------------------------------------------------------
     double dl;
     if (host_eval_stopping(tp.data(), th.data(), d, eps, &dl)) break;                   // coordinate.go:119-120

@@ -201,6 +201,7 @@ void klo_backend_table(klr_backend* out) {
   out->ctx_fork = ob_ctx_fork;
   out->ctx_release = ob_ctx_release;
   out->mat_view = ob_mat_view;
+  out->solve_run_begin = 0;
 }
 
 void klo_backend_mat_destroy(klr_mat* m) { ob_mat_destroy(m); }
