@@ -1678,7 +1678,14 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
       if (probe && relin < (int)cd_prev.size() && cd_prev[(size_t)relin] > 0)
         probe_k = std::min(batch_k, cd_prev[(size_t)relin] + 1);
       first_batch = false;
-      const int Kb = (int)std::min<i64>(probe ? probe_k : batch_k, max_iter - iter);
+      int want_k = probe ? probe_k : batch_k;
+      // a later batch of a re-linearisation whose like took p sweeps last time: no more than what is left of p (+ the stopping
+      // sweep); past p, full batches again
+      if (!probe && relin < (int)cd_prev.size() && cd_prev[(size_t)relin] > 0) {
+        const i64 left = (i64)cd_prev[(size_t)relin] + 1 - (iter - dbg_iter0);
+        if (left > 0) want_k = (int)std::min<i64>(KSPEC, left);     // (also past the cautious default of large problems)
+      }
+      const int Kb = (int)std::min<i64>(want_k, max_iter - iter);
       CdArgs a;
       a.G = G; a.xy = xy; a.d = d; a.theta = thd; a.l1reg = l1reg; a.l2reg = l2reg; a.eps = eps; a.K = Kb;
       a.hist = hist; a.delta = delta; a.stopf = stopf; a.ndone = ndone; a.g_in_lds = g_in_lds;
