@@ -19,7 +19,7 @@
 #include <chrono>
 #include <cmath>
 
-#define KSPEC 8          // sweeps per launch
+#define KSPEC 16         // most sweeps per launch (a batch is 8 or 4 by default, up to this many when the run's history says so)
 #define CD_THREADS 1024
 
 
@@ -1388,13 +1388,13 @@ __global__ __launch_bounds__(TPB) void k_loss_multi(const i64* __restrict__ rowp
                                                     double cw0, double cw1, double* __restrict__ blk, int kl_log2) {
   // kl = 1 << kl_log2 lanes per row (the batch holds at most kl iterates): a probe batch of one sweep keeps every
   // lane on a row of its own -- the exp / log1p chain costs a wavefront the same whether 1 or 8 of 8 lanes need it
-  extern __shared__ double lm_lds[];            // KSPEC * d iterates, layout [column][k]
+  extern __shared__ double lm_lds[];            // kl * d iterates, layout [column][k]
   __shared__ double sh[KSPEC][TPB / 64];
   const int K = *ndone;
   const int kl = 1 << kl_log2;
   if (LDS) {
-    for (int t = threadIdx.x; t < KSPEC * d; t += TPB) {
-      const int c = t / KSPEC, k = t % KSPEC;
+    for (int t = threadIdx.x; t < (d << kl_log2); t += TPB) {           // [column][kl]: only the batch's iterates are staged
+      const int c = t >> kl_log2, k = t & (kl - 1);
       lm_lds[t] = k < K ? hist[(i64)k * d + c] : 0.0;
     }
     __syncthreads();
@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(TPB) void k_loss_multi(const i64* __restrict__ rowp
       for (int u = 0; u < 4; u++) { const bool h = p + u < e; c4[u] = h ? col[p + u] : 0u; v4[u] = h ? val[p + u] : 0.0; }
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        if (p + u < e) r += v4[u] * (LDS ? lm_lds[(size_t)c4[u] * KSPEC + k] : hist[(i64)k * d + c4[u]]);
+        if (p + u < e) r += v4[u] * (LDS ? lm_lds[((size_t)c4[u] << kl_log2) + k] : hist[(i64)k * d + c4[u]]);
     }
     const double rr = (LDS ? lm_lds[k] : hist[(i64)k * d]) + r;            // theta[0] + sum
     const double l1p = log1p(exp(-fabs(rr)));
@@ -1581,7 +1581,7 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
   // sweeps per speculative batch: a batch costs ~45 us beside its sweeps (launches, loss pass, report, host turn) and
   // wastes (K-1)/2 sweeps on average when the loss rule stops it; a sweep is ~8 us at d = 101 and ~67 us at d = 501:
   // small problems want full batches, large ones shorter ones (measured at d = 501: 8 -> 190 ms, 4 -> 180, 2 -> 187)
-  const int batch_k = ctx_opt(ctx, "KLR_CD_BATCH") ? std::max(1, std::min(KSPEC, atoi(ctx_opt(ctx, "KLR_CD_BATCH")))) : (d <= 128 ? KSPEC : KSPEC / 2);
+  const int batch_k = ctx_opt(ctx, "KLR_CD_BATCH") ? std::max(1, std::min(KSPEC, atoi(ctx_opt(ctx, "KLR_CD_BATCH")))) : (d <= 128 ? 8 : 4);
   const bool dbg_sync = ctx_opt(ctx, "KLR_CD_DEBUG") && atoi(ctx_opt(ctx, "KLR_CD_DEBUG")) >= 2;
 #define DBG_STEP(name) do { if (dbg_sync) { hipError_t e_ = hipStreamSynchronize(st); fprintf(stderr, "[cd] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
   for (i64 iter = 0; iter < max_iter; iter++, relin++) {
@@ -1736,15 +1736,16 @@ extern "C" int klr_cd_solve(klr_ctx* ctx, const klr_mat* red, double* theta, con
         while ((1 << kl_log2) < Kb) kl_log2++;
         const bool lm_small = kl_log2 == 0 && n >= 64 * 256;         // a probe batch: blocks of 256 rows
         const i64 nbl = std::max<i64>(1, ceil_div(n, (i64)((lm_small ? 256 : LM_THREADS) >> kl_log2)));
-        const bool lm_lds = (double)d <= (double)LM_ROWS * std::max(2.0, red->avg_row) && (size_t)KSPEC * d * 8 <= 48 * 1024;
+        const size_t lm_bytes = ((size_t)d << kl_log2) * 8;
+        const bool lm_lds = (double)d <= (double)(LM_THREADS >> kl_log2) * std::max(2.0, red->avg_row) && lm_bytes <= 48 * 1024;
         if (lm_small && lm_lds)
-          hipLaunchKernelGGL((k_loss_multi<true, 256>), dim3((unsigned)nbl), dim3(256), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
+          hipLaunchKernelGGL((k_loss_multi<true, 256>), dim3((unsigned)nbl), dim3(256), lm_bytes, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
         else if (lm_small)
           hipLaunchKernelGGL((k_loss_multi<false, 256>), dim3((unsigned)nbl), dim3(256), 0, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
         else if (lm_lds)
-          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nbl), dim3(LM_THREADS), (size_t)KSPEC * d * 8, st, red->rowptr, red->col,
+          hipLaunchKernelGGL(k_loss_multi<true>, dim3((unsigned)nbl), dim3(LM_THREADS), lm_bytes, st, red->rowptr, red->col,
                              (const double*)red->val, red->labels, red->active, n, d, hist, ndone, cw[0], cw[1], lossb, kl_log2);
         else
           hipLaunchKernelGGL(k_loss_multi<false>, dim3((unsigned)nbl), dim3(LM_THREADS), 0, st, red->rowptr, red->col,
