@@ -48,6 +48,7 @@ int         klr_ctx_create(int device_id, klr_ctx** out);
  * what the same re-linearisation took in the solve before -- a matter of speed, the iterates do not depend on it; the call
  * forgets that history (klr_estimator_estimate makes it through the backend table). */
 void        klr_solve_run_begin(klr_ctx* ctx);
+void        klr_solve_run_end(klr_ctx* ctx);          /* later solves start without a history again */
 /* A second context on the same device with the switches of `parent` (own stream, own workspaces), for concurrent work on
  * shared data from another host thread: one fold of a cross-validation per context, on klr_mat_view's of the data
  * (klr_config.threads_cv; the reference runs its folds in threads too, kmerLr_crossvalidation.go:176).  A context with

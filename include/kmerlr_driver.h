@@ -53,6 +53,7 @@ typedef struct klr_backend {
    * batch of sweeps of a re-linearisation by what the same re-linearisation took in the solve before (the iterates do not
    * depend on it); the call forgets that history, so that a run is the same whatever the context did before */
   void (*solve_run_begin)(klr_ctx*);
+  void (*solve_run_end)(klr_ctx*);       /* the run is over: later solves on the context start without a history again */
 } klr_backend;
 
 /* the HIP table for an existing context */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "klr_ctx_create": (_int, [_int, _PVP]),
     "klr_ctx_destroy": (None, [_vp]),
     "klr_solve_run_begin": (None, [_vp]),
+    "klr_solve_run_end": (None, [_vp]),
     "klr_ctx_fork": (_int, [_vp, C.POINTER(_vp)]),
     "klr_ctx_release": (None, [_vp]),
     "klr_last_error": (C.c_char_p, [_vp]),

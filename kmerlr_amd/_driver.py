@@ -13,7 +13,7 @@ class Backend(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ctx", "last_error", "mat_shape", "mat_destroy", "class_weights", "gradient",
                                           "loss", "select_columns", "sweep_select", "cd_solve", "set_active_rows",
                                           "log_pdf", "expand_cooccurrence", "transform_fit", "ctx_fork", "ctx_release",
-                                          "mat_view", "solve_run_begin")]
+                                          "mat_view", "solve_run_begin", "solve_run_end")]
 
 
 class Config(C.Structure):

@@ -434,6 +434,12 @@ extern "C" void klr_solve_run_begin(klr_ctx* ctx) {
   ctx->cd_pred_on = !ctx_opt(ctx, "KLR_CD_NO_PREDICT");
 }
 
+extern "C" void klr_solve_run_end(klr_ctx* ctx) {
+  if (!ctx) return;
+  ctx->cd_pred.clear();
+  ctx->cd_pred_on = false;
+}
+
 extern "C" int klr_ctx_set_collectives(klr_ctx* ctx, klr_reduce_scatter_fn rs, klr_allgather_fn ag, void* user) {
   if (!ctx) return klr_fail(nullptr, KLR_EINVAL, "ctx is NULL");
   KLR_ARG(ctx, (rs == nullptr) == (ag == nullptr));
@@ -717,5 +723,6 @@ extern "C" int klr_hip_backend(klr_ctx* ctx, klr_backend* out) {
   out->ctx_release = klr_ctx_release;
   out->mat_view = klr_mat_view;
   out->solve_run_begin = klr_solve_run_begin;
+  out->solve_run_end = klr_solve_run_end;
   return KLR_OK;
 }

@@ -325,6 +325,7 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
     rc = fail(e, KLR_EINVAL, "no classifier was estimated (max_epochs = %lld)", (long long)e->cfg.max_epochs);
   }
   if (red) e->be.mat_destroy(red);
+  if (e->be.solve_run_end) e->be.solve_run_end(e->be.ctx);
   return rc;
 }
 

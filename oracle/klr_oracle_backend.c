@@ -202,6 +202,7 @@ void klo_backend_table(klr_backend* out) {
   out->ctx_release = ob_ctx_release;
   out->mat_view = ob_mat_view;
   out->solve_run_begin = 0;
+  out->solve_run_end = 0;
 }
 
 void klo_backend_mat_destroy(klr_mat* m) { ob_mat_destroy(m); }
