@@ -249,6 +249,9 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
   if (e->cols.size() > 1) { if ((rc = rebuild()) != KLR_OK) return rc; }
 
   std::vector<uint8_t> b((size_t)dim);
+  double prev_lambda = NAN;
+  std::vector<int64_t> prev_cols;
+  int stuck = 0;
   // -vvv: where the host's time goes (seconds in the backend's sweep_select / select_columns / reduced solve, and in between)
   double t_sweep = 0.0, t_sub = 0.0, t_solve = 0.0;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -306,6 +309,18 @@ static int estimate_common(klr_estimator* e, const klr_mat* data, const double* 
     int64_t nz = 0;
     for (size_t j = 1; j < e->theta.size(); j++) if (e->theta[j] != 0.0) nz++;
     e->ep_lambda.push_back(lambda); e->ep_nonzero.push_back(nz);
+    // Epochs that end where the one before ended -- the same columns, lambda within 1e-12 of the last -- while the selection
+    // still reports a change will go on for ever: a model with more non-zero coefficients than lambda_auto asks for (a
+    // warm start from a larger model): nothing is ever removed, `c > N` keeps `ok` set (kmerLr_feature_selection.go:117-119)
+    // and lambda creeps to a fixed point.  The reference spins there; three such epochs in a row end the run with an error.
+    if (have && lambda_auto && nz > N && e->cols == prev_cols && std::fabs(lambda - prev_lambda) <= 1e-12 * std::fabs(lambda)) stuck++;
+    else stuck = 0;
+    if (stuck >= 3) {
+      rc = fail(e, KLR_EINVAL, "the leapfrog loop makes no progress (lambda = %g, %lld non-zero coefficients for lambda_auto = %lld): "
+                               "a model with more non-zero coefficients than features to select?", lambda, (long long)nz, (long long)N);
+      break;
+    }
+    prev_lambda = lambda; prev_cols = e->cols;
     have = true;
   }
   say(e, 3, "leapfrog loop: %.3f ms in all, sweep + selection %.3f, column sub-select %.3f, reduced solve %.3f, the driver itself %.3f\n",

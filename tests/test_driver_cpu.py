@@ -572,3 +572,16 @@ def test_ensemble_members_in_threads_change_nothing():
     for a, b in zip(ca, cb):
         np.testing.assert_array_equal(a["cols"], b["cols"])
         np.testing.assert_array_equal(a["theta"], b["theta"])
+
+
+def test_a_model_with_more_coefficients_than_asked_for_ends_with_an_error():
+    """Warm start from 6 features into lambda_auto = 5: the selection never removes a feature and `c > N` keeps the loop
+    alive (kmerLr_feature_selection.go:117-119) -- the reference spins; here three epochs without progress end the run."""
+    x, labels = O.synth_csr(43, 0, 600, 600, 256, 60, 8)
+    h = OD.matrix(x, labels)
+    est = OD.estimator()
+    est.estimate(h, [6])
+    with pytest.raises(Exception, match="makes no progress"):
+        est.estimate(h, [5])
+    assert len(est.epochs()[0]) < 200
+    OD.free_matrix(h)
