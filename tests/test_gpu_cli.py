@@ -364,6 +364,86 @@ def test_ensemble_with_fixed_lambda_cli(tmp_path):
     OD.free_matrix(h)
 
 
+def test_kmers5_standardizer_fasta_cli(tmp_path):
+    # TestKmers5 (kmerLr_test.go:155-190): learn --lambda-auto=2 --epsilon=0 --epsilon-loss=1e-10 --revcomp
+    # --data-transform=standardizer 2 6 on the bundled FASTA files; then loss with lambda = 4.460029
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
+    run(["learn", "--lambda-auto=2", "--epsilon=0", "--epsilon-loss=1e-10", "--revcomp", "--data-transform=standardizer", "2", "6", fg, bg, "k5"], tmp_path)
+    m = json.load(open(tmp_path / "k5.json"))
+    theta = m["Distributions"][0]["Parameters"]
+    ref = [5.552570741538388e-05, -0.00772452196477929, 0.09287154394711336]                     # :168-174
+    assert len(theta) == 3 and m["Parameters"]["Features"] == [[0, 0], [1, 1]]                  # :165, :177-185
+    # the reference's theta is SAGA's early-stopped iterate (its own tolerance 1e-5); the coordinate-descent optimum of the
+    # same problem lies 2e-5 from it
+    np.testing.assert_allclose(theta, ref, atol=5e-5)
+    out = run(["loss", "--lambda=4.460029", "k5.json", fg, bg], tmp_path).stdout
+    assert abs(float(out) - 1.107745182633717) < 1e-4                                            # :186 (its tolerance)
+    # the reference's own theta through OUR counter, standardizer and loss: its number to the printed precision
+    m["Distributions"][0]["Parameters"] = ref
+    json.dump(m, open(tmp_path / "k5_ref.json", "w"))
+    out = run(["loss", "--lambda=4.460029", "k5_ref.json", fg, bg], tmp_path).stdout
+    assert abs(float(out) - 1.107745182633717) < 2e-6
+
+
+def read_fasta_seqs(path):
+    seqs, cur = [], None
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur is not None:
+                seqs.append(cur)
+            cur = ""
+        elif cur is not None:
+            cur += line
+    if cur is not None:
+        seqs.append(cur)
+    return seqs
+
+
+def test_scores4_kmer_counts_as_a_scores_table_cli(tmp_path):
+    # TestScores4 (scoresLr_test.go:161-199): kmerLr learn --lambda-auto=3 2 6 on the FASTA files against scoresLr learn
+    # --header on the exported count tables: the same coefficients (1e-10) and the k-mer names as feature names.  The
+    # reference's `export` command is out of scope; the tables are written here from the device counter's own counts.
+    import kmerlr_amd as K
+    fg, bg = os.path.join(GOLDEN, "kmerLr_test_fg.fa"), os.path.join(GOLDEN, "kmerLr_test_bg.fa")
+    run(["learn", "--lambda-auto=3", "2", "6", fg, bg, "s1"], tmp_path)
+    ctx = K.Context(0)
+    kc = K.KmerClasses(2, 6)
+    names = [kc.name(c) for c in range(len(kc))]
+    for src, label, out in ((fg, 1, "exp_fg.table"), (bg, 0, "exp_bg.table")):
+        seqs = read_fasta_seqs(src)
+        mt = K.Matrix.from_sequences(ctx, seqs, [label] * len(seqs), classes=kc)
+        rowptr, col, val = mt.to_csr()
+        dense = np.zeros((mt.n, mt.dim))
+        for i in range(mt.n):
+            dense[i, col[rowptr[i]:rowptr[i + 1]]] = val[rowptr[i]:rowptr[i + 1]]
+        with open(tmp_path / out, "w") as f:
+            f.write(",".join(names) + "\n")
+            for r in dense[:, 1:]:
+                f.write(",".join("%d" % v for v in r) + "\n")
+        mt.close()
+    run(["--type=scoresLr", "learn", "--lambda-auto=3", "--header", "exp_fg.table", "exp_bg.table", "s2"], tmp_path)
+    m1, m2 = json.load(open(tmp_path / "s1.json")), json.load(open(tmp_path / "s2.json"))
+    t1, t2 = m1["Distributions"][0]["Parameters"], m2["Distributions"][0]["Parameters"]
+    assert len(t1) == len(t2) == 4
+    np.testing.assert_allclose(t1, t2, rtol=0, atol=1e-10)                                        # :178-187
+    assert m1["Parameters"]["Kmers"] == m2["Parameters"]["Names"]                                # :188-193
+    kc.close(); ctx.close()
+
+
+def test_kmers34_no_explicit_zeros_in_the_count_rows():
+    # TestKmers3 / TestKmers4 (kmerLr_test.go:99-153) assert one thing: the sparse rows of the 8-mer + revcomp count data
+    # hold no explicit zero (their estimates run the fixed-lambda = 0 branch over all 32,896 classes: SURVEY.md section 4)
+    import kmerlr_amd as K
+    ctx = K.Context(0)
+    seqs = read_fasta_seqs(os.path.join(GOLDEN, "kmerLr_test_fg.fa")) + read_fasta_seqs(os.path.join(GOLDEN, "kmerLr_test_bg.fa"))
+    mt = K.Matrix.from_sequences(ctx, seqs, [1] * 11 + [0] * 11, M=8, N=8, revcomp=True)
+    rowptr, col, val = mt.to_csr()
+    assert mt.dim == 32896 + 1 and len(val) == rowptr[-1] > 22 and np.all(val != 0.0)
+    assert np.all(col[rowptr[:-1]] == 0) and np.all(val[rowptr[:-1]] == 1.0)                     # every row starts with the bias entry
+    mt.close(); ctx.close()
+
+
 def test_kmers6_cooccurrence_fasta_cli(tmp_path):
     # TestKmers6 (kmerLr_test.go:192-268): learn --lambda-auto=2 --binarize --revcomp --co-occurrence 2 6 on the co_*.fa
     # files.  Every fg sequence carries both motifs, every bg sequence one of them twice: no single k-mer separates
