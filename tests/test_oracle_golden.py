@@ -282,3 +282,29 @@ def test_golden_scores2_cooccurrence_selection(golden_dir):
     picked = np.nonzero(b2)[0][1:]
     assert len(picked) == 1
     assert O.coeff_sub2ind(dense.shape[1], int(picked[0]) - 1) == (1, 2)
+
+
+def test_kmers5_standardizer_revcomp_loss_golden():
+    """TestKmers5 (kmerLr_test.go:155-190): learn --lambda-auto=2 --epsilon=0 --epsilon-loss=1e-10 --revcomp
+    --data-transform=standardizer 2 6 on the bundled FASTA files.  The reference's theta (SAGA's early-stopped iterate) on the
+    two classes the oracle's own leapfrog run selects, through the standardizer fitted here, gives the reference's loss
+    1.107745182633717 (lambda = 4.460029) to the last digit: revcomp class counting, TransformFull.Fit and Loss are pinned
+    together (G8); the oracle's own optimum lies 2e-5 from that theta and 6e-5 in the loss (the test's tolerances: 1e-5 on a
+    theta that is 1 % from the optimum, 1e-4)."""
+    from tests import oracle_driver as OD
+    from tests.conftest import GOLDEN
+    from tests.test_gpu_ingest import read_fasta, host_counts
+    seqs = read_fasta(os.path.join(GOLDEN, "kmerLr_test_fg.fa")) + read_fasta(os.path.join(GOLDEN, "kmerLr_test_bg.fa"))
+    labels = np.array([1] * 11 + [0] * 11, dtype=np.uint8)
+    x = host_counts(seqs, 2, 6, revcomp=True)
+    sc, of = O.transform_fit(x, "standardizer")
+    h = OD.matrix(x, labels)
+    c = OD.estimator(epsilon=0.0, epsilon_loss=1e-10).estimate(h, [2], scale=sc, offset=of)[0]
+    OD.free_matrix(h)
+    cols = c["cols"]
+    assert len(cols) == 3
+    ref = np.array([5.552570741538388e-05, -0.00772452196477929, 0.09287154394711336])          # :168-174
+    red = O.select_columns(x, cols, sc[cols], of[cols])
+    assert abs(O.loss(red, labels, ref, lam=4.460029) - 1.107745182633717) < 1e-14              # :186
+    np.testing.assert_allclose(c["theta"], ref, atol=5e-5)
+    assert abs(O.loss(red, labels, c["theta"], lam=4.460029) - 1.107745182633717) < 1e-4
