@@ -174,7 +174,8 @@ def test_kmers1_known_answers_gapped_revcomp(ctx):
     """TestKmers1 (kmerLr_test.go:30-66), the only counting known-answers the reference holds: M = 4, N = 8, revcomp,
     gapped nucleotide alphabet on kmerLr_test.fa; row 0: gntanc|gntanc = 3, gntcaa|ttganc = 0, aaagaaa|tttcttt = 1,
     aagannt|anntctt = 7, aacgcgna|tncgcgtt = 1, tgaatgca|tgcattca = 1; the pair feature (gntanc, aagannt) = 21.
-    Classes are addressed by NAME: gonetics' own class numbering (4671, 5486, ...) cannot be reproduced offline."""
+    Classes are addressed by NAME here; that the reference's six INDICES (4671, 5486, ... among the observed classes) come out
+    of this library's class order too is tests/test_kmers_cpu.py."""
     seqs, cur = [], []
     for line in open(os.path.join(GOLDEN, "kmerLr_test.fa")):
         line = line.strip()
