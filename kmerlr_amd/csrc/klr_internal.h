@@ -27,6 +27,10 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// coefficients of a reduced problem that ride in the row pass's kernel arguments instead of an upload (4 KiB; the runtime
+// takes kernel arguments of 8 KiB and more)
+#define KLR_THETA_INLINE_MAX 512
+
 enum {
   WS_S = 0,        // per-row weights s_i / w_i (f64[n])
   WS_Z,            // IRLS working response (f64[n])
@@ -273,7 +277,7 @@ enum { ROW_SWEEP = 0, ROW_LOSS = 1, ROW_IRLS = 2, ROW_LOGPDF = 3, ROW_SWEEP_FIX 
 // loss_acc_dev (nullable) is OVERWRITTEN with the local sum (deterministic two-stage reduction).
 int   launch_row_pass(klr_ctx* ctx, const klr_mat* mat, const double* theta_dev, int mode,
                       const double cw[2], double* out0, double* out1, double* loss_acc_dev,
-                      const double* theta_host = nullptr, i64 theta_len = 0);   // theta_host (<= 128): in the kernel arguments
+                      const double* theta_host = nullptr, i64 theta_len = 0);   // theta_host (<= KLR_THETA_INLINE_MAX): in the kernel arguments
 // out0 for rows when theta has only a bias (no matrix access)
 int   launch_row_const(klr_ctx* ctx, const klr_mat* mat, double theta0, int mode, const double cw[2],
                        double* out0, double* out1, double* loss_acc_dev);

@@ -1107,7 +1107,7 @@ extern "C" int klr_sweep_select(klr_ctx* ctx, const klr_mat* full, const klr_mat
     KLR_TRY(ws_get(ctx, WS_THETA, (size_t)c_plus_1 * sizeof(double), (void**)&thd));
     // count data and a small reduced problem: theta rides in the row pass's kernel arguments (a 1 KB upload
     // is a 5 us blit kernel of its own)
-    theta_inline = use_int && c_plus_1 <= 128;
+    theta_inline = use_int && c_plus_1 <= KLR_THETA_INLINE_MAX;
     if (!theta_inline) KLR_TRY(h2d(ctx, thd, theta_red, (size_t)c_plus_1 * sizeof(double)));
   }
   bool keys_ready = false, restored = false;

@@ -34,7 +34,7 @@ __device__ __forceinline__ double group_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // row pass: G lanes per row
 // ---------------------------------------------------------------------------------------------
-#define THETA_INLINE_MAX 128
+#define THETA_INLINE_MAX KLR_THETA_INLINE_MAX
 #define THETA_LDS_MAX 2048        // a reduced problem's theta up to this length is staged in LDS by every block (16 KiB)
 struct RowPassArgs {
   const i64* rowptr; const u32* col; const void* val; const uint8_t* labels; const uint8_t* active;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_row_pass(RowPassArgs a) {
   }
   const bool inl = a.theta_inline_n > 0 || a.theta_lds_n > 0;   // theta of a reduced problem: kernel arguments / device -> LDS
   if (a.theta_inline_n > 0) {
-    if ((int)threadIdx.x < a.theta_inline_n) sth[threadIdx.x] = a.theta_inline[threadIdx.x];
+    for (int i = threadIdx.x; i < a.theta_inline_n; i += 256) sth[i] = a.theta_inline[i];
     __syncthreads();
   } else if (a.theta_lds_n > 0) {
     for (int i = threadIdx.x; i < a.theta_lds_n; i += 256) sth[i] = a.theta[i];
