@@ -812,7 +812,7 @@ int main(int argc, char** argv) {
     // Not given: up to four folds at once on one rank (the results do not depend on it; the reference's default of one
     // fold at a time leaves the card idle between the small kernels of a fold's solves: 117 against 58 ms for five folds).
     cfg.threads_cv = o.kv.count("threads-cv") ? (int)opt_int(o, "threads-cv", "1") : 4;
-    cfg.threads = (int)opt_int(go, "threads", "1");                      // config.Pool: the members of an ensemble (:81)
+    cfg.threads = go.kv.count("threads") ? (int)opt_int(go, "threads", "1") : 4;   // config.Pool: the members of an ensemble (:81), likewise
     if (cfg.threads_cv < 1) die("invalid --threads-cv");
     if (flag(o, "adaptive-step-size") || flag(o, "scale-step-size")) say(1, "note: the step-size options belong to the reference's SAGA solver and have no effect here\n");
     const int kfold = (int)opt_int(o, "k-fold-cv", "1");
